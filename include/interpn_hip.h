@@ -1,0 +1,198 @@
+/*
+ * interpn_hip.h — C ABI of libinterpn_hip.so: MI355X (gfx950) implementation of the batched
+ * per-observation-point hot path of jlogan03/interpn v0.8.2.
+ *
+ * What it replaces (paths relative to the reference repository):
+ *   multilinear::regular::interpn       src/multilinear/regular.rs:51-117
+ *   multilinear::rectilinear::interpn   src/multilinear/rectilinear.rs:49-83
+ *   multicubic::regular::interpn        src/multicubic/regular.rs:52-136
+ *   multicubic::rectilinear::interpn    src/multicubic/rectilinear.rs:54-104
+ * and who would call it: the bodies of the PyO3 functions interpn_{linear,cubic}_
+ * {regular,rectilinear}_{f64,f32} (src/python.rs:55-85, 119-147, 228-292) through a Rust
+ * `hip_sys` extern block (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - Every Rust slice `&[T]` crosses the boundary as (pointer, length); a slice of slices
+ *     `&[&[T]]` as (array of pointers, array of lengths, count).  All buffers are borrowed for
+ *     the duration of the call only; nothing is retained after a function returns, except the
+ *     device copies a handle owns (and a device `vals` buffer lent with INTERPN_HIP_MEM_DEVICE,
+ *     which must outlive the handle).
+ *   - `vals` is C-ordered; `obs` is struct-of-arrays (one array per dimension); `out` has one
+ *     element per observation point and is written only in [0, nout).
+ *   - Return value: 0 on success, otherwise an interpn_hip_status.  interpn_hip_strerror()
+ *     returns, for the statuses that mirror a reference error, the reference's exact
+ *     `&'static str` (what src/python.rs turns into AssertionError(msg)).
+ *   - INTERPN_HIP_ERR_UNREPRESENTABLE ("Unrepresentable coordinate value"): the reference
+ *     aborts the batch at the first failing point i with out[0..i) written and out[i..]
+ *     untouched.  The host-pointer entry points reproduce exactly that.  The device-pointer
+ *     entry point reports i through interpn_hip_finish(); device `out[i..]` is unspecified.
+ *   - Conditions on which the reference *panics* (mismatched slice lengths in
+ *     multicubic::*::interpn, usize overflow) return INTERPN_HIP_ERR_REFERENCE_PANIC instead
+ *     of aborting the process.
+ *   - Numerics follow the reference's `fma` cargo feature ON (what every published wheel is
+ *     built with, pyproject.toml:72); interpn_hip_set_fma(0) selects the non-fused flavour
+ *     (plain `cargo test`).  Results are bit-identical to the Rust code of the same flavour.
+ *   - Thread safety: all functions are re-entrant; concurrent evaluation on one handle is
+ *     allowed (the grid is read-only), but the sticky first-bad-index word of a handle is
+ *     shared by its in-flight device evaluations.
+ */
+#ifndef INTERPN_HIP_H
+#define INTERPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum interpn_hip_status {
+  INTERPN_HIP_OK = 0,
+  /* mirrors of the reference's error strings */
+  INTERPN_HIP_ERR_DIM_MISMATCH = 1,      /* "Dimension mismatch" */
+  INTERPN_HIP_ERR_MIN_TWO_ENTRIES = 2,   /* "All grids must have at least two entries"  multilinear/regular.rs:245 */
+  INTERPN_HIP_ERR_MIN_2_ENTRIES = 3,     /* "All grids must have at least 2 entries"    multilinear/rectilinear.rs:192 */
+  INTERPN_HIP_ERR_MIN_FOUR_ENTRIES = 4,  /* "All grids must have at least four entries" multicubic/regular.rs:261 */
+  INTERPN_HIP_ERR_MIN_4_ENTRIES = 5,     /* "All grids must have at least 4 entries"    multicubic/rectilinear.rs:214 */
+  INTERPN_HIP_ERR_NOT_MONOTONIC = 6,     /* "All grids must be monotonically increasing" */
+  INTERPN_HIP_ERR_UNREPRESENTABLE = 7,   /* "Unrepresentable coordinate value"          multilinear/regular.rs:418 */
+  INTERPN_HIP_ERR_TOO_MANY_DIMS = 8,     /* "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions." */
+  INTERPN_HIP_ERR_REFERENCE_PANIC = 9,   /* the reference would panic here */
+  /* statuses of this implementation */
+  INTERPN_HIP_ERR_INVALID_ARGUMENT = 32, /* null pointer, unknown enum value, dtype mismatch */
+  INTERPN_HIP_ERR_UNSUPPORTED = 33,      /* axis longer than 2^31-257 points (f32: 2^24) */
+  INTERPN_HIP_ERR_NO_DEVICE = 34,        /* no usable HIP device */
+  INTERPN_HIP_ERR_OUT_OF_MEMORY = 35,    /* device or pinned-host allocation failed */
+  INTERPN_HIP_ERR_HIP = 36               /* any other HIP runtime failure (see interpn_hip_last_hip_error) */
+} interpn_hip_status;
+
+enum { INTERPN_HIP_LINEAR = 0, INTERPN_HIP_CUBIC = 1 };        /* method */
+enum { INTERPN_HIP_MEM_HOST = 0, INTERPN_HIP_MEM_DEVICE = 1 }; /* where a buffer lives */
+
+const char* interpn_hip_strerror(int status);
+/* Text of the last HIP runtime error seen by the calling thread ("" if none). */
+const char* interpn_hip_last_hip_error(void);
+/* Library version "major.minor.patch". */
+const char* interpn_hip_version(void);
+/* Select the reference's `fma` feature flavour for interpolators created afterwards
+ * (process-wide; default 1).  Returns the previous value. */
+int interpn_hip_set_fma(int enabled);
+/* Number of visible HIP devices (0 when none; never fails). */
+int interpn_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot entry points, host pointers — drop-in for the calls made inside the PyO3 bodies.
+ * They build the interpolator, move the batch through the current HIP device in chunks and
+ * return when `out` is complete.
+ *
+ * interpn_hip_linear_regular_*      <- multilinear::regular::interpn(dims, starts, steps, vals, obs, out)
+ *                                      src/python.rs:69-76
+ * interpn_hip_linear_rectilinear_*  <- multilinear::rectilinear::interpn(grids, vals, obs, out)
+ *                                      src/python.rs:133-138
+ * interpn_hip_cubic_regular_*       <- multicubic::regular::interpn(dims, starts, steps, vals,
+ *                                      linearize_extrapolation, obs, out)  src/python.rs:243-251
+ * interpn_hip_cubic_rectilinear_*   <- multicubic::rectilinear::interpn(grids, vals,
+ *                                      linearize_extrapolation, obs, out)  src/python.rs:277-283
+ * ---------------------------------------------------------------------------------------- */
+#define INTERPN_HIP_DECLARE_ONESHOT(T, SUFFIX)                                                            \
+  int interpn_hip_linear_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,             \
+                                          size_t nstarts, const T* steps, size_t nsteps, const T* vals,  \
+                                          size_t nvals, const T* const* obs, const size_t* obs_lens,     \
+                                          size_t nobs, T* out, size_t nout);                             \
+  int interpn_hip_linear_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,            \
+                                              size_t ngrids, const T* vals, size_t nvals,                \
+                                              const T* const* obs, const size_t* obs_lens, size_t nobs,  \
+                                              T* out, size_t nout);                                      \
+  int interpn_hip_cubic_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,              \
+                                         size_t nstarts, const T* steps, size_t nsteps, const T* vals,   \
+                                         size_t nvals, int linearize_extrapolation, const T* const* obs, \
+                                         const size_t* obs_lens, size_t nobs, T* out, size_t nout);      \
+  int interpn_hip_cubic_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,             \
+                                             size_t ngrids, const T* vals, size_t nvals,                 \
+                                             int linearize_extrapolation, const T* const* obs,           \
+                                             const size_t* obs_lens, size_t nobs, T* out, size_t nout);
+
+INTERPN_HIP_DECLARE_ONESHOT(double, f64)
+INTERPN_HIP_DECLARE_ONESHOT(float, f32)
+
+/* ------------------------------------------------------------------------------------------
+ * Persistent interpolators — the counterpart of MultilinearRegular::new / MulticubicRegular::new
+ * ... (src/multilinear/regular.rs:225-259, rectilinear.rs:175-201, multicubic/regular.rs:239-288,
+ * rectilinear.rs:193-228) whose grid stays resident in HBM between evaluations, and of
+ * `.interp(obs, out)` (regular.rs:268-283 etc.).  This is the surface the Python classes'
+ * `.eval()` sits on (src/interpn/multilinear_regular.py:101-168).
+ *
+ * `method`  INTERPN_HIP_LINEAR | INTERPN_HIP_CUBIC
+ * `vals_mem` INTERPN_HIP_MEM_HOST: `vals` is copied to the device;
+ *            INTERPN_HIP_MEM_DEVICE: `vals` is a device pointer on `device`, borrowed (e.g. the
+ *            buffer an RCCL broadcast just filled on this rank).
+ * `device`  HIP device ordinal, or -1 for the calling thread's current device.
+ * Validation (order and messages) is the reference's `new`.  Axis coordinates, starts and steps
+ * are always host pointers (they are a few KiB).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct interpn_hip_interp interpn_hip_interp;
+
+#define INTERPN_HIP_DECLARE_CREATE(T, SUFFIX)                                                             \
+  int interpn_hip_create_regular_##SUFFIX(int method, const size_t* dims, size_t ndims, const T* starts, \
+                                          size_t nstarts, const T* steps, size_t nsteps, const T* vals,  \
+                                          size_t nvals, int vals_mem, int linearize_extrapolation,       \
+                                          int device, interpn_hip_interp** handle);                      \
+  int interpn_hip_create_rectilinear_##SUFFIX(int method, const T* const* grids,                         \
+                                              const size_t* grid_lens, size_t ngrids, const T* vals,     \
+                                              size_t nvals, int vals_mem, int linearize_extrapolation,   \
+                                              int device, interpn_hip_interp** handle);
+
+INTERPN_HIP_DECLARE_CREATE(double, f64)
+INTERPN_HIP_DECLARE_CREATE(float, f32)
+
+/* sizeof of the element type of the interpolator (8 or 4), number of dimensions, device. */
+int interpn_hip_elem_size(const interpn_hip_interp* h);
+int interpn_hip_ndims(const interpn_hip_interp* h);
+int interpn_hip_device(const interpn_hip_interp* h);
+
+/* Evaluate on host arrays (synchronous).  `obs`/`out` element type must be the handle's.
+ * Mirrors `.interp(obs, out)`: "Dimension mismatch" unless nobs == ndims and every
+ * obs_lens[d] == nout; abort-at-first-bad-point semantics as described above. */
+int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const size_t* obs_lens,
+                          size_t nobs, void* out, size_t nout);
+
+/* Evaluate on device arrays (asynchronous on `stream`, a hipStream_t; NULL = default stream).
+ * `obs` is a HOST array of `nobs` DEVICE pointers, each to `npoints` elements; `out` is a device
+ * pointer to `npoints` elements.  Returns as soon as the kernel is enqueued. */
+int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out,
+                            size_t npoints, void* stream);
+
+/* Wait for `stream` and report the sticky status of the device evaluations enqueued since the
+ * last finish: 0, or INTERPN_HIP_ERR_UNREPRESENTABLE with the smallest failing point index
+ * (relative to the evaluation it occurred in) in *first_bad_index.  Clears the sticky word. */
+int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_index);
+
+/* Tuning knob: workgroups per CU the launch grid is sized for (default 8). */
+int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu);
+
+void interpn_hip_destroy(interpn_hip_interp* h);
+
+/* ------------------------------------------------------------------------------------------
+ * check_bounds (src/multilinear/regular.rs:145-182, rectilinear.rs:109-134; exported to Python
+ * as check_bounds_{regular,rectilinear}_{f64,f32}, src/python.rs:87-117, 203-226).
+ * out[d] = 1 if any observation violates the bounds of dimension d by atol or more.
+ * Host pointers; streamed through the current device.
+ * ---------------------------------------------------------------------------------------- */
+#define INTERPN_HIP_DECLARE_BOUNDS(T, SUFFIX)                                                            \
+  int interpn_hip_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,      \
+                                                size_t nstarts, const T* steps, size_t nsteps,          \
+                                                const T* const* obs, const size_t* obs_lens,            \
+                                                size_t nobs, T atol, uint8_t* out, size_t nout);        \
+  int interpn_hip_check_bounds_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,     \
+                                                    size_t ngrids, const T* const* obs,                 \
+                                                    const size_t* obs_lens, size_t nobs, T atol,        \
+                                                    uint8_t* out, size_t nout);
+
+INTERPN_HIP_DECLARE_BOUNDS(double, f64)
+INTERPN_HIP_DECLARE_BOUNDS(float, f32)
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* INTERPN_HIP_H */

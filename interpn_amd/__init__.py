@@ -1,0 +1,107 @@
+"""interpn_amd — MI355X (gfx950) implementation of the batched per-observation-point hot path of
+jlogan03/interpn (multilinear / multicubic interpolation on regular and rectilinear grids).
+
+The public names mirror the reference's Python package (src/interpn/__init__.py): `interpn()`,
+`raw`, and the `Multilinear*/Multicubic*` classes.  Everything evaluates through the HIP kernels
+behind the C ABI of include/interpn_hip.h; there is no CPU evaluation path in this package.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import Literal
+
+import numpy as np
+
+from . import _lib, raw
+from .classes import MulticubicRectilinear, MulticubicRegular, MultilinearRectilinear, MultilinearRegular
+from .handle import Interpolator
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "__version__",
+    "raw",
+    "interpn",
+    "Interpolator",
+    "MultilinearRegular",
+    "MultilinearRectilinear",
+    "MulticubicRegular",
+    "MulticubicRectilinear",
+]
+
+
+def interpn(
+    obs: Sequence,
+    grids: Sequence,
+    vals,
+    *,
+    method: Literal["linear", "cubic"] = "linear",
+    out=None,
+    linearize_extrapolation: bool = True,
+    assume_regular: bool = False,
+    check_bounds: bool = False,
+    bounds_atol: float = 1e-8,
+):
+    """Evaluate an N-dimensional grid at the supplied observation points.
+
+    Same contract as the reference's helper (src/interpn/__init__.py:48-194): inputs are
+    ravelled and made contiguous, the dtype is taken from `vals` (float64 / float32), a grid is
+    treated as regular iff every axis has exactly equal spacing (`_check_regular`, :197-203)
+    or `assume_regular` is set, and the call dispatches to the matching raw function (:135-192).
+    `method="nearest"` is outside the hot path this package implements and raises ValueError.
+    """
+    # src/interpn/__init__.py:86-88 (the reference's `out or ...` raises on multi-element arrays;
+    # `is None` is what it means)
+    out = out if out is not None else np.zeros_like(obs[0])
+    outshape = out.shape
+    out = out.ravel()
+
+    obs = [np.ascontiguousarray(x.ravel()) for x in obs]
+    grids = [np.ascontiguousarray(x.ravel()) for x in grids]
+    vals = np.ascontiguousarray(vals.ravel())
+
+    dtype = vals.dtype
+    assert dtype in [np.float64, np.float32], "`interpn` defined only for float32 and float64 data"
+
+    is_regular = assume_regular or _check_regular(grids)
+
+    if is_regular:
+        dims = [len(grid) for grid in grids]
+        starts = np.array([grid[0] for grid in grids], dtype=dtype)
+        steps = np.array([grid[1] - grid[0] for grid in grids], dtype=dtype)
+
+    sfx = "f64" if dtype == np.float64 else "f32"
+
+    if check_bounds:
+        outb = np.zeros(len(grids), dtype=bool)
+        if is_regular:
+            getattr(raw, f"check_bounds_regular_{sfx}")(dims, starts, steps, obs, bounds_atol, outb)
+        else:
+            getattr(raw, f"check_bounds_rectilinear_{sfx}")(grids, obs, bounds_atol, outb)
+        if any(outb):
+            raise ValueError("Observation points violate interpolator bounds")
+
+    if method == "linear":
+        if is_regular:
+            getattr(raw, f"interpn_linear_regular_{sfx}")(dims, starts, steps, vals, obs, out)
+        else:
+            getattr(raw, f"interpn_linear_rectilinear_{sfx}")(grids, vals, obs, out)
+    elif method == "cubic":
+        if is_regular:
+            getattr(raw, f"interpn_cubic_regular_{sfx}")(dims, starts, steps, vals, linearize_extrapolation, obs, out)
+        else:
+            getattr(raw, f"interpn_cubic_rectilinear_{sfx}")(grids, vals, linearize_extrapolation, obs, out)
+    else:
+        raise ValueError(f"Unsupported interpolation configuration: {dtype}, {is_regular}, {method}")
+
+    return out.reshape(outshape)
+
+
+def _check_regular(grids) -> bool:
+    """src/interpn/__init__.py:197-203 — exact equality of all spacings."""
+    is_regular = True
+    for grid in grids:
+        dgrid = np.diff(grid)
+        is_regular = is_regular and np.all(dgrid == dgrid[0])
+    return bool(is_regular)

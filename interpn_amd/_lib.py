@@ -1,0 +1,105 @@
+"""Loader for libinterpn_hip.so (the C ABI declared in include/interpn_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded this module
+raises, and every entry point of the package fails loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint8, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinterpn_hip.so")
+
+# interpn_hip_status (include/interpn_hip.h)
+OK = 0
+ERR_UNREPRESENTABLE = 7
+ERR_REFERENCE_PANIC = 9
+ERR_INVALID_ARGUMENT = 32
+
+LINEAR, CUBIC = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_lib = None
+
+
+class InterpnHipError(RuntimeError):
+    """Failure of the HIP implementation itself (no device, out of memory, HIP runtime error)."""
+
+
+class ReferencePanic(RuntimeError):
+    """The reference implementation panics on this input (pyo3 surfaces it as PanicException)."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C interpn_amd/csrc`. interpn_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.interpn_hip_strerror.restype = c_char_p
+    lib.interpn_hip_strerror.argtypes = [c_int]
+    lib.interpn_hip_last_hip_error.restype = c_char_p
+    lib.interpn_hip_version.restype = c_char_p
+    lib.interpn_hip_set_fma.argtypes = [c_int]
+    lib.interpn_hip_set_fma.restype = c_int
+    lib.interpn_hip_device_count.restype = c_int
+    for sfx, ct in (("f64", c_double), ("f32", c_float)):
+        pp = POINTER(POINTER(ct))
+        p = POINTER(ct)
+        sz = POINTER(c_size_t)
+        getattr(lib, f"interpn_hip_linear_regular_{sfx}").argtypes = [
+            sz, c_size_t, p, c_size_t, p, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_linear_rectilinear_{sfx}").argtypes = [
+            pp, sz, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_cubic_regular_{sfx}").argtypes = [
+            sz, c_size_t, p, c_size_t, p, c_size_t, p, c_size_t, c_int, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_cubic_rectilinear_{sfx}").argtypes = [
+            pp, sz, c_size_t, p, c_size_t, c_int, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_create_regular_{sfx}").argtypes = [
+            c_int, sz, c_size_t, p, c_size_t, p, c_size_t, c_void_p, c_size_t, c_int, c_int, c_int,
+            POINTER(c_void_p)]
+        getattr(lib, f"interpn_hip_create_rectilinear_{sfx}").argtypes = [
+            c_int, pp, sz, c_size_t, c_void_p, c_size_t, c_int, c_int, c_int, POINTER(c_void_p)]
+        getattr(lib, f"interpn_hip_check_bounds_regular_{sfx}").argtypes = [
+            sz, c_size_t, p, c_size_t, p, c_size_t, pp, sz, c_size_t, ct, POINTER(c_uint8), c_size_t]
+        getattr(lib, f"interpn_hip_check_bounds_rectilinear_{sfx}").argtypes = [
+            pp, sz, c_size_t, pp, sz, c_size_t, ct, POINTER(c_uint8), c_size_t]
+    lib.interpn_hip_elem_size.argtypes = [c_void_p]
+    lib.interpn_hip_ndims.argtypes = [c_void_p]
+    lib.interpn_hip_device.argtypes = [c_void_p]
+    lib.interpn_hip_eval_host.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_size_t, c_void_p, c_size_t]
+    lib.interpn_hip_eval_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p]
+    lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
+    lib.interpn_hip_set_blocks_per_cu.argtypes = [c_void_p, c_int]
+    lib.interpn_hip_destroy.argtypes = [c_void_p]
+    lib.interpn_hip_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def strerror(status: int) -> str:
+    return load().interpn_hip_strerror(status).decode()
+
+
+def raise_for_status(status: int) -> None:
+    """Map a status to the exception the reference's Python surface raises.
+
+    Reference errors (`Err(&'static str)`) become AssertionError(msg), src/python.rs:77-79."""
+    if status == OK:
+        return
+    msg = strerror(status)
+    if status < ERR_REFERENCE_PANIC:
+        raise AssertionError(msg)
+    if status == ERR_REFERENCE_PANIC:
+        raise ReferencePanic(msg)
+    if status == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    detail = load().interpn_hip_last_hip_error().decode()
+    raise InterpnHipError(f"{msg}: {detail}" if detail else msg)

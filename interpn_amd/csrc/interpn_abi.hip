@@ -1,0 +1,628 @@
+// C ABI of libinterpn_hip.so (see include/interpn_hip.h).  Host logic only: argument
+// validation in the reference's order, device residency of the grid, the chunked host->device
+// pipeline of the host-pointer entry points, and status reporting.  No CPU evaluation path
+// exists in this library: if the HIP runtime or a device is missing, calls fail with
+// INTERPN_HIP_ERR_NO_DEVICE / INTERPN_HIP_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/interpn_hip.h"
+#include "interpn_host.h"
+
+using namespace interpn;
+
+namespace {
+
+std::atomic<int> g_fma{1};
+thread_local std::string t_last_hip_error;
+
+int hip_fail(hipError_t e) {
+  t_last_hip_error = hipGetErrorString(e);
+  if (e == hipErrorOutOfMemory) return INTERPN_HIP_ERR_OUT_OF_MEMORY;
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return INTERPN_HIP_ERR_NO_DEVICE;
+  return INTERPN_HIP_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                        \
+  do {                                       \
+    hipError_t _e = (expr);                  \
+    if (_e != hipSuccess) return hip_fail(_e); \
+  } while (0)
+
+// Axis length limits of the device kernels (cell indices are 32-bit; f32 classifies cells by
+// comparing against (float)n, exact only up to 2^24).
+template <typename T> constexpr size_t max_axis_len() { return sizeof(T) == 8 ? (size_t)2147483391u : (size_t)16777216u; }
+
+bool checked_product(const size_t* dims, size_t n, size_t* out) {
+  size_t acc = 1;
+  for (size_t i = 0; i < n; ++i)
+    if (__builtin_mul_overflow(acc, dims[i], &acc)) return false;  // Cargo.toml:45 overflow-checks => panic
+  *out = acc;
+  return true;
+}
+
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) : prev_(-1), ok_(true) {
+    if (hipGetDevice(&prev_) != hipSuccess) { ok_ = false; return; }
+    if (device >= 0 && device != prev_) {
+      if (hipSetDevice(device) != hipSuccess) ok_ = false;
+      changed_ = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  bool ok() const { return ok_; }
+
+ private:
+  int prev_;
+  bool ok_;
+  bool changed_ = false;
+};
+
+}  // namespace
+
+struct interpn_hip_interp {
+  GridDesc desc;
+  int device = 0;
+  void* vals_owned = nullptr;   // device copy of vals when created from host memory
+  void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
+  unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
+  // Host-evaluation workspace (lazily allocated, reused across calls)
+  size_t ws_points = 0;
+  void* ws_obs = nullptr;   // ndims * ws_points elements
+  void* ws_out = nullptr;   // ws_points elements
+  unsigned long long* ws_flag_host = nullptr;  // pinned
+  hipStream_t ws_stream = nullptr;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Validation, in the order of the reference's `interpn` + `new` (+ `interp`).
+// `nobs`/`obs_lens` may be absent (handle creation): pass check_obs = false.
+template <typename T>
+int validate_regular(int method, const size_t* dims, size_t ndims, const T* starts, size_t nstarts,
+                     const T* steps, size_t nsteps, size_t nvals) {
+  if (method == kLinear) {
+    // multilinear/regular.rs:60 — obs.len() is checked by the caller of this helper
+    if (nstarts != ndims || nsteps != ndims) return INTERPN_HIP_ERR_DIM_MISMATCH;
+    if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // regular.rs:111-113
+  } else {
+    if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // multicubic/regular.rs:130-132
+    // multicubic/regular.rs:66-73 — try_into().unwrap() panics in the flattened arm
+    if (ndims <= 4 && (nstarts != ndims || nsteps != ndims)) return INTERPN_HIP_ERR_REFERENCE_PANIC;
+  }
+  if (!dims || !starts || !steps) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  size_t prod;
+  if (!checked_product(dims, ndims, &prod)) return INTERPN_HIP_ERR_REFERENCE_PANIC;
+  if (method == kCubic && !(nstarts == ndims && nsteps == ndims)) return INTERPN_HIP_ERR_DIM_MISMATCH;
+  if (nvals != prod) return INTERPN_HIP_ERR_DIM_MISMATCH;  // regular.rs:239 / multicubic/regular.rs:254
+  const size_t minlen = method == kLinear ? 2 : 4;
+  for (size_t i = 0; i < ndims; ++i)
+    if (dims[i] < minlen) return method == kLinear ? INTERPN_HIP_ERR_MIN_TWO_ENTRIES : INTERPN_HIP_ERR_MIN_FOUR_ENTRIES;
+  for (size_t i = 0; i < ndims; ++i)
+    if (!(steps[i] > (T)0)) return INTERPN_HIP_ERR_NOT_MONOTONIC;  // regular.rs:248
+  for (size_t i = 0; i < ndims; ++i)
+    if (dims[i] > max_axis_len<T>()) return INTERPN_HIP_ERR_UNSUPPORTED;
+  return INTERPN_HIP_OK;
+}
+
+template <typename T>
+int validate_rectilinear(int method, const T* const* grids, const size_t* grid_lens, size_t ngrids, size_t nvals) {
+  const size_t ndims = ngrids;
+  if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // rectilinear.rs:77-79
+  if (!grids || !grid_lens) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  size_t prod;
+  if (!checked_product(grid_lens, ndims, &prod)) return INTERPN_HIP_ERR_REFERENCE_PANIC;
+  if (nvals != prod) return INTERPN_HIP_ERR_DIM_MISMATCH;  // rectilinear.rs:186 / multicubic/rectilinear.rs:208
+  const size_t minlen = method == kLinear ? 2 : 4;
+  for (size_t i = 0; i < ndims; ++i)
+    if (grid_lens[i] < minlen) return method == kLinear ? INTERPN_HIP_ERR_MIN_2_ENTRIES : INTERPN_HIP_ERR_MIN_4_ENTRIES;
+  for (size_t i = 0; i < ndims; ++i) {
+    if (!grids[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+    if (!(grids[i][1] > grids[i][0])) return INTERPN_HIP_ERR_NOT_MONOTONIC;  // rectilinear.rs:195
+  }
+  for (size_t i = 0; i < ndims; ++i)
+    if (grid_lens[i] > max_axis_len<T>()) return INTERPN_HIP_ERR_UNSUPPORTED;
+  return INTERPN_HIP_OK;
+}
+
+// `.interp(obs, out)` length checks (multilinear/regular.rs:271, multicubic/regular.rs:301, ...),
+// including the flattened cubic arms' `obs.try_into().unwrap()` panic.
+int validate_obs(const GridDesc& g, const size_t* obs_lens, size_t nobs, size_t nout) {
+  const size_t ndims = (size_t)g.ndims;
+  if (nobs != ndims) {
+    if (g.method == kCubic && ndims <= 4) return INTERPN_HIP_ERR_REFERENCE_PANIC;
+    return INTERPN_HIP_ERR_DIM_MISMATCH;
+  }
+  if (obs_lens)
+    for (size_t i = 0; i < ndims; ++i)
+      if (obs_lens[i] != nout) return INTERPN_HIP_ERR_DIM_MISMATCH;
+  return INTERPN_HIP_OK;
+}
+
+int resolve_device(int device, int* out) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    t_last_hip_error = e != hipSuccess ? hipGetErrorString(e) : "no HIP device";
+    return INTERPN_HIP_ERR_NO_DEVICE;
+  }
+  if (device < 0) {
+    HIP_TRY(hipGetDevice(&device));
+  }
+  if (device >= count) return INTERPN_HIP_ERR_NO_DEVICE;
+  *out = device;
+  return INTERPN_HIP_OK;
+}
+
+int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t elem, int vals_mem) {
+  GridDesc& g = h->desc;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  g.cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* env = getenv("INTERPN_HIP_BLOCKS_PER_CU")) {
+    int v = atoi(env);
+    if (v >= 1 && v <= 64) g.cfg.blocks_per_cu = v;
+  }
+  g.nvals = nvals;
+  if (vals_mem == INTERPN_HIP_MEM_DEVICE) {
+    g.vals = vals;
+  } else {
+    HIP_TRY(hipMalloc(&h->vals_owned, nvals * elem));
+    HIP_TRY(hipMemcpy(h->vals_owned, vals, nvals * elem, hipMemcpyHostToDevice));
+    g.vals = h->vals_owned;
+  }
+  HIP_TRY(hipMalloc((void**)&h->first_bad, sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(h->first_bad, 0xFF, sizeof(unsigned long long)));
+  return INTERPN_HIP_OK;
+}
+
+template <typename T>
+int create_regular(int method, const size_t* dims, size_t ndims, const T* starts, size_t nstarts, const T* steps,
+                   size_t nsteps, const T* vals, size_t nvals, int vals_mem, int linearize, int device,
+                   interpn_hip_interp** handle) {
+  if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  *handle = nullptr;
+  if (method != kLinear && method != kCubic) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int st = validate_regular<T>(method, dims, ndims, starts, nstarts, steps, nsteps, nvals);
+  if (st) return st;
+  if (!vals && nvals) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int dev;
+  st = resolve_device(device, &dev);
+  if (st) return st;
+  DeviceGuard guard(dev);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  interpn_hip_interp* h = new (std::nothrow) interpn_hip_interp();
+  if (!h) return INTERPN_HIP_ERR_OUT_OF_MEMORY;
+  h->device = dev;
+  GridDesc& g = h->desc;
+  g.method = method;
+  g.kind = kRegular;
+  g.dtype = sizeof(T) == 8 ? kF64 : kF32;
+  g.ndims = (int)ndims;
+  g.linearize = linearize ? 1 : 0;
+  g.fma = g_fma.load();
+  for (size_t i = 0; i < ndims; ++i) {
+    g.n[i] = (int)dims[i];
+    g.start[i] = (double)starts[i];
+    g.step[i] = (double)steps[i];
+    g.grid_total += dims[i];
+  }
+  st = finish_create(h, vals, nvals, sizeof(T), vals_mem);
+  if (st) {
+    interpn_hip_destroy(h);
+    return st;
+  }
+  *handle = h;
+  return INTERPN_HIP_OK;
+}
+
+template <typename T>
+int create_rectilinear(int method, const T* const* grids, const size_t* grid_lens, size_t ngrids, const T* vals,
+                       size_t nvals, int vals_mem, int linearize, int device, interpn_hip_interp** handle) {
+  if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  *handle = nullptr;
+  if (method != kLinear && method != kCubic) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int st = validate_rectilinear<T>(method, grids, grid_lens, ngrids, nvals);
+  if (st) return st;
+  if (!vals && nvals) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int dev;
+  st = resolve_device(device, &dev);
+  if (st) return st;
+  DeviceGuard guard(dev);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  interpn_hip_interp* h = new (std::nothrow) interpn_hip_interp();
+  if (!h) return INTERPN_HIP_ERR_OUT_OF_MEMORY;
+  h->device = dev;
+  GridDesc& g = h->desc;
+  g.method = method;
+  g.kind = kRectilinear;
+  g.dtype = sizeof(T) == 8 ? kF64 : kF32;
+  g.ndims = (int)ngrids;
+  g.linearize = linearize ? 1 : 0;
+  g.fma = g_fma.load();
+  size_t total = 0;
+  for (size_t i = 0; i < ngrids; ++i) {
+    g.n[i] = (int)grid_lens[i];
+    total += grid_lens[i];
+  }
+  g.grid_total = total;
+  // All axes in one device allocation (each axis 16-byte aligned for the LDS staging loop).
+  std::vector<size_t> offs(ngrids);
+  size_t bytes = 0;
+  for (size_t i = 0; i < ngrids; ++i) {
+    offs[i] = bytes;
+    bytes += (grid_lens[i] * sizeof(T) + 15) & ~(size_t)15;
+  }
+  hipError_t e = hipMalloc(&h->grids_owned, bytes);
+  if (e != hipSuccess) {
+    interpn_hip_destroy(h);
+    return hip_fail(e);
+  }
+  for (size_t i = 0; i < ngrids; ++i) {
+    e = hipMemcpy((char*)h->grids_owned + offs[i], grids[i], grid_lens[i] * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      interpn_hip_destroy(h);
+      return hip_fail(e);
+    }
+    g.grid[i] = (char*)h->grids_owned + offs[i];
+  }
+  st = finish_create(h, vals, nvals, sizeof(T), vals_mem);
+  if (st) {
+    interpn_hip_destroy(h);
+    return st;
+  }
+  *handle = h;
+  return INTERPN_HIP_OK;
+}
+
+template <typename T>
+hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
+                  hipStream_t stream) {
+  if (npts == 0) return hipSuccess;
+  if (!fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
+  if (g.method == kLinear)
+    return g.kind == kRegular ? launch_linear_regular<T>(g, obs, out, npts, first_bad, stream)
+                              : launch_linear_rectilinear<T>(g, obs, out, npts, first_bad, stream);
+  return g.kind == kRegular ? launch_cubic_regular<T>(g, obs, out, npts, first_bad, stream)
+                            : launch_cubic_rectilinear<T>(g, obs, out, npts, first_bad, stream);
+}
+
+hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
+                      unsigned long long* first_bad, hipStream_t stream) {
+  if (g.dtype == kF64)
+    return launch<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts, first_bad, stream);
+  return launch<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts, first_bad, stream);
+}
+
+// Chunk size of the host pipeline (points).  Bounded so that the workspace stays modest
+// (8 dims x 8 B x 4 Mi = 256 MiB worst case) while each kernel launch still fills the chip.
+constexpr size_t kHostChunkPoints = (size_t)4 << 20;
+
+int ensure_workspace(interpn_hip_interp* h, size_t points) {
+  if (points > kHostChunkPoints) points = kHostChunkPoints;
+  if (h->ws_points >= points && h->ws_obs) return INTERPN_HIP_OK;
+  const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
+  if (h->ws_obs) { (void)hipFree(h->ws_obs); h->ws_obs = nullptr; }
+  if (h->ws_out) { (void)hipFree(h->ws_out); h->ws_out = nullptr; }
+  h->ws_points = 0;
+  HIP_TRY(hipMalloc(&h->ws_obs, (size_t)h->desc.ndims * points * elem));
+  HIP_TRY(hipMalloc(&h->ws_out, points * elem));
+  if (!h->ws_flag_host) HIP_TRY(hipHostMalloc((void**)&h->ws_flag_host, sizeof(unsigned long long), hipHostMallocDefault));
+  if (!h->ws_stream) HIP_TRY(hipStreamCreateWithFlags(&h->ws_stream, hipStreamNonBlocking));
+  h->ws_points = points;
+  return INTERPN_HIP_OK;
+}
+
+// check_bounds over host arrays: stream each dimension's coordinates through the device and OR
+// the per-point violations (multilinear/regular.rs:168-171).
+template <typename T>
+int check_bounds_host(const T* lo, const T* hi, size_t ndims, const T* const* obs, const size_t* obs_lens, T atol,
+                      uint8_t* out) {
+  int dev;
+  int st = resolve_device(-1, &dev);
+  if (st) return st;
+  unsigned* flags = nullptr;
+  T* buf = nullptr;
+  size_t maxlen = 0;
+  for (size_t d = 0; d < ndims; ++d) maxlen = obs_lens[d] > maxlen ? obs_lens[d] : maxlen;
+  const size_t chunk = maxlen < kHostChunkPoints ? (maxlen ? maxlen : 1) : kHostChunkPoints;
+  hipError_t e = hipMalloc((void**)&flags, sizeof(unsigned) * (ndims ? ndims : 1));
+  if (e == hipSuccess) e = hipMemset(flags, 0, sizeof(unsigned) * (ndims ? ndims : 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&buf, chunk * sizeof(T));
+  for (size_t d = 0; d < ndims && e == hipSuccess; ++d) {
+    if (obs_lens[d] && !obs[d]) { e = hipErrorInvalidValue; break; }
+    for (size_t begin = 0; begin < obs_lens[d] && e == hipSuccess; begin += chunk) {
+      const size_t count = obs_lens[d] - begin < chunk ? obs_lens[d] - begin : chunk;
+      e = hipMemcpy(buf, obs[d] + begin, count * sizeof(T), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_check_bounds<T>(buf, count, lo[d], hi[d], atol, flags + d, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
+  }
+  std::vector<unsigned> host(ndims ? ndims : 1, 0);
+  if (e == hipSuccess) e = hipMemcpy(host.data(), flags, sizeof(unsigned) * (ndims ? ndims : 1), hipMemcpyDeviceToHost);
+  if (buf) (void)hipFree(buf);
+  if (flags) (void)hipFree(flags);
+  if (e != hipSuccess) return hip_fail(e);
+  for (size_t d = 0; d < ndims; ++d) out[d] = host[d] ? 1 : 0;
+  return INTERPN_HIP_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char* interpn_hip_strerror(int status) {
+  switch (status) {
+    case INTERPN_HIP_OK: return "";
+    case INTERPN_HIP_ERR_DIM_MISMATCH: return "Dimension mismatch";
+    case INTERPN_HIP_ERR_MIN_TWO_ENTRIES: return "All grids must have at least two entries";
+    case INTERPN_HIP_ERR_MIN_2_ENTRIES: return "All grids must have at least 2 entries";
+    case INTERPN_HIP_ERR_MIN_FOUR_ENTRIES: return "All grids must have at least four entries";
+    case INTERPN_HIP_ERR_MIN_4_ENTRIES: return "All grids must have at least 4 entries";
+    case INTERPN_HIP_ERR_NOT_MONOTONIC: return "All grids must be monotonically increasing";
+    case INTERPN_HIP_ERR_UNREPRESENTABLE: return "Unrepresentable coordinate value";
+    case INTERPN_HIP_ERR_TOO_MANY_DIMS:
+      return "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions.";
+    case INTERPN_HIP_ERR_REFERENCE_PANIC: return "the reference implementation panics on this input (slice length mismatch or integer overflow)";
+    case INTERPN_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case INTERPN_HIP_ERR_UNSUPPORTED: return "grid axis too long for the device kernels";
+    case INTERPN_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case INTERPN_HIP_ERR_OUT_OF_MEMORY: return "out of device or pinned host memory";
+    case INTERPN_HIP_ERR_HIP: return "HIP runtime error";
+    default: return "unknown status";
+  }
+}
+
+const char* interpn_hip_last_hip_error(void) { return t_last_hip_error.c_str(); }
+const char* interpn_hip_version(void) { return "0.1.0"; }
+int interpn_hip_set_fma(int enabled) { return g_fma.exchange(enabled ? 1 : 0); }
+
+int interpn_hip_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+#define DEFINE_CREATE(T, SUFFIX)                                                                              \
+  int interpn_hip_create_regular_##SUFFIX(int method, const size_t* dims, size_t ndims, const T* starts,     \
+                                          size_t nstarts, const T* steps, size_t nsteps, const T* vals,      \
+                                          size_t nvals, int vals_mem, int linearize_extrapolation,           \
+                                          int device, interpn_hip_interp** handle) {                         \
+    return create_regular<T>(method, dims, ndims, starts, nstarts, steps, nsteps, vals, nvals, vals_mem,     \
+                             linearize_extrapolation, device, handle);                                       \
+  }                                                                                                           \
+  int interpn_hip_create_rectilinear_##SUFFIX(int method, const T* const* grids, const size_t* grid_lens,    \
+                                              size_t ngrids, const T* vals, size_t nvals, int vals_mem,      \
+                                              int linearize_extrapolation, int device,                       \
+                                              interpn_hip_interp** handle) {                                 \
+    return create_rectilinear<T>(method, grids, grid_lens, ngrids, vals, nvals, vals_mem,                    \
+                                 linearize_extrapolation, device, handle);                                   \
+  }
+DEFINE_CREATE(double, f64)
+DEFINE_CREATE(float, f32)
+
+int interpn_hip_elem_size(const interpn_hip_interp* h) { return h ? (h->desc.dtype == kF64 ? 8 : 4) : 0; }
+int interpn_hip_ndims(const interpn_hip_interp* h) { return h ? h->desc.ndims : 0; }
+int interpn_hip_device(const interpn_hip_interp* h) { return h ? h->device : -1; }
+
+int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
+  if (!h || blocks_per_cu < 1 || blocks_per_cu > 64) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  h->desc.cfg.blocks_per_cu = blocks_per_cu;
+  return INTERPN_HIP_OK;
+}
+
+void interpn_hip_destroy(interpn_hip_interp* h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  if (h->ws_stream) (void)hipStreamDestroy(h->ws_stream);
+  if (h->ws_flag_host) (void)hipHostFree(h->ws_flag_host);
+  if (h->ws_obs) (void)hipFree(h->ws_obs);
+  if (h->ws_out) (void)hipFree(h->ws_out);
+  if (h->first_bad) (void)hipFree(h->first_bad);
+  if (h->grids_owned) (void)hipFree(h->grids_owned);
+  if (h->vals_owned) (void)hipFree(h->vals_owned);
+  delete h;
+}
+
+int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t npoints,
+                            void* stream) {
+  if (!h || (!obs && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int st = validate_obs(h->desc, nullptr, nobs, npoints);
+  if (st) return st;
+  if (npoints == 0) return INTERPN_HIP_OK;
+  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < nobs; ++i)
+    if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
+  return INTERPN_HIP_OK;
+}
+
+int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_index) {
+  if (!h) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned long long word = kNoBadIndexHost;
+  HIP_TRY(hipMemcpyAsync(&word, h->first_bad, sizeof(word), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (word == kNoBadIndexHost) return INTERPN_HIP_OK;
+  HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(word), s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (first_bad_index) *first_bad_index = (uint64_t)word;
+  return INTERPN_HIP_ERR_UNREPRESENTABLE;
+}
+
+int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const size_t* obs_lens, size_t nobs,
+                          void* out, size_t nout) {
+  if (!h || (!obs && nobs) || (!obs_lens && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int st = validate_obs(h->desc, obs_lens, nobs, nout);
+  if (st) return st;
+  if (nout == 0) return INTERPN_HIP_OK;
+  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < nobs; ++i)
+    if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  st = ensure_workspace(h, nout);
+  if (st) return st;
+  const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
+  const int nd = h->desc.ndims;
+  hipStream_t s = h->ws_stream;
+  const void* dev_obs[8];
+  for (size_t begin = 0; begin < nout; begin += h->ws_points) {
+    const size_t count = (nout - begin) < h->ws_points ? (nout - begin) : h->ws_points;
+    for (int d = 0; d < nd; ++d) {
+      char* dst = (char*)h->ws_obs + (size_t)d * h->ws_points * elem;
+      HIP_TRY(hipMemcpyAsync(dst, (const char*)obs[d] + begin * elem, count * elem, hipMemcpyHostToDevice, s));
+      dev_obs[d] = dst;
+    }
+    HIP_TRY(launch_any(h->desc, dev_obs, h->ws_out, count, h->first_bad, s));
+    HIP_TRY(hipMemcpyAsync(h->ws_flag_host, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned long long bad = *h->ws_flag_host;
+    // The reference's loop stops at the first failing point: out[0..i) written, out[i..] untouched
+    // (multilinear/regular.rs:277-280).
+    const size_t good = bad == kNoBadIndexHost ? count : (size_t)bad;
+    if (good) HIP_TRY(hipMemcpyAsync((char*)out + begin * elem, h->ws_out, good * elem, hipMemcpyDeviceToHost, s));
+    if (bad != kNoBadIndexHost) {
+      HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(unsigned long long), s));
+      HIP_TRY(hipStreamSynchronize(s));
+      return INTERPN_HIP_ERR_UNREPRESENTABLE;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return INTERPN_HIP_OK;
+}
+
+// One-shot entry points: `interpn(...)` = new(..)? then interp(obs, out) — the struct is rebuilt
+// on every call in the reference as well (multilinear/regular.rs:65-71).
+#define ONESHOT_TAIL(T)                                                                         \
+  st = interpn_hip_eval_host(h, reinterpret_cast<const void* const*>(obs), obs_lens, nobs, out, nout); \
+  interpn_hip_destroy(h);                                                                       \
+  return st;
+
+// Cheap checks first (grid validation, then the `.interp` length checks) so that a call that
+// the reference rejects never touches the device; the order of the checks is the reference's.
+#define ONESHOT_PRECHECK(METHOD, NDIMS, VALIDATE)                  \
+  {                                                                \
+    int pst = (VALIDATE);                                          \
+    if (pst) return pst;                                           \
+    GridDesc tmp;                                                  \
+    tmp.method = (METHOD);                                         \
+    tmp.ndims = (int)(NDIMS);                                      \
+    if (!obs_lens && nobs) return INTERPN_HIP_ERR_INVALID_ARGUMENT; \
+    pst = validate_obs(tmp, obs_lens, nobs, nout);                 \
+    if (pst) return pst;                                           \
+  }
+
+#define DEFINE_ONESHOT(T, SUFFIX)                                                                             \
+  int interpn_hip_linear_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts, size_t nstarts, \
+                                          const T* steps, size_t nsteps, const T* vals, size_t nvals,        \
+                                          const T* const* obs, const size_t* obs_lens, size_t nobs, T* out,  \
+                                          size_t nout) {                                                     \
+    /* multilinear/regular.rs:60 */                                                                           \
+    if (nstarts != ndims || nsteps != ndims || nobs != ndims) return INTERPN_HIP_ERR_DIM_MISMATCH;           \
+    ONESHOT_PRECHECK(kLinear, ndims, validate_regular<T>(kLinear, dims, ndims, starts, nstarts, steps, nsteps, nvals)) \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_regular<T>(kLinear, dims, ndims, starts, nstarts, steps, nsteps, vals, nvals,            \
+                               INTERPN_HIP_MEM_HOST, 0, -1, &h);                                             \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }                                                                                                           \
+  int interpn_hip_linear_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens, size_t ngrids, \
+                                              const T* vals, size_t nvals, const T* const* obs,              \
+                                              const size_t* obs_lens, size_t nobs, T* out, size_t nout) {    \
+    /* multilinear/rectilinear.rs:59 */                                                                       \
+    if (nobs != ngrids) return INTERPN_HIP_ERR_DIM_MISMATCH;                                                 \
+    ONESHOT_PRECHECK(kLinear, ngrids, validate_rectilinear<T>(kLinear, grids, grid_lens, ngrids, nvals))     \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_rectilinear<T>(kLinear, grids, grid_lens, ngrids, vals, nvals, INTERPN_HIP_MEM_HOST, 0,  \
+                                   -1, &h);                                                                  \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }                                                                                                           \
+  int interpn_hip_cubic_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts, size_t nstarts,  \
+                                         const T* steps, size_t nsteps, const T* vals, size_t nvals,         \
+                                         int linearize_extrapolation, const T* const* obs,                   \
+                                         const size_t* obs_lens, size_t nobs, T* out, size_t nout) {         \
+    ONESHOT_PRECHECK(kCubic, ndims, validate_regular<T>(kCubic, dims, ndims, starts, nstarts, steps, nsteps, nvals)) \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_regular<T>(kCubic, dims, ndims, starts, nstarts, steps, nsteps, vals, nvals,             \
+                               INTERPN_HIP_MEM_HOST, linearize_extrapolation, -1, &h);                       \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }                                                                                                           \
+  int interpn_hip_cubic_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens, size_t ngrids,  \
+                                             const T* vals, size_t nvals, int linearize_extrapolation,       \
+                                             const T* const* obs, const size_t* obs_lens, size_t nobs,       \
+                                             T* out, size_t nout) {                                          \
+    ONESHOT_PRECHECK(kCubic, ngrids, validate_rectilinear<T>(kCubic, grids, grid_lens, ngrids, nvals))       \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_rectilinear<T>(kCubic, grids, grid_lens, ngrids, vals, nvals, INTERPN_HIP_MEM_HOST,      \
+                                   linearize_extrapolation, -1, &h);                                         \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }
+DEFINE_ONESHOT(double, f64)
+DEFINE_ONESHOT(float, f32)
+
+#define DEFINE_BOUNDS(T, SUFFIX)                                                                              \
+  int interpn_hip_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,           \
+                                                size_t nstarts, const T* steps, size_t nsteps,               \
+                                                const T* const* obs, const size_t* obs_lens, size_t nobs,    \
+                                                T atol, uint8_t* out, size_t nout) {                         \
+    /* multilinear/regular.rs:153-156 */                                                                      \
+    if (!(nobs == ndims && nout == ndims)) return INTERPN_HIP_ERR_DIM_MISMATCH;                              \
+    /* starts[i] / steps[i] index out of range => panic in the reference */                                   \
+    if (nstarts < ndims || nsteps < ndims) return INTERPN_HIP_ERR_REFERENCE_PANIC;                           \
+    if (ndims && (!dims || !starts || !steps || !obs || !obs_lens || !out)) return INTERPN_HIP_ERR_INVALID_ARGUMENT; \
+    std::vector<T> lo(ndims), hi(ndims);                                                                     \
+    for (size_t i = 0; i < ndims; ++i) {                                                                     \
+      if (dims[i] == 0) return INTERPN_HIP_ERR_REFERENCE_PANIC; /* dims[i] - 1 underflows */                 \
+      const T first = starts[i];                                                                             \
+      const T prod = steps[i] * (T)(dims[i] - 1);                                                            \
+      const T last = starts[i] + prod; /* regular.rs:164, not fused */                                       \
+      lo[i] = __builtin_fmin(first, last);                                                                   \
+      hi[i] = __builtin_fmax(first, last);                                                                   \
+    }                                                                                                        \
+    return check_bounds_host<T>(lo.data(), hi.data(), ndims, obs, obs_lens, atol, out);                      \
+  }                                                                                                           \
+  int interpn_hip_check_bounds_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,          \
+                                                    size_t ngrids, const T* const* obs,                      \
+                                                    const size_t* obs_lens, size_t nobs, T atol,             \
+                                                    uint8_t* out, size_t nout) {                             \
+    const size_t ndims = ngrids;                                                                             \
+    if (ndims && (!grids || !grid_lens)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;                            \
+    bool nonempty = true;                                                                                    \
+    for (size_t i = 0; i < ndims; ++i) nonempty = nonempty && grid_lens[i] > 0;                              \
+    /* multilinear/rectilinear.rs:115-118 */                                                                  \
+    if (!(nobs == ndims && nout == ndims && nonempty)) return INTERPN_HIP_ERR_DIM_MISMATCH;                  \
+    if (ndims && (!obs || !obs_lens || !out)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;                       \
+    std::vector<T> lo(ndims), hi(ndims);                                                                     \
+    for (size_t i = 0; i < ndims; ++i) {                                                                     \
+      lo[i] = grids[i][0];                                                                                   \
+      hi[i] = grids[i][grid_lens[i] - 1];                                                                    \
+    }                                                                                                        \
+    return check_bounds_host<T>(lo.data(), hi.data(), ndims, obs, obs_lens, atol, out);                      \
+  }
+DEFINE_BOUNDS(double, f64)
+DEFINE_BOUNDS(float, f32)
+
+}  // extern "C"

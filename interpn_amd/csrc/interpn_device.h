@@ -1,0 +1,317 @@
+// Device-side building blocks of the MI355X (gfx950) interpolation kernels.
+//
+// One wavefront lane evaluates one observation point.  Observation coordinates are
+// struct-of-arrays (one contiguous array per dimension, as the reference's `obs: &[&[T]]`,
+// src/multilinear/regular.rs:56), so a wave reads each coordinate as one coalesced 512-B
+// (f64) request.  Per-dimension cell index / normalized coordinate / saturation class live
+// in registers; the 2^N (linear) or 4^N (cubic) corner values are gathered from the
+// read-only grid, which is small enough to stay resident in the XCD L2 / Infinity Cache.
+// Along the last (stride-1) dimension the footprint is contiguous in memory, so corners are
+// fetched as 16-B (linear f64) / 32-B (cubic f64) vectors: 2^(N-1) resp. 4^(N-1) gathers
+// per point instead of 2^N / 4^N.
+//
+// Numerics: every operation below is written in the order of the reference source, and the
+// translation unit is compiled with -ffp-contract=off, so the only fused multiply-adds are
+// the explicit ones at the reference's `#[cfg(feature = "fma")]` sites.  f64/f32 division,
+// floor and fma are IEEE-correct on CDNA4, so results are bit-identical to the Rust code
+// built with the same feature set.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace interpn {
+
+constexpr int kMaxDims = 8;  // src/python.rs:10
+constexpr unsigned long long kNoBadIndex = ~0ull;
+
+enum Sat : int { kSatNone = 0, kSatLow = 1, kSatHigh = 2 };  // src/multicubic/mod.rs:59-66 (Inside/Outside kept apart in `outside`)
+
+// ---------------------------------------------------------------------------
+// Scalar helpers
+template <typename T> __device__ __forceinline__ T dev_fma(T a, T b, T c);
+template <> __device__ __forceinline__ double dev_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float dev_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T> __device__ __forceinline__ T dev_floor(T a);
+template <> __device__ __forceinline__ double dev_floor<double>(double a) { return __builtin_floor(a); }
+template <> __device__ __forceinline__ float dev_floor<float>(float a) { return __builtin_floorf(a); }
+
+// a*b + c with one rounding when FMA (Float::mul_add), two otherwise.
+template <bool FMA, typename T>
+__device__ __forceinline__ T mul_add(T a, T b, T c) {
+  if constexpr (FMA) {
+    return dev_fma<T>(a, b, c);
+  } else {
+    T p = a * b;
+    return p + c;
+  }
+}
+
+// Vector leaf types: W contiguous elements of the last dimension, element-aligned only.
+template <typename T, int W> struct LeafVec;
+template <> struct LeafVec<double, 2> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+template <> struct LeafVec<double, 4> { typedef double type __attribute__((ext_vector_type(4), aligned(8))); };
+template <> struct LeafVec<float, 2> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct LeafVec<float, 4> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+
+template <typename T, int W>
+struct Leaf {
+  T v[W];
+};
+
+template <typename T, int W>
+__device__ __forceinline__ Leaf<T, W> load_leaf(const T* __restrict__ p) {
+  typedef typename LeafVec<T, W>::type V;
+  V x = *reinterpret_cast<const V*>(p);
+  Leaf<T, W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = x[i];
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// Cell location
+//
+// Regular grid, linear: src/multilinear/regular.rs:414-425.  Returns false when the
+// reference's float->isize conversion fails (NaN, +-inf, |floc| >= 2^63).
+// `dimmax` = dims-2 (linear) or dims-4 (cubic); host guarantees 0 <= dimmax < 2^31-256.
+template <typename T>
+__device__ __forceinline__ bool regular_floc(T x, T start, T step, T* floc_out) {
+  T floc = dev_floor<T>((x - start) / step);
+  *floc_out = floc;
+  // num-traits 0.2.19 <isize as NumCast>::from: Some iff -2^63 <= f < 2^63
+  return (floc >= (T)-9223372036854775808.0) && (floc < (T)9223372036854775808.0);
+}
+
+template <typename T>
+__device__ __forceinline__ int clamp_loc(T floc_shifted, int dimmax) {
+  // iloc.max(0).min(dimmax): done in the float domain up to 2^31, then in int.
+  const T big = sizeof(T) == 8 ? (T)2147483647.0 : (T)2147483520.0;
+  T c = floc_shifted;
+  c = c > (T)0 ? c : (T)0;  // NaN never reaches here (caller checked)
+  c = c < big ? c : big;
+  int li = (int)c;
+  return li < dimmax ? li : dimmax;
+}
+
+// core::slice::partition_point(|g| *g < x) restated with Rust std's probe sequence
+// (size-halving binary search); trip count depends only on n, so a wave never diverges.
+template <typename T, typename GridPtr>
+__device__ __forceinline__ int partition_point_lt(GridPtr g, int n, T x) {
+  int size = n;
+  int base = 0;
+  while (size > 1) {
+    int half = size >> 1;
+    int mid = base + half;
+    base = (g[mid] < x) ? mid : base;
+    size -= half;
+  }
+  return base + ((g[base] < x) ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------
+// Linear tree: reduce dims 0..D-1 (dim 0 innermost) on a W-wide leaf of the last dim.
+// Same dependency tree as src/multilinear/regular.rs:347-393 / regular_recursive.rs:348-389.
+template <typename T, typename IdxT, int D, bool FMA>
+struct LinearTree {
+  __device__ __forceinline__ static Leaf<T, 2> run(const T* __restrict__ vals, IdxT base, const IdxT* stride, const T* t) {
+    Leaf<T, 2> a = LinearTree<T, IdxT, D - 1, FMA>::run(vals, base, stride, t);
+    Leaf<T, 2> b = LinearTree<T, IdxT, D - 1, FMA>::run(vals, base + stride[D - 1], stride, t);
+    Leaf<T, 2> r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      T y0 = a.v[i];
+      T dy = b.v[i] - y0;
+      r.v[i] = mul_add<FMA>(t[D - 1], dy, y0);  // regular.rs:378-385
+    }
+    return r;
+  }
+};
+template <typename T, typename IdxT, bool FMA>
+struct LinearTree<T, IdxT, 0, FMA> {
+  __device__ __forceinline__ static Leaf<T, 2> run(const T* __restrict__ vals, IdxT base, const IdxT*, const T*) {
+    return load_leaf<T, 2>(vals + base);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Cubic node, regular grid: src/multicubic/regular.rs:474-623 with the saturation match
+// turned into selects (every case computes exactly the reference's expression for it):
+//   None : t,    y0=v1, dy=v2-v1, k0=(v2-v0)/2,  k1=(v3-v1)/2
+//   Low  : -t,   y0=v1, dy=v0-v1, k0=-(v2-v0)/2, k1=2dy-k0   (Inside/OutsideLow)
+//   High : t-1,  y0=v2, dy=v3-v2, k0=(v3-v1)/2,  k1=2dy-k0   (Inside/OutsideHigh)
+// `two.mul_add(dy, -k0)` == `two*dy - k0` bit for bit (2*dy is exact).
+// Hermite: src/multicubic/mod.rs:72-91.
+template <bool FMA, typename T>
+__device__ __forceinline__ T hermite(T t, T y0, T dy, T k0, T k1) {
+  T a = k0 - dy;
+  T b = -k1 + dy;
+  T c1 = dy + a;
+  T c2 = b - (a + a);
+  T c3 = a - b;
+  if constexpr (FMA) {
+    return dev_fma<T>(dev_fma<T>(dev_fma<T>(c3, t, c2), t, c1), t, y0);
+  } else {
+    T i0 = t * c3;
+    T i1 = c2 + i0;
+    T i2 = t * i1;
+    T i3 = c1 + i2;
+    T i4 = t * i3;
+    return y0 + i4;
+  }
+}
+
+template <typename T>
+struct CubicDimRegular {
+  T tt;        // t (None), -t (Low), t-1 (High)
+  int sat;     // Sat
+  bool linear; // OutsideLow/OutsideHigh with linearize_extrapolation
+};
+
+template <bool FMA, typename T>
+__device__ __forceinline__ T cubic_regular_node(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
+  const T two = (T)2, one = (T)1;
+  const bool low = d.sat == kSatLow;
+  const bool high = d.sat == kSatHigh;
+  T y0 = high ? v2 : v1;
+  T ya = low ? v0 : (high ? v3 : v2);
+  T dy = ya - y0;
+  T cd = high ? (v3 - v1) : (v2 - v0);
+  T k0 = cd / two;
+  k0 = low ? -k0 : k0;
+  T k1n = (v3 - v1) / two;
+  T k1e = two * dy - k0;
+  T k1 = (low || high) ? k1e : k1n;
+  if (d.linear) {
+    T y1 = ya;  // vals[0] (low) / vals[3] (high)
+    return mul_add<FMA>(k1, d.tt - one, y1);  // regular.rs:553-561, :609-617
+  }
+  return hermite<FMA>(d.tt, y0, dy, k0, k1);
+}
+
+// Cubic node, rectilinear grid: src/multicubic/rectilinear.rs:413-545, with the
+// non-uniform central difference of src/multicubic/mod.rs:103-117.  Everything that
+// depends only on the dimension (spacings, spacing ratios, weights a and c of the
+// non-uniform central difference, t) is computed once per point and dimension; the
+// per-node part is the value-dependent remainder, evaluated in the reference's order.
+template <typename T>
+struct CubicDimRect {
+  int sat;
+  bool linear;
+  bool fma_linear;  // recursive arm fuses the linearized branch (rectilinear_recursive.rs:467,527)
+  T t;
+  // cd(y0,y1,y2,hA,hB) = a*b + c*d, a = hA/(hA+hB), b = (y2-y1)/hB, c = hB/(hB+hA), d = (y1-y0)/hA
+  //   None: k0 = cd(v0,v1,v2, h01/h12, 1),  k1 = cd(v1,v2,v3, 1, h23/h12)
+  //   Low : k0 = -cd(v0,v1,v2, 1, h12/h01); High: k0 = cd(v1,v2,v3, h12/h23, 1)
+  // One of (hA, hB) is always the literal 1 and x/1 == x exactly, so each central difference
+  // carries a single real division; r is the other (non-unit) spacing ratio.
+  T r0, a0, c0;  // k0's difference: hB == 1 for None/High, hA == 1 for Low
+  T r1, a1, c1;  // k1's difference (None only): hA == 1
+};
+
+template <typename T, typename GridPtr>
+__device__ __forceinline__ void cubic_rect_dim_setup(GridPtr g, int loc, T x, CubicDimRect<T>& d) {
+  const T one = (T)1;
+  T g0 = g[loc], g1 = g[loc + 1], g2 = g[loc + 2], g3 = g[loc + 3];
+  d.r1 = one; d.a1 = one; d.c1 = one;
+  if (d.sat == kSatNone) {
+    T h01 = g1 - g0, h12 = g2 - g1, h23 = g3 - g2;
+    d.r0 = h01 / h12;  // (hA, hB) = (r0, 1)
+    d.a0 = d.r0 / (d.r0 + one);
+    d.c0 = one / (one + d.r0);
+    d.r1 = h23 / h12;  // (hA, hB) = (1, r1)
+    d.a1 = one / (one + d.r1);
+    d.c1 = d.r1 / (d.r1 + one);
+    d.t = (x - g1) / h12;
+  } else if (d.sat == kSatLow) {
+    T h01 = g1 - g0, h12 = g2 - g1;
+    d.r0 = h12 / h01;  // (hA, hB) = (1, r0)
+    d.a0 = one / (one + d.r0);
+    d.c0 = d.r0 / (d.r0 + one);
+    d.t = -(x - g1) / h01;
+  } else {
+    T h12 = g2 - g1, h23 = g3 - g2;
+    d.r0 = h12 / h23;  // (hA, hB) = (r0, 1)
+    d.a0 = d.r0 / (d.r0 + one);
+    d.c0 = one / (one + d.r0);
+    d.t = (x - g2) / h23;
+  }
+}
+
+// Central difference with hB == 1: b = (y2-y1)/1, d = (y1-y0)/r.
+template <bool FMA, typename T>
+__device__ __forceinline__ T cd_unit_b(T y0, T y1, T y2, T r, T a, T c) {
+  T b = y2 - y1;
+  T dd = (y1 - y0) / r;
+  if constexpr (FMA) {
+    return dev_fma<T>(a, b, c * dd);
+  } else {
+    T ab = a * b;
+    T cdd = c * dd;
+    return ab + cdd;
+  }
+}
+// Central difference with hA == 1: b = (y2-y1)/r, d = (y1-y0)/1.
+template <bool FMA, typename T>
+__device__ __forceinline__ T cd_unit_a(T y0, T y1, T y2, T r, T a, T c) {
+  T b = (y2 - y1) / r;
+  T dd = y1 - y0;
+  if constexpr (FMA) {
+    return dev_fma<T>(a, b, c * dd);
+  } else {
+    T ab = a * b;
+    T cdd = c * dd;
+    return ab + cdd;
+  }
+}
+
+template <bool FMA, typename T>
+__device__ __forceinline__ T cubic_rect_node(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d) {
+  const T two = (T)2, one = (T)1;
+  if (d.sat == kSatNone) {
+    T y0 = v1;
+    T dy = v2 - v1;
+    T k0 = cd_unit_b<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
+    T k1 = cd_unit_a<FMA>(v1, v2, v3, d.r1, d.a1, d.c1);
+    return hermite<FMA>(d.t, y0, dy, k0, k1);
+  }
+  T y0, y1, dy, k0;
+  if (d.sat == kSatLow) {
+    y0 = v1; y1 = v0; dy = v0 - v1;
+    k0 = -cd_unit_a<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
+  } else {
+    y0 = v2; y1 = v3; dy = v3 - v2;
+    k0 = cd_unit_b<FMA>(v1, v2, v3, d.r0, d.a0, d.c0);
+  }
+  T k1 = two * dy - k0;
+  if (d.linear) {
+    if (FMA && d.fma_linear) return dev_fma<T>(k1, d.t - one, y1);
+    T p = k1 * (d.t - one);
+    return y1 + p;  // rectilinear.rs:500,:539 — never fused in the flattened arm
+  }
+  return hermite<FMA>(d.t, y0, dy, k0, k1);
+}
+
+// Cubic tree on a 4-wide leaf of the last dim; NodeFn(v0..v3, dim) -> T.
+template <typename T, typename IdxT, int D, typename DimT, typename NodeFn>
+struct CubicTree {
+  __device__ __forceinline__ static Leaf<T, 4> run(const T* __restrict__ vals, IdxT base, const IdxT* stride, const DimT* dim, NodeFn fn) {
+    Leaf<T, 4> r0 = CubicTree<T, IdxT, D - 1, DimT, NodeFn>::run(vals, base, stride, dim, fn);
+    Leaf<T, 4> r1 = CubicTree<T, IdxT, D - 1, DimT, NodeFn>::run(vals, base + stride[D - 1], stride, dim, fn);
+    Leaf<T, 4> r2 = CubicTree<T, IdxT, D - 1, DimT, NodeFn>::run(vals, base + 2 * stride[D - 1], stride, dim, fn);
+    Leaf<T, 4> r3 = CubicTree<T, IdxT, D - 1, DimT, NodeFn>::run(vals, base + 3 * stride[D - 1], stride, dim, fn);
+    Leaf<T, 4> r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = fn(r0.v[i], r1.v[i], r2.v[i], r3.v[i], dim[D - 1]);
+    return r;
+  }
+};
+template <typename T, typename IdxT, typename DimT, typename NodeFn>
+struct CubicTree<T, IdxT, 0, DimT, NodeFn> {
+  __device__ __forceinline__ static Leaf<T, 4> run(const T* __restrict__ vals, IdxT base, const IdxT*, const DimT*, NodeFn) {
+    return load_leaf<T, 4>(vals + base);
+  }
+};
+
+}  // namespace interpn

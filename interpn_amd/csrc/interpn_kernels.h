@@ -1,0 +1,392 @@
+// Kernels and launchers (templates).  Instantiated per method/grid kind in the *.hip files
+// next to this header so that the translation units build in parallel.
+//
+// Kernel families
+//   k_linear_regular<T,N,FMA,U>      N = 1..6   multilinear::regular      (flattened arm)
+//   k_linear_rectilinear<T,N,FMA,U>  N = 1..6   multilinear::rectilinear  (flattened arm)
+//   k_cubic_regular<T,N,FMA>         N = 1..4   multicubic::regular       (flattened arm)
+//   k_cubic_rectilinear<T,N,FMA>     N = 1..4   multicubic::rectilinear   (flattened arm)
+//   k_generic<T,METHOD,KIND,FMA>     runtime N <= 8, 64-bit indexing: the recursive arms
+//                                    (linear N = 7,8; cubic N = 5..8) and grids >= 4 GiB.
+//
+// Launch shape: 256-thread workgroups (4 waves, one per SIMD), a grid of a few workgroups
+// per CU that strides over the observation points; U points per lane and iteration keep
+// several independent gathers in flight per wave.
+#pragma once
+
+#include "interpn_device.h"
+#include "interpn_host.h"
+
+namespace interpn {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------
+template <typename T, int N>
+struct RegularArgs {
+  const T* vals;
+  const T* obs[N];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  T start[N];
+  T step[N];
+  int n[N];            // points per axis
+  unsigned stride[N];  // element stride of each dim (C order)
+  int linearize;
+};
+
+template <typename T, int N>
+struct RectArgs {
+  const T* vals;
+  const T* obs[N];
+  T* out;
+  size_t npts;
+  const T* grid[N];
+  int n[N];
+  unsigned lds_off[N];  // element offset of each axis inside the LDS image
+  unsigned stride[N];
+  int use_lds;
+  int linearize;
+};
+
+// ===========================================================================
+// multilinear::regular — src/multilinear/regular.rs:268-283 (loop), :296-404 (interp_one)
+template <typename T, int N, bool FMA, int U>
+__global__ void __launch_bounds__(kBlock) k_linear_regular(const RegularArgs<T, N> a) {
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x; i0 < a.npts; i0 += nthreads * U) {
+    T x[U][N];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * nthreads;
+#pragma unroll
+      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? a.obs[d][i] : a.start[d];
+    }
+    T t[U][N];
+    unsigned base[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      bool ok = true;
+      base[u] = 0;
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        T floc;
+        ok &= regular_floc<T>(x[u][d], a.start[d], a.step[d], &floc);  // regular.rs:415-418
+        const int loc = clamp_loc<T>(floc, a.n[d] - 2);                // regular.rs:420-422
+        // regular.rs:334-339: fused in the flattened arm when the `fma` feature is on
+        const T index_zero_loc = mul_add<FMA>(a.step[d], (T)loc, a.start[d]);
+        t[u][d] = (x[u][d] - index_zero_loc) / a.step[d];
+        base[u] += (unsigned)loc * a.stride[d];
+      }
+      if (!ok && i < a.npts) atomicMin(a.first_bad, (unsigned long long)i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      Leaf<T, 2> r = LinearTree<T, unsigned, N - 1, FMA>::run(a.vals, base[u], a.stride, t[u]);
+      const T y0 = r.v[0];
+      const T dy = r.v[1] - y0;
+      const T res = mul_add<FMA>(t[u][N - 1], dy, y0);  // regular.rs:396-402
+      if (i < a.npts) a.out[i] = res;
+    }
+  }
+}
+
+// ===========================================================================
+// multilinear::rectilinear — src/multilinear/rectilinear.rs:210-231, :244-370
+template <typename T, int N, bool FMA, int U, bool LDS>
+__device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a, const T* lds) {
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x; i0 < a.npts; i0 += nthreads * U) {
+    T x[U][N];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * nthreads;
+#pragma unroll
+      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? a.obs[d][i] : (T)0;
+    }
+    T t[U][N];
+    unsigned base[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      base[u] = 0;
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        const T* g = LDS ? (lds + a.lds_off[d]) : a.grid[d];
+        const int pp = partition_point_lt<T>(g, a.n[d], x[u][d]);  // rectilinear.rs:363
+        int loc = pp - 1;
+        loc = loc > 0 ? loc : 0;
+        loc = loc < a.n[d] - 2 ? loc : a.n[d] - 2;  // rectilinear.rs:365-367
+        const T x0 = g[loc];
+        const T x1 = g[loc + 1];
+        const T step = x1 - x0;
+        t[u][d] = (x[u][d] - x0) / step;  // rectilinear.rs:310-313 (same value at every node of dim d)
+        base[u] += (unsigned)loc * a.stride[d];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      Leaf<T, 2> r = LinearTree<T, unsigned, N - 1, FMA>::run(a.vals, base[u], a.stride, t[u]);
+      const T y0 = r.v[0];
+      const T dy = r.v[1] - y0;
+      const T res = mul_add<FMA>(t[u][N - 1], dy, y0);  // rectilinear.rs:339-344
+      if (i < a.npts) a.out[i] = res;
+    }
+  }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void stage_grids(const RectArgs<T, N>& a, T* lds) {
+#pragma unroll
+  for (int d = 0; d < N; ++d) {
+    for (int k = threadIdx.x; k < a.n[d]; k += kBlock) lds[a.lds_off[d] + k] = a.grid[d][k];
+  }
+  __syncthreads();
+}
+
+template <typename T, int N, bool FMA, int U>
+__global__ void __launch_bounds__(kBlock) k_linear_rectilinear(const RectArgs<T, N> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  if (a.use_lds) {
+    stage_grids<T, N>(a, lds);
+    linear_rectilinear_body<T, N, FMA, U, true>(a, lds);
+  } else {
+    linear_rectilinear_body<T, N, FMA, U, false>(a, nullptr);
+  }
+}
+
+// ===========================================================================
+// multicubic::regular — src/multicubic/regular.rs:297-313, :325-469
+template <typename T, bool FMA>
+struct CubicRegularNode {
+  __device__ __forceinline__ T operator()(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) const {
+    return cubic_regular_node<FMA, T>(v0, v1, v2, v3, d);
+  }
+};
+
+template <typename T, int N, bool FMA>
+__global__ void __launch_bounds__(kBlock) k_cubic_regular(const RegularArgs<T, N> a) {
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
+    CubicDimRegular<T> dim[N];
+    unsigned base = 0;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const T x = a.obs[d][i];
+      T floc;
+      ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);  // regular.rs:435-438
+      ok &= floc != (T)-9223372036854775808.0;  // `- 1` would overflow isize: the reference panics
+      // iloc = isize(floc) - 1.  All comparisons below are on floc (an integer-valued float),
+      // which is exact for |floc| < 2^63; beyond 2^53 neighbouring integers coincide in f64 but
+      // every threshold involved (−1, 0, n−3) is far below that.
+      const T n = (T)a.n[d];
+      const int loc = clamp_loc<T>(floc - (T)1, a.n[d] - 4);  // regular.rs:440-442
+      int sat;
+      bool outside;
+      // regular.rs:445-466 with iloc = floc-1: iloc < -1 <=> floc < 0; iloc == -1 <=> floc == 0;
+      // iloc > n-3 <=> floc > n-2; iloc == n-3 <=> floc == n-2.
+      if (floc < (T)0) { sat = kSatLow; outside = true; }
+      else if (floc == (T)0) { sat = kSatLow; outside = false; }
+      else if (floc > n - (T)2) { sat = kSatHigh; outside = true; }
+      else if (floc == n - (T)2) { sat = kSatHigh; outside = false; }
+      else { sat = kSatNone; outside = false; }
+      // regular.rs:356-360 — never fused
+      const T index_one_loc = mul_add<false>(a.step[d], (T)(loc + 1), a.start[d]);
+      const T t = (x - index_one_loc) / a.step[d];
+      dim[d].sat = sat;
+      dim[d].linear = outside && a.linearize;
+      dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
+      base += (unsigned)loc * a.stride[d];
+    }
+    if (!ok) atomicMin(a.first_bad, (unsigned long long)i);
+    typedef CubicRegularNode<T, FMA> Node;
+    Leaf<T, 4> r = CubicTree<T, unsigned, N - 1, CubicDimRegular<T>, Node>::run(a.vals, base, a.stride, dim, Node());
+    a.out[i] = cubic_regular_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]);  // regular.rs:415-421
+  }
+}
+
+// ===========================================================================
+// multicubic::rectilinear — src/multicubic/rectilinear.rs:237-253, :265-408
+template <typename T, bool FMA>
+struct CubicRectNode {
+  __device__ __forceinline__ T operator()(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d) const {
+    return cubic_rect_node<FMA, T>(v0, v1, v2, v3, d);
+  }
+};
+
+template <typename T, typename GridPtr>
+__device__ __forceinline__ int cubic_rect_locate(GridPtr g, int n, T x, int linearize, bool fma_linear, CubicDimRect<T>& d) {
+  const int iloc = partition_point_lt<T>(g, n, x) - 2;  // rectilinear.rs:377
+  int loc = iloc > 0 ? iloc : 0;
+  loc = loc < n - 4 ? loc : n - 4;  // rectilinear.rs:379-381
+  bool outside = false;
+  if (iloc == -2) { d.sat = kSatLow; outside = true; }  // rectilinear.rs:384-405
+  else if (iloc == -1) { d.sat = kSatLow; }
+  else if (iloc == n - 2) { d.sat = kSatHigh; outside = true; }
+  else if (iloc == n - 3) { d.sat = kSatHigh; }
+  else { d.sat = kSatNone; }
+  d.linear = outside && linearize;
+  d.fma_linear = fma_linear;
+  cubic_rect_dim_setup<T>(g, loc, x, d);
+  return loc;
+}
+
+template <typename T, int N, bool FMA, bool LDS>
+__device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, const T* lds) {
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
+    CubicDimRect<T> dim[N];
+    unsigned base = 0;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const T x = a.obs[d][i];
+      const T* g = LDS ? (lds + a.lds_off[d]) : a.grid[d];
+      const int loc = cubic_rect_locate<T>(g, a.n[d], x, a.linearize, /*fma_linear=*/false, dim[d]);
+      base += (unsigned)loc * a.stride[d];
+    }
+    typedef CubicRectNode<T, FMA> Node;
+    Leaf<T, 4> r = CubicTree<T, unsigned, N - 1, CubicDimRect<T>, Node>::run(a.vals, base, a.stride, dim, Node());
+    a.out[i] = cubic_rect_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]);  // rectilinear.rs:346-355
+  }
+}
+
+template <typename T, int N, bool FMA>
+__global__ void __launch_bounds__(kBlock) k_cubic_rectilinear(const RectArgs<T, N> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  if (a.use_lds) {
+    stage_grids<T, N>(a, lds);
+    cubic_rectilinear_body<T, N, FMA, true>(a, lds);
+  } else {
+    cubic_rectilinear_body<T, N, FMA, false>(a, nullptr);
+  }
+}
+
+// ===========================================================================
+// Generic runtime-N kernel: the recursive arms of the reference's `interpn`
+// (multilinear N = 7,8: regular_recursive.rs / rectilinear_recursive.rs;
+//  multicubic N = 5..8: regular_recursive.rs / rectilinear_recursive.rs) and any grid whose
+// element count does not fit 32-bit indexing.  Same dependency tree, written as the
+// reference's flattened vertex loop (multilinear/regular.rs:347-393) with a runtime bound.
+template <typename T>
+struct GenericArgs {
+  const T* vals;
+  const T* obs[kMaxDims];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  int ndims;
+  T start[kMaxDims];
+  T step[kMaxDims];
+  const T* grid[kMaxDims];
+  int n[kMaxDims];
+  unsigned long long stride[kMaxDims];
+  int linearize;
+  int fma_index;   // linear regular: index_zero_loc fused (flattened arm, N <= 6)
+  int fma_linear;  // cubic rectilinear: linearized branch fused (recursive arm, N >= 5)
+};
+
+template <typename T, int METHOD, int KIND, bool FMA>
+__global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
+  constexpr int FP = METHOD == kLinear ? 2 : 4;
+  constexpr int BITS = METHOD == kLinear ? 1 : 2;
+  const int N = a.ndims;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
+    T tlin[kMaxDims];
+    CubicDimRegular<T> dreg[kMaxDims];
+    CubicDimRect<T> drect[kMaxDims];
+    unsigned long long base = 0;
+    bool ok = true;
+    for (int d = 0; d < N; ++d) {
+      const T x = a.obs[d][i];
+      int loc;
+      if constexpr (KIND == kRegular) {
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);
+        if constexpr (METHOD == kCubic) ok &= floc != (T)-9223372036854775808.0;
+        if constexpr (METHOD == kLinear) {
+          loc = clamp_loc<T>(floc, a.n[d] - 2);
+          const T izl = (FMA && a.fma_index) ? dev_fma<T>(a.step[d], (T)loc, a.start[d])
+                                             : mul_add<false>(a.step[d], (T)loc, a.start[d]);
+          tlin[d] = (x - izl) / a.step[d];
+        } else {
+          const T n = (T)a.n[d];
+          loc = clamp_loc<T>(floc - (T)1, a.n[d] - 4);
+          int sat;
+          bool outside;
+          if (floc < (T)0) { sat = kSatLow; outside = true; }
+          else if (floc == (T)0) { sat = kSatLow; outside = false; }
+          else if (floc > n - (T)2) { sat = kSatHigh; outside = true; }
+          else if (floc == n - (T)2) { sat = kSatHigh; outside = false; }
+          else { sat = kSatNone; outside = false; }
+          const T iol = mul_add<false>(a.step[d], (T)(loc + 1), a.start[d]);
+          const T t = (x - iol) / a.step[d];
+          dreg[d].sat = sat;
+          dreg[d].linear = outside && a.linearize;
+          dreg[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
+        }
+      } else {
+        const T* g = a.grid[d];
+        if constexpr (METHOD == kLinear) {
+          loc = partition_point_lt<T>(g, a.n[d], x) - 1;
+          loc = loc > 0 ? loc : 0;
+          loc = loc < a.n[d] - 2 ? loc : a.n[d] - 2;
+          const T x0 = g[loc];
+          const T x1 = g[loc + 1];
+          const T step = x1 - x0;
+          tlin[d] = (x - x0) / step;
+        } else {
+          loc = cubic_rect_locate<T>(g, a.n[d], x, a.linearize, a.fma_linear != 0, drect[d]);
+        }
+      }
+      base += (unsigned long long)loc * a.stride[d];
+    }
+    if (!ok) atomicMin(a.first_bad, (unsigned long long)i);
+
+    auto node = [&](const T* v, int d) -> T {
+      if constexpr (METHOD == kLinear) {
+        const T y0 = v[0];
+        const T dy = v[1] - y0;
+        return mul_add<FMA>(tlin[d], dy, y0);
+      } else if constexpr (KIND == kRegular) {
+        return cubic_regular_node<FMA, T>(v[0], v[1], v[2], v[3], dreg[d]);
+      } else {
+        return cubic_rect_node<FMA, T>(v[0], v[1], v[2], v[3], drect[d]);
+      }
+    };
+
+    T store[kMaxDims][FP];
+    const unsigned long long nverts = 1ull << (BITS * N);
+    for (unsigned long long v = 0; v < nverts; ++v) {
+      unsigned long long idx = base;
+      for (int k = 0; k < N; ++k) idx += ((v >> (BITS * k)) & (FP - 1)) * a.stride[k];
+      store[0][v & (FP - 1)] = a.vals[idx];
+      for (int j = 1; j < N; ++j) {
+        const unsigned long long q = 1ull << (BITS * j);
+        if (((v + 1) & (q - 1)) == 0) {
+          const int p = (int)((((v + 1) >> (BITS * j)) - 1) & (FP - 1));
+          store[j][p] = node(store[j - 1], j - 1);
+        }
+      }
+    }
+    a.out[i] = node(store[N - 1], N - 1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Launch geometry
+inline unsigned grid_blocks(size_t npts, int points_per_thread, const LaunchConfig& cfg) {
+  size_t per_block = (size_t)kBlock * points_per_thread;
+  size_t want = (npts + per_block - 1) / per_block;
+  size_t cap = (size_t)cfg.num_cus * cfg.blocks_per_cu;
+  if (want < 1) want = 1;
+  return (unsigned)(want < cap ? want : cap);
+}
+
+}  // namespace interpn

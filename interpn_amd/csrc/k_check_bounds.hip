@@ -1,0 +1,31 @@
+// check_bounds as a streaming any-reduction (reference: src/multilinear/regular.rs:145-182,
+// rectilinear.rs:109-134): one coalesced pass over a coordinate array, HBM-bound.
+#include "interpn_kernels.h"
+
+namespace interpn {
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_check_bounds(const T* __restrict__ x, size_t n, T lo, T hi, T atol,
+                                                         unsigned* flag) {
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+    const T v = x[i];
+    bad |= ((v - lo) <= -atol) || ((v - hi) >= atol);  // regular.rs:170
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+template <typename T>
+hipError_t launch_check_bounds(const T* x, size_t n, T lo, T hi, T atol, unsigned* flag, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  LaunchConfig cfg;
+  const unsigned blocks = grid_blocks(n, 4, cfg);
+  hipLaunchKernelGGL((k_check_bounds<T>), dim3(blocks), dim3(kBlock), 0, stream, x, n, lo, hi, atol, flag);
+  return hipGetLastError();
+}
+
+template hipError_t launch_check_bounds<double>(const double*, size_t, double, double, double, unsigned*, hipStream_t);
+template hipError_t launch_check_bounds<float>(const float*, size_t, float, float, float, unsigned*, hipStream_t);
+
+}  // namespace interpn

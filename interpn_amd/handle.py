@@ -1,0 +1,165 @@
+"""Persistent, device-resident interpolators over the handle API of include/interpn_hip.h.
+
+`Interpolator` is the counterpart of the reference's interpolator structs
+(`MultilinearRegular::new(..).interp(obs, out)`, src/multilinear/regular.rs:225-283 and the
+three siblings) with the grid kept in HBM between evaluations.  Observation points may be host
+numpy arrays (`eval_host`) or device buffers (`eval_device`, e.g. torch tensors on the GPU —
+torch is only plumbing for device memory and streams here).
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_double, c_float, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from .raw import _check_arr, _dims, _slice_of_slices
+
+
+class Interpolator:
+    def __init__(self, handle: int, dtype, ndims: int, keepalive=None):
+        self._h = c_void_p(handle)
+        self.dtype = np.dtype(dtype)
+        self._ndims = ndims
+        self._keepalive = keepalive  # e.g. a torch tensor whose storage the handle borrows
+
+    # -- construction ---------------------------------------------------------------------
+    @staticmethod
+    def _vals_arg(vals, dtype):
+        """Return (void* address, nvals, mem kind, keepalive) for a numpy array or a torch tensor."""
+        if isinstance(vals, np.ndarray):
+            v = _check_arr("vals", vals, dtype)
+            return v.ctypes.data_as(c_void_p), v.size, _lib.MEM_HOST, v
+        # torch tensor (duck-typed so that torch stays an optional import)
+        if hasattr(vals, "data_ptr") and hasattr(vals, "is_cuda"):
+            if not vals.is_contiguous() or vals.dim() != 1:
+                raise ValueError("argument 'vals': expected a contiguous 1-D tensor")
+            want = "torch.float64" if dtype == np.float64 else "torch.float32"
+            if str(vals.dtype) != want:
+                raise TypeError(f"argument 'vals': expected {want}, got {vals.dtype}")
+            mem = _lib.MEM_DEVICE if vals.is_cuda else _lib.MEM_HOST
+            return c_void_p(vals.data_ptr()), vals.numel(), mem, vals
+        raise TypeError("argument 'vals': expected a numpy array or a torch tensor")
+
+    @classmethod
+    def regular(cls, method: str, dims, starts, steps, vals, linearize_extrapolation: bool = False,
+                device: int = -1, dtype=None) -> "Interpolator":
+        dtype = np.dtype(dtype or starts.dtype)
+        sfx = "f64" if dtype == np.float64 else "f32"
+        ct = c_double if dtype == np.float64 else c_float
+        lib = _lib.load()
+        d, nd = _dims(dims)
+        starts = _check_arr("starts", starts, dtype)
+        steps = _check_arr("steps", steps, dtype)
+        vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
+        h = c_void_p()
+        st = getattr(lib, f"interpn_hip_create_regular_{sfx}")(
+            _lib.LINEAR if method == "linear" else _lib.CUBIC, d, nd, starts.ctypes.data_as(POINTER(ct)),
+            starts.size, steps.ctypes.data_as(POINTER(ct)), steps.size, vptr, nvals, mem,
+            int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
+        _lib.raise_for_status(st)
+        return cls(h.value, dtype, nd, keep if mem == _lib.MEM_DEVICE else None)
+
+    @classmethod
+    def rectilinear(cls, method: str, grids, vals, linearize_extrapolation: bool = False, device: int = -1,
+                    dtype=None) -> "Interpolator":
+        dtype = np.dtype(dtype or grids[0].dtype)
+        sfx = "f64" if dtype == np.float64 else "f32"
+        lib = _lib.load()
+        gptr, glen, ng, _keep_grids = _slice_of_slices("grids", grids, dtype)
+        vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
+        h = c_void_p()
+        st = getattr(lib, f"interpn_hip_create_rectilinear_{sfx}")(
+            _lib.LINEAR if method == "linear" else _lib.CUBIC, gptr, glen, ng, vptr, nvals, mem,
+            int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
+        _lib.raise_for_status(st)
+        return cls(h.value, dtype, ng, keep if mem == _lib.MEM_DEVICE else None)
+
+    # -- evaluation -----------------------------------------------------------------------
+    def ndims(self) -> int:
+        return self._ndims
+
+    def device(self) -> int:
+        return _lib.load().interpn_hip_device(self._h)
+
+    def set_blocks_per_cu(self, n: int) -> None:
+        _lib.raise_for_status(_lib.load().interpn_hip_set_blocks_per_cu(self._h, int(n)))
+
+    def eval_host(self, obs, out: np.ndarray) -> np.ndarray:
+        """`.interp(obs, out)` on host arrays (synchronous)."""
+        lib = _lib.load()
+        out = _check_arr("out", out, self.dtype, writable=True)
+        optr, olen, nobs, _keep = _slice_of_slices("obs", obs, self.dtype)
+        vp = (c_void_p * max(nobs, 1))()
+        for i in range(nobs):
+            vp[i] = ctypes.cast(optr[i], c_void_p)
+        st = lib.interpn_hip_eval_host(self._h, vp, olen, nobs, out.ctypes.data_as(c_void_p), out.size)
+        _lib.raise_for_status(st)
+        return out
+
+    def eval_device_ptrs(self, obs_ptrs, out_ptr: int, npoints: int, stream: int = 0) -> None:
+        """Enqueue one evaluation on device buffers given as raw addresses (asynchronous)."""
+        lib = _lib.load()
+        n = len(obs_ptrs)
+        vp = (c_void_p * max(n, 1))()
+        for i, p in enumerate(obs_ptrs):
+            vp[i] = c_void_p(int(p))
+        st = lib.interpn_hip_eval_device(self._h, vp, n, c_void_p(int(out_ptr)), int(npoints),
+                                         c_void_p(int(stream)))
+        _lib.raise_for_status(st)
+
+    def eval_tensors(self, obs, out=None, stream=None):
+        """Evaluate on torch CUDA tensors (asynchronous on torch's current stream unless given).
+        Call `finish()` to synchronise and surface "Unrepresentable coordinate value"."""
+        import torch
+
+        want = torch.float64 if self.dtype == np.float64 else torch.float32
+        obs = list(obs)
+        for i, t in enumerate(obs):
+            if not (t.is_cuda and t.is_contiguous() and t.dim() == 1 and t.dtype == want):
+                raise TypeError(f"obs[{i}]: expected a contiguous 1-D {want} CUDA tensor")
+        n = obs[0].numel() if obs else 0
+        for t in obs:
+            if t.numel() != n:
+                raise AssertionError("Dimension mismatch")
+        if out is None:
+            out = torch.empty(n, dtype=want, device=obs[0].device)
+        elif not (out.is_cuda and out.is_contiguous() and out.dim() == 1 and out.dtype == want):
+            raise TypeError(f"out: expected a contiguous 1-D {want} CUDA tensor")
+        elif out.numel() != n:
+            raise AssertionError("Dimension mismatch")
+        s = stream if stream is not None else torch.cuda.current_stream(obs[0].device).cuda_stream
+        self.eval_device_ptrs([t.data_ptr() for t in obs], out.data_ptr(), n, s)
+        return out
+
+    def finish(self, stream=None) -> None:
+        """Wait for the stream; raise AssertionError("Unrepresentable coordinate value") if any
+        device evaluation since the last finish hit a NaN/inf/out-of-range coordinate."""
+        lib = _lib.load()
+        if stream is None:
+            try:
+                import torch
+
+                stream = torch.cuda.current_stream(self.device()).cuda_stream if torch.cuda.is_available() else 0
+            except ImportError:
+                stream = 0
+        bad = c_uint64(0)
+        st = lib.interpn_hip_finish(self._h, c_void_p(int(stream)), ctypes.byref(bad))
+        if st == _lib.ERR_UNREPRESENTABLE:
+            err = AssertionError(_lib.strerror(st))
+            err.first_bad_index = bad.value
+            raise err
+        _lib.raise_for_status(st)
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().interpn_hip_destroy(self._h)
+            self._h = c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

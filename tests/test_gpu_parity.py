@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's
+known answers.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (north_star): <= 1e-12 relative for linear, <= 1e-10 for cubic in f64, normalised by
+max(|ref|, 1); f32: 1e-6 (test/test_multicubic_regular.py:6).  The kernels reproduce the
+reference's operation order and FMA sites, so the *expected* difference to the oracle is zero
+ulp; the tests assert bit equality and would report the tolerance margin if that ever broke.
+"""
+
+import numpy as np
+import pytest
+
+from tests import kat
+from tests.helpers import rel_err, run_hip_raw, run_oracle, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = {("linear", np.float64): 1e-12, ("cubic", np.float64): 1e-10, ("linear", np.float32): 1e-6,
+       ("cubic", np.float32): 1e-6}
+
+
+def assert_parity(case, got, want):
+    dtype = np.dtype(got.dtype).type
+    err = rel_err(got, want)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), case.name
+    tol = TOL[(case.method, dtype)]
+    assert np.all(err[finite] <= tol), (case.name, float(err[finite].max()))
+    # stronger: bit-identical
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    assert np.all(same), (case.name, int((~same).sum()), float(err[finite].max()))
+
+
+ALL_KATS = kat.all_cases(8, 6)
+
+
+@pytest.mark.parametrize("case", ALL_KATS, ids=lambda c: c.name)
+def test_known_answers(oracle, case):
+    """Every hot-path known-answer test of the reference, through the raw (one-shot) ABI."""
+    got = run_hip_raw(case)
+    kat.check(case, got)
+    assert_parity(case, got, run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_linear_random(oracle, kind, n, dtype):
+    axis = {1: [257], 2: [33, 64], 3: [17, 9, 32], 4: [7, 9, 5, 12], 5: [4, 5, 3, 6, 7], 6: [3, 4, 2, 5, 3, 4]}[n]
+    case = synthetic_case("linear", kind, n, axis, 200_003, 100 + n, dtype)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_cubic_random(oracle, kind, n, linearize, dtype):
+    axis = {1: [129], 2: [17, 32], 3: [9, 6, 16], 4: [5, 7, 4, 9]}[n]
+    case = synthetic_case("cubic", kind, n, axis, 100_003, 200 + n, dtype, linearize=linearize, extrap=0.2)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("method,n", [("linear", 7), ("linear", 8), ("cubic", 5), ("cubic", 6)])
+def test_recursive_arms(oracle, method, kind, n):
+    """N = 7,8 (linear) and 5,6 (cubic) take the reference's recursive arm, with its own FMA
+    sites (regular_recursive.rs:310-313; rectilinear_recursive.rs:467,527)."""
+    m = 2 if method == "linear" else 4
+    axis = [m + (d % 2) for d in range(n)]
+    case = synthetic_case(method, kind, n, axis, 3001, 300 + n, np.float64, linearize=True, extrap=0.3)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+def test_no_fma_flavour(oracle):
+    """interpn_hip_set_fma(0) == the reference built without the `fma` feature."""
+    from interpn_amd import _lib
+
+    lib = _lib.load()
+    prev = lib.interpn_hip_set_fma(0)
+    try:
+        for method, kind, n, axis in [("linear", "regular", 3, [9, 8, 7]), ("linear", "rectilinear", 2, [11, 6]),
+                                      ("cubic", "regular", 2, [8, 9]), ("cubic", "rectilinear", 3, [5, 6, 7]),
+                                      ("linear", "regular", 7, [2, 3, 2, 3, 2, 3, 2])]:
+            case = synthetic_case(method, kind, n, axis, 50_001, 400 + n, np.float64, linearize=True, extrap=0.2)
+            assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, False))
+    finally:
+        lib.interpn_hip_set_fma(prev)
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf, 1e300])
+def test_unrepresentable_aborts_at_first_bad_point(oracle, method, bad):
+    """multilinear/regular.rs:418 + :277-280: the batch stops at the first failing point; the
+    prefix is written, the rest of `out` untouched.  (1e300/step overflows isize.)"""
+    case = synthetic_case(method, "regular", 2, [8, 9], 10_000, 5, np.float64, specials=False)
+    k = 7777
+    case.obs[1][k] = bad
+    case.obs[0][k + 50] = np.nan  # a later failure must not win
+    want = np.full(10_000, -123.0)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+        if method == "linear":
+            oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, case.obs, want)
+        else:
+            oracle.cubic_regular(case.dims, case.starts, case.steps, case.vals, False, case.obs, want)
+    assert ei.value.first_bad == k
+    from interpn_amd import raw
+
+    got = np.full(10_000, -123.0)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+        if method == "linear":
+            raw.interpn_linear_regular_f64(case.dims, case.starts, case.steps, case.vals, case.obs, got)
+        else:
+            raw.interpn_cubic_regular_f64(case.dims, case.starts, case.steps, case.vals, False, case.obs, got)
+    assert np.array_equal(got, want)
+    assert np.all(got[k:] == -123.0)
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_rectilinear_never_errors_and_propagates_nan(oracle, method):
+    """multilinear/rectilinear.rs:353-370: NaN lands in cell 0 and the result is NaN; +-inf
+    extrapolate to +-inf/NaN; no error is raised."""
+    case = synthetic_case(method, "rectilinear", 2, [8, 9], 4096, 6, np.float64, specials=False)
+    case.obs[0][10] = np.nan
+    case.obs[1][11] = np.inf
+    case.obs[0][12] = -np.inf
+    case.obs[1][13] = 1e300
+    want = run_oracle(oracle, case, True)
+    got = run_hip_raw(case)
+    assert np.isnan(got[10])
+    assert_parity(case, got, want)
+
+
+def test_eval_host_multi_chunk(oracle):
+    """More points than one host-pipeline chunk (4 Mi): chunk seams must be invisible."""
+    case = synthetic_case("linear", "regular", 3, [16, 16, 16], (4 << 20) + 12345, 9, np.float64)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+def test_classes_and_helper(oracle):
+    """`.new(...).eval(obs)` and `interpn()` — the three API levels of
+    test/test_multilinear_regular.py:46-93 give the same (oracle-identical) result."""
+    import interpn_amd
+
+    for dtype in (np.float64, np.float32):
+        for c in kat.py_on_grid_cases():
+            if c.vals.dtype != dtype:
+                continue
+            want = run_oracle(oracle, c, True)
+            if c.kind == "regular":
+                cls = interpn_amd.MultilinearRegular if c.method == "linear" else interpn_amd.MulticubicRegular
+                args = (c.dims, c.starts, c.steps, c.vals)
+            else:
+                cls = interpn_amd.MultilinearRectilinear if c.method == "linear" else interpn_amd.MulticubicRectilinear
+                args = (c.grids, c.vals)
+            it = cls.new(*args) if c.method == "linear" else cls.new(*args, linearize_extrapolation=False)
+            got = it.eval(c.obs)
+            assert got.dtype == dtype
+            assert np.array_equal(got, want)
+            rt = cls.model_validate_json(it.model_dump_json())
+            assert np.array_equal(rt.eval(c.obs), want)
+            got2 = interpn_amd.interpn(obs=c.obs, grids=c.grids, vals=c.vals, method=c.method,
+                                       linearize_extrapolation=False)
+            kat.check(c, got2)
+            # check_bounds: nodes are inside, a far point is outside
+            assert not any(it.check_bounds(c.obs, dtype(1e-6)))
+            far = [np.array([-5.0]).astype(dtype), np.array([-25.0]).astype(dtype)]
+            assert any(it.check_bounds(far, dtype(1e-6)))
+
+
+def test_check_bounds_matches_oracle(oracle):
+    from interpn_amd import raw
+
+    rng = np.random.default_rng(3)
+    dims, starts, steps = [10, 20, 30], np.array([0.0, -1.0, 2.0]), np.array([0.1, 0.2, 0.3])
+    obs = [rng.uniform(0.0, 0.9, 100_000), rng.uniform(-1.0, 2.8, 100_000), rng.uniform(2.0, 10.7, 100_000)]
+    obs[1][77_777] = 2.8 + 1e-3
+    got = np.zeros(3, dtype=bool)
+    want = np.zeros(3, dtype=bool)
+    raw.check_bounds_regular_f64(dims, starts, steps, obs, 1e-8, got)
+    oracle.check_bounds_regular(dims, starts, steps, obs, 1e-8, want)
+    assert np.array_equal(got, want) and list(want) == [False, True, False]
+    grids = [starts[d] + steps[d] * np.arange(dims[d]) for d in range(3)]
+    raw.check_bounds_rectilinear_f64(grids, obs, 1e-8, got)
+    oracle.check_bounds_rectilinear(grids, obs, 1e-8, want)
+    assert np.array_equal(got, want)
+
+
+def test_device_tensors_full_size_properties(oracle):
+    """BASELINE config 2 at full size (3-D multilinear-regular, 64^3 grid, 1e8 obs) on device
+    tensors: (a) a sampled subset is bit-identical to the oracle; (b) evaluating a sub-range
+    separately reproduces the corresponding slice bit for bit (no dependence on launch
+    geometry); (c) a field that is linear in every coordinate is reproduced to 1e-12."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n, P = 64, 100_000_000
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0])
+    rng = np.random.default_rng(11)
+    vals = rng.uniform(-1, 1, n**3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(3)]
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
+    out = it.eval_tensors(obs)
+    it.finish()
+    # (a) sampled subset vs oracle
+    idx = torch.randint(0, P, (500_000,), device=dev, generator=gen)
+    sub = [o[idx].cpu().numpy() for o in obs]
+    want = np.zeros(idx.numel())
+    oracle.linear_regular(dims, starts, steps, vals, sub, want)
+    assert np.array_equal(out[idx].cpu().numpy(), want)
+    # (b) sub-range == slice
+    lo, hi = 12_345_678, 23_456_789
+    part = it.eval_tensors([o[lo:hi].contiguous() for o in obs])
+    it.finish()
+    assert torch.equal(part, out[lo:hi])
+    # (c) linear field
+    mesh = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    lin = mesh @ np.array([0.5, -1.25, 2.0]) + 0.75
+    it2 = interpn_amd.Interpolator.regular("linear", dims, starts, steps, np.ascontiguousarray(lin))
+    out2 = it2.eval_tensors(obs)
+    it2.finish()
+    exact = 0.5 * obs[0] - 1.25 * obs[1] + 2.0 * obs[2] + 0.75
+    assert float((out2 - exact).abs().max()) < 1e-12
