@@ -33,10 +33,36 @@ class ReferencePanic(RuntimeError):
     """The reference implementation panics on this input (pyo3 surfaces it as PanicException)."""
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, the same as /opt/rocm's).  If libinterpn_hip.so were loaded first it would
+    bind to /opt/rocm's copy and a later `import torch` would bring up a second runtime that
+    cannot open the device ("no ROCm-capable device is detected").  Loading torch's copy first
+    (by path, without importing torch) makes both bind to the same runtime."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
