@@ -76,6 +76,7 @@ struct interpn_hip_interp {
   int device = 0;
   void* vals_owned = nullptr;   // device copy of vals when created from host memory
   void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
+  void* bricks_owned = nullptr; // bricked copy of vals (3-D multilinear f64)
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
   // Host-evaluation workspace (lazily allocated, reused across calls)
   size_t ws_points = 0;
@@ -166,6 +167,51 @@ int resolve_device(int device, int* out) {
   return INTERPN_HIP_OK;
 }
 
+// Bricked copy of the grid for the 3-D multilinear f64 kernels (k_linear3_brick.hip).  The layout
+// is chosen by where the table will live: fully overlapped bricks (one line per cell, 5.3x the
+// grid) while that still fits the 4 MiB XCD L2 or once the grid is far beyond it anyway (served
+// by the 256 MiB Infinity Cache, where fewer lines per point matter most); in between, the
+// cheaper overlaps that keep most of the table L2-resident.  INTERPN_HIP_BRICKS=off|11|12|22
+// overrides (tuning).
+int maybe_build_bricks(interpn_hip_interp* h) {
+  GridDesc& g = h->desc;
+  if (!(g.method == kLinear && g.dtype == kF64 && g.ndims == 3)) return INTERPN_HIP_OK;
+  const char* env = getenv("INTERPN_HIP_BRICKS");
+  if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
+  int si = 0, sj = 0;
+  if (env && strlen(env) == 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2')) {
+    si = env[0] - '0';
+    sj = env[1] - '0';
+  } else {
+    const size_t MiB = (size_t)1 << 20;
+    unsigned nb[3];
+    size_t b11, b12, b22;
+    brick3_geometry(g.n, 1, 1, nb, &b11);
+    brick3_geometry(g.n, 1, 2, nb, &b12);
+    brick3_geometry(g.n, 2, 2, nb, &b22);
+    if (b11 <= 3 * MiB) { si = 1; sj = 1; }
+    else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
+    else if (b22 <= 4 * MiB) { si = 2; sj = 2; }
+    else if (b11 <= 192 * MiB) { si = 1; sj = 1; }
+    else if (b22 <= (size_t)2048 * MiB) { si = 2; sj = 2; }
+    else return INTERPN_HIP_OK;  // very large grids stay on the C-order kernel
+  }
+  size_t bytes;
+  brick3_geometry(g.n, si, sj, g.brick_nb, &bytes);
+  // brick element offsets are 32-bit in the kernel
+  if (bytes / sizeof(double) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) return INTERPN_HIP_OK;
+  g.brick_step[0] = si;
+  g.brick_step[1] = sj;
+  hipError_t e = hipMalloc(&h->bricks_owned, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
+  HIP_TRY(build_bricks3(g, h->bricks_owned, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  g.bricks = h->bricks_owned;
+  return INTERPN_HIP_OK;
+}
+
 int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t elem, int vals_mem) {
   GridDesc& g = h->desc;
   hipDeviceProp_t prop;
@@ -185,6 +231,8 @@ int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t 
   }
   HIP_TRY(hipMalloc((void**)&h->first_bad, sizeof(unsigned long long)));
   HIP_TRY(hipMemset(h->first_bad, 0xFF, sizeof(unsigned long long)));
+  int st = maybe_build_bricks(h);
+  if (st) return st;
   return INTERPN_HIP_OK;
 }
 
@@ -303,6 +351,9 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
 
 hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
                       unsigned long long* first_bad, hipStream_t stream) {
+  if (g.bricks && npts)
+    return launch_linear3_brick(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts,
+                                first_bad, stream);
   if (g.dtype == kF64)
     return launch<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts, first_bad, stream);
   return launch<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts, first_bad, stream);
@@ -435,6 +486,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
   if (h->ws_out) (void)hipFree(h->ws_out);
   if (h->first_bad) (void)hipFree(h->first_bad);
   if (h->grids_owned) (void)hipFree(h->grids_owned);
+  if (h->bricks_owned) (void)hipFree(h->bricks_owned);
   if (h->vals_owned) (void)hipFree(h->vals_owned);
   delete h;
 }

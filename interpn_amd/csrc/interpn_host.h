@@ -30,6 +30,11 @@ struct GridDesc {
   size_t nvals = 0;
   const void* grid[8] = {nullptr};  // device, rectilinear axes
   size_t grid_total = 0;            // sum of n[d]
+  // Optional bricked copy of `vals` (3-D multilinear f64 only; see k_linear3_brick.hip):
+  // 2 x 2 x 4 element bricks of one 128-B line, brick steps (brick_step[0], brick_step[1], 3).
+  const void* bricks = nullptr;
+  int brick_step[2] = {2, 2};
+  unsigned brick_nb[3] = {0, 0, 0};
   LaunchConfig cfg;
 };
 
@@ -53,6 +58,12 @@ hipError_t launch_cubic_rectilinear(const GridDesc& g, const T* const* obs, T* o
 template <typename T>
 hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                           unsigned long long* first_bad, hipStream_t stream);
+
+// Bricked 3-D multilinear path (f64).
+void brick3_geometry(const int n[3], int si, int sj, unsigned nb[3], size_t* bytes);
+hipError_t build_bricks3(const GridDesc& g, void* bricks, hipStream_t stream);
+hipError_t launch_linear3_brick(const GridDesc& g, const double* const* obs, double* out, size_t npts,
+                                unsigned long long* first_bad, hipStream_t stream);
 
 // check_bounds: OR into flag[0] whether any of x[0..n) violates [lo, hi] by atol or more
 // (src/multilinear/regular.rs:168-171).

@@ -72,6 +72,27 @@ def test_recursive_arms(oracle, method, kind, n):
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("layout", ["off", "11", "12", "22"])
+@pytest.mark.parametrize("axis", [[2, 2, 2], [3, 4, 5], [17, 9, 32], [64, 64, 64], [8, 7, 3]], ids=str)
+def test_linear3_brick_layouts(oracle, monkeypatch, kind, layout, axis):
+    """3-D multilinear f64 runs on a bricked copy of the grid with a quad-cooperative gather
+    (k_linear3_brick.hip); every brick overlap scheme and the C-order kernel must give the same
+    bits, including the 2-point axes, odd sizes and NaN / out-of-range coordinates."""
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
+    case = synthetic_case("linear", kind, 3, axis, 70_001, 900 + sum(axis), np.float64, extrap=0.3,
+                          specials=min(axis) >= 8)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+    if kind == "regular":
+        case.obs[2][4321] = np.nan
+        from interpn_amd import raw
+
+        got = np.full(70_001, -1.0)
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+            raw.interpn_linear_regular_f64(case.dims, case.starts, case.steps, case.vals, case.obs, got)
+        assert np.all(got[4321:] == -1.0) and np.all(got[:4321] != -1.0)
+
+
 def test_no_fma_flavour(oracle):
     """interpn_hip_set_fma(0) == the reference built without the `fma` feature."""
     from interpn_amd import _lib
