@@ -1,0 +1,132 @@
+"""Multi-GPU evaluation: one process per GPU, observation points sharded, grid replicated.
+
+The hot path has no cross-point dependence (src/multilinear/regular.rs:276-280: `out[i]`
+depends only on the grid and `obs[.][i]`), so the batch shards trivially:
+
+  * rank r of R evaluates the contiguous index range `shard_bounds(P, R, r)` of every
+    `obs[d]` and of `out` (equal sizes +-1);
+  * the read-only grid (`vals`, and the axes of a rectilinear grid) is replicated by ONE
+    broadcast from rank 0 at set-up (RCCL over xGMI when the process group is "nccl"); there is
+    no collective in the evaluation loop;
+  * the reference's "abort at the first failing point" contract is kept by taking the minimum
+    over ranks of (shard offset + local first failing index) — one 8-byte all-reduce at status
+    time, off the data path;
+  * results stay sharded on the devices; `concat_on_host` assembles them on rank 0 for callers
+    that want the reference's single `out` array.
+
+torch.distributed is plumbing here (process group, broadcast); the evaluation itself goes
+through libinterpn_hip.so.  `evaluator_factory` exists so that the sharding logic can be
+exercised on CPU with the gloo backend (tests/test_sharded_gloo.py) — the product default is the
+HIP `Interpolator`.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(npoints: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, equal (+-1) split: the first `npoints % world` ranks get one extra point."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("invalid rank/world")
+    base, extra = divmod(int(npoints), world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def broadcast_grid(vals, grids=None, src: int = 0):
+    """Replicate the grid from `src` to every rank of the default process group (in place).
+
+    `vals` (and each axis in `grids`) must be a torch tensor already allocated with the right
+    shape/dtype on every rank (on the rank's GPU for the nccl/RCCL backend).  Returns them."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(vals, src=src)
+        for g in grids or []:
+            dist.broadcast(g, src=src)
+    return vals, grids
+
+
+class ShardedInterpolator:
+    """One rank's view of a sharded evaluation."""
+
+    def __init__(self, method, kind, *, dims=None, starts=None, steps=None, grids=None, vals=None,
+                 linearize_extrapolation=False, device=-1, dtype=np.float64, evaluator_factory=None):
+        import torch.distributed as dist
+
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.method, self.kind = method, kind
+        if evaluator_factory is None:
+            from .handle import Interpolator
+
+            if kind == "regular":
+                self._interp = Interpolator.regular(method, dims, starts, steps, vals, linearize_extrapolation,
+                                                    device, dtype)
+            else:
+                self._interp = Interpolator.rectilinear(method, grids, vals, linearize_extrapolation, device, dtype)
+        else:
+            self._interp = evaluator_factory(method=method, kind=kind, dims=dims, starts=starts, steps=steps,
+                                             grids=grids, vals=vals,
+                                             linearize_extrapolation=linearize_extrapolation)
+        self._offset = 0
+
+    def bounds(self, npoints: int) -> tuple[int, int]:
+        return shard_bounds(npoints, self.world, self.rank)
+
+    def eval_shard(self, obs_shard, out_shard=None, global_offset: int = 0):
+        """Evaluate this rank's shard (device tensors -> device tensor, asynchronous).
+        `global_offset` is the global index of the shard's first point (for error reporting)."""
+        self._offset = int(global_offset)
+        return self._interp.eval_tensors(obs_shard, out_shard)
+
+    def finish(self) -> None:
+        """Synchronise and raise AssertionError("Unrepresentable coordinate value") on EVERY rank
+        if any rank saw a failing point; `.first_bad_index` is the smallest global index."""
+        import torch
+        import torch.distributed as dist
+
+        sentinel = np.iinfo(np.int64).max
+        local = sentinel
+        msg = "Unrepresentable coordinate value"
+        try:
+            self._interp.finish()
+        except AssertionError as e:
+            local = self._offset + int(getattr(e, "first_bad_index", 0))
+            msg = str(e)
+        if self.world > 1:
+            t = torch.tensor([local], dtype=torch.int64)
+            backend = dist.get_backend()
+            if backend == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            local = int(t.item())
+        if local != sentinel:
+            err = AssertionError(msg)
+            err.first_bad_index = local
+            raise err
+
+    def concat_on_host(self, out_shard, npoints: int, dst: int = 0):
+        """Assemble the full `out` on rank `dst` (numpy array there, None elsewhere).  Host-side
+        convenience, never inside a timed loop."""
+        import torch
+        import torch.distributed as dist
+
+        local = out_shard.detach().cpu() if hasattr(out_shard, "detach") else torch.from_numpy(np.asarray(out_shard))
+        if self.world == 1:
+            return local.numpy()
+        # Shards differ in size by one point and live on the host: ship them as objects through
+        # the process group's store (RCCL cannot move host tensors, gloo's gather wants equal sizes).
+        parts = [None] * self.world if self.rank == dst else None
+        dist.gather_object(local.numpy(), parts, dst=dst)
+        if self.rank != dst:
+            return None
+        full = np.concatenate(parts)
+        assert full.size == npoints
+        return full
+
+    def close(self):
+        if hasattr(self._interp, "close"):
+            self._interp.close()

@@ -117,9 +117,6 @@ __global__ void __launch_bounds__(256) k_coop(const Args a) {
     if (PF) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) x[d] = xn[d];
-      const size_t i1 = i0 + nthreads;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) xn[d] = (i1 < a.npts) ? a.obs[d][i1] : a.start;
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -128,6 +125,13 @@ __global__ void __launch_bounds__(256) k_coop(const Args a) {
         unsigned long long z = (i0 * 3 + d) * 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
         x[d] = -1.0 + 2.0 * (double)(z >> 11) * (1.0 / 9007199254740992.0);
+      } else if (SP >= 4) {
+        x[d] = a.start;
+        if (live) {
+          const double* ptr = &a.obs[d][i0];
+          if (SP == 5) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x[d]) : "v"(ptr) : "memory");
+          else asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x[d]) : "v"(ptr) : "memory");
+        }
       } else x[d] = live ? ((SP == 1 || SP == 2) ? __builtin_nontemporal_load(&a.obs[d][i0]) : a.obs[d][i0]) : a.start;
       double floc = __builtin_floor((x[d] - a.start) / a.step);
       floc = floc > 0 ? floc : 0; int l = (int)floc; l = l < a.n - 2 ? l : a.n - 2; loc[d] = l;
@@ -146,6 +150,11 @@ __global__ void __launch_bounds__(256) k_coop(const Args a) {
     pc[1] = *(const d2u*)(a.vals + toff.y);
     pc[2] = *(const d2u*)(a.vals + toff.z);
     pc[3] = *(const d2u*)(a.vals + toff.w);
+    if (PF) {  // next iteration's coordinates, issued behind the gathers (VMEM returns in order)
+      const size_t i1 = i0 + nthreads;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xn[d] = (i1 < a.npts) ? a.obs[d][i1] : a.start;
+    }
     // write piece q of point r at [quad][r][q]; quad stride 5*4 d2u (80 B per point row -> padding)
 #pragma unroll
     for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * 5 + q] = pc[r];
@@ -162,7 +171,9 @@ __global__ void __launch_bounds__(256) k_coop(const Args a) {
       r[dk] = __builtin_fma(t[1], c1 - c0, c0);
     }
     double res = __builtin_fma(t[2], r[1] - r[0], r[0]);
-    if (NOSTREAM) { if (res == 123.456) a.out[i0] = res; } else if (live) { if (SP >= 2) __builtin_nontemporal_store(res, &a.out[i0]); else a.out[i0] = res; }
+    if (NOSTREAM) { if (res == 123.456) a.out[i0] = res; } else if (live) {
+      if (SP == 6) { double* op = &a.out[i0]; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(op), "v"(res) : "memory"); }
+      else if (SP == 2 || SP == 3) __builtin_nontemporal_store(res, &a.out[i0]); else a.out[i0] = res; }
   }
 }
 
@@ -216,6 +227,14 @@ int main(int argc, char** argv) {
   for (int d = 0; d < 3; ++d) a.obs[d] = dx[d];
   printf("P=%zu grid=%d^3 (%.1f MiB row-major)\n", P, n, G * 8 / 1048576.0);
   const unsigned BLK = 2048 * 2;
+  if (argc > 3 && argv[3][0] == 's') {  // streaming-rate calibration
+    for (int blk : {1024, 2048, 4096, 8192}) {
+      char name[128];
+      snprintf(name, sizeof name, "stream 16B/lane x+y+z->o  %d blocks x 1024", blk);
+      time_it(name, [&] { hipLaunchKernelGGL(k_stream16, dim3(blk), dim3(1024), 0, 0, (const double2*)dx[0], (const double2*)dx[1], (const double2*)dx[2], (double2*)dref, P / 2); }, P);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'c') {  // concurrency: gather-only on GC CUs + stream on SC CUs
     hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     a.out = dout;
@@ -304,6 +323,12 @@ int main(int argc, char** argv) {
       time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 1>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
       snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full nt-loads+nt-stores", SI, SJ, SK);   \
       time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 2>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
+      snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full sc0sc1-loads(serial)", SI, SJ, SK);   \
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 4>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
+      snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full sc1-loads(serial)", SI, SJ, SK);   \
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 5>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
+      snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full sc0sc1 ld+st", SI, SJ, SK);   \
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 6>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
       snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full nt-stores", SI, SJ, SK);   \
       time_it(name, [&] { hipLaunchKernelGGL((k_coop<SI, SJ, SK, false, false, 3>), dim3(BLK), dim3(256), 0, 0, c); }, P); \
       snprintf(name, sizeof name, "  coop quad step(%d,%d,%d)    full+prefetch [mismatch %zu]", SI, SJ, SK, bad);   \
