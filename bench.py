@@ -192,7 +192,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "kernel": "interpn::k_linear_regular<double,3,true,U>",
+                "kernel": "interpn::k_linear3_brick<false,true,SI,SJ> (bricked grid, quad-cooperative gather)",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_point": BYTES_PER_POINT,
             },

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.json single-GPU configurations (device-resident obs, kernel time by HIP
+events on the launch stream).  Not the driver's bench (that is bench.py = configs[1]); this is
+the per-config table quoted in DESIGN.md."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(name, method, kind, n_axis, ndims, P, linearize=False, dtype=np.float64, reps=7):
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    rng = np.random.default_rng(1)
+    g = np.linspace(-1.0, 1.0, n_axis)
+    step = g[1] - g[0]
+    grids = []
+    for d in range(ndims):
+        gg = g.copy()
+        if kind == "rectilinear":
+            j = (rng.random(n_axis) - 0.5) * 0.5 * step
+            j[0] = j[-1] = 0
+            gg = gg + j
+        grids.append(gg.astype(dtype))
+    vals = rng.uniform(-1, 1, n_axis**ndims).astype(dtype)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular(method, [n_axis] * ndims, np.full(ndims, -1.0, dtype=dtype),
+                                              np.full(ndims, step, dtype=dtype), vals, linearize, 0, dtype)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(method, grids, vals, linearize, 0, dtype)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    obs = [torch.rand(P, dtype=tdt, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(ndims)]
+    out = torch.empty(P, dtype=tdt, device=dev)
+    for _ in range(2):
+        it.eval_tensors(obs, out)
+    it.finish()
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        it.eval_tensors(obs, out)
+        b.record()
+        it.finish()
+        ms.append(a.elapsed_time(b))
+    ms.sort()
+    med = ms[len(ms) // 2]
+    bpp = np.dtype(dtype).itemsize * (ndims + 1)
+    rec = {"config": name, "ms": round(med, 3), "Mpts/s": round(P / med / 1e3, 1), "GB/s": round(P * bpp / med / 1e6, 1),
+           "frac_of_8TB/s": round(P * bpp / med / 1e6 / 8000, 4)}
+    print(json.dumps(rec), flush=True)
+    it.close()
+    del obs, out
+    torch.cuda.empty_cache()
+    return rec
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    cfgs = [
+        ("cfg2 3D linear regular 64^3 1e8", "linear", "regular", 64, 3, 100_000_000, False),
+        ("cfg3 3D linear rectilinear 64^3 1e8", "linear", "rectilinear", 64, 3, 100_000_000, False),
+        ("cfg4 4D cubic regular 32^4 1e7 (linearize=false)", "cubic", "regular", 32, 4, 10_000_000, False),
+        ("cfg4 4D cubic regular 32^4 1e7 (linearize=true)", "cubic", "regular", 32, 4, 10_000_000, True),
+        ("cfg5-shard 3D linear regular 128^3 1e8", "linear", "regular", 128, 3, 100_000_000, False),
+        ("extra 3D cubic regular 64^3 1e7", "cubic", "regular", 64, 3, 10_000_000, False),
+        ("extra 3D cubic rectilinear 64^3 1e7", "cubic", "rectilinear", 64, 3, 10_000_000, False),
+        ("extra 2D linear regular 1000^2 1e8", "linear", "regular", 1000, 2, 100_000_000, False),
+        ("extra 4D linear regular 32^4 1e8", "linear", "regular", 32, 4, 100_000_000, False),
+    ]
+    for c in cfgs:
+        if args.only and args.only not in c[0]:
+            continue
+        run(*c)
+    if not args.only or "f32" in args.only:
+        run("extra f32 3D linear regular 64^3 1e8", "linear", "regular", 64, 3, 100_000_000, False, np.float32)
