@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -308,25 +309,57 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     total += grid_lens[i];
   }
   g.grid_total = total;
-  // All axes in one device allocation (each axis 16-byte aligned for the LDS staging loop).
-  std::vector<size_t> offs(ngrids);
+  // Axis image: per axis the coordinates (16-byte aligned) followed by the bucket table
+  // ((M+1) x u32, M = 2n) when the axis is strictly increasing and finite; otherwise M = 0 and the
+  // kernels bisect with the reference's probe sequence (its `new` only checks g[1] > g[0],
+  // multilinear/rectilinear.rs:195, so unsorted axes are legal input).
   size_t bytes = 0;
   for (size_t i = 0; i < ngrids; ++i) {
-    offs[i] = bytes;
-    bytes += (grid_lens[i] * sizeof(T) + 15) & ~(size_t)15;
+    const size_t n = grid_lens[i];
+    bool sorted = true;
+    for (size_t k = 0; k + 1 < n && sorted; ++k) sorted = grids[i][k + 1] > grids[i][k];
+    sorted = sorted && std::isfinite((double)grids[i][0]) && std::isfinite((double)grids[i][n - 1]);
+    const double span = (double)grids[i][n - 1] - (double)grids[i][0];
+    int M = 0;
+    if (sorted && span > 0 && std::isfinite(span) && n <= ((size_t)1 << 28)) M = (int)(2 * n);
+    g.axis_buckets[i] = M;
+    g.axis_g0[i] = (double)grids[i][0];
+    g.axis_scale[i] = M ? (double)(T)((double)M / span) : 0.0;
+    if (M && !(g.axis_scale[i] > 0 && std::isfinite(g.axis_scale[i]))) { g.axis_buckets[i] = 0; M = 0; }
+    g.axis_g_off[i] = (unsigned)bytes;
+    bytes += (n * sizeof(T) + 15) & ~(size_t)15;
+    g.axis_tab_off[i] = (unsigned)bytes;
+    bytes += (((size_t)M + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
+    if (bytes > 0xFFFFFF00ull) {
+      interpn_hip_destroy(h);
+      return INTERPN_HIP_ERR_UNSUPPORTED;
+    }
   }
+  g.axis_image_bytes = (unsigned)bytes;
   hipError_t e = hipMalloc(&h->grids_owned, bytes);
+  if (e == hipSuccess) e = hipMemset(h->grids_owned, 0, bytes);
   if (e != hipSuccess) {
     interpn_hip_destroy(h);
     return hip_fail(e);
   }
+  g.axis_image = h->grids_owned;
   for (size_t i = 0; i < ngrids; ++i) {
-    e = hipMemcpy((char*)h->grids_owned + offs[i], grids[i], grid_lens[i] * sizeof(T), hipMemcpyHostToDevice);
+    char* gdev = (char*)h->grids_owned + g.axis_g_off[i];
+    e = hipMemcpy(gdev, grids[i], grid_lens[i] * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess && g.axis_buckets[i])
+      e = build_buckets<T>(reinterpret_cast<const T*>(gdev), g.n[i], g.axis_buckets[i], (T)g.axis_g0[i],
+                           (T)g.axis_scale[i], reinterpret_cast<unsigned*>((char*)h->grids_owned + g.axis_tab_off[i]),
+                           nullptr);
     if (e != hipSuccess) {
       interpn_hip_destroy(h);
       return hip_fail(e);
     }
-    g.grid[i] = (char*)h->grids_owned + offs[i];
+    g.grid[i] = gdev;
+  }
+  e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) {
+    interpn_hip_destroy(h);
+    return hip_fail(e);
   }
   st = finish_create(h, vals, nvals, sizeof(T), vals_mem);
   if (st) {
@@ -341,7 +374,8 @@ template <typename T>
 hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
                   hipStream_t stream) {
   if (npts == 0) return hipSuccess;
-  if (!fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
+  const bool force_generic = getenv("INTERPN_HIP_FORCE_GENERIC") != nullptr;  // testing aid
+  if (force_generic || !fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
   if (g.method == kLinear)
     return g.kind == kRegular ? launch_linear_regular<T>(g, obs, out, npts, first_bad, stream)
                               : launch_linear_rectilinear<T>(g, obs, out, npts, first_bad, stream);
@@ -351,7 +385,7 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
 
 hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
                       unsigned long long* first_bad, hipStream_t stream) {
-  if (g.bricks && npts)
+  if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC"))
     return launch_linear3_brick(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts,
                                 first_bad, stream);
   if (g.dtype == kF64)

@@ -110,6 +110,43 @@ __device__ __forceinline__ int partition_point_lt(GridPtr g, int n, T x) {
   return base + ((g[base] < x) ? 1 : 0);
 }
 
+// Rectilinear axis as the kernels see it: coordinates plus (for strictly increasing, finite
+// axes) a bucket table that brackets the bisection.  tab[b] = number of coordinates whose own
+// bucket index is < b, so for a query x in bucket b the answer lies in [tab[b], tab[b+1]].
+// bucket_of() is monotone non-decreasing in x (subtract, multiply by a positive constant,
+// truncate, clamp), and the same function is applied to the coordinates when the table is
+// built (k_build_buckets), therefore every coordinate in an earlier bucket is < x and every one
+// in a later bucket is >= x, for any rounding: the count of coordinates < x is exactly what
+// core::slice::partition_point returns on a sorted slice.
+template <typename T>
+struct Axis {
+  const T* g;
+  const unsigned* tab;
+  int n;
+  int M;  // number of buckets, 0 = no table (axis not proven sorted): std probe sequence
+  T g0;
+  T scale;
+};
+
+template <typename T>
+__device__ __forceinline__ int bucket_of(T x, T g0, T scale, int M) {
+  const T u = (x - g0) * scale;
+  return u >= (T)(M - 1) ? (M - 1) : (u > (T)0 ? (int)u : 0);
+}
+
+template <typename T>
+__device__ __forceinline__ int axis_partition_point(const Axis<T>& ax, T x) {
+  if (ax.M > 0) {
+    if (!(x == x)) return 0;  // NaN: `g < NaN` is false for every g
+    const int b = bucket_of<T>(x, ax.g0, ax.scale, ax.M);
+    int idx = (int)ax.tab[b];
+    const int hi = (int)ax.tab[b + 1];
+    while (idx < hi && ax.g[idx] < x) ++idx;
+    return idx;
+  }
+  return partition_point_lt<T>(ax.g, ax.n, x);
+}
+
 // ---------------------------------------------------------------------------
 // Linear tree: reduce dims 0..D-1 (dim 0 innermost) on a W-wide leaf of the last dim.
 // Same dependency tree as src/multilinear/regular.rs:347-393 / regular_recursive.rs:348-389.
@@ -166,7 +203,7 @@ template <typename T>
 struct CubicDimRegular {
   T tt;        // t (None), -t (Low), t-1 (High)
   int sat;     // Sat
-  bool linear; // OutsideLow/OutsideHigh with linearize_extrapolation
+  int linear;  // OutsideLow/OutsideHigh with linearize_extrapolation
 };
 
 template <bool FMA, typename T>
@@ -198,8 +235,8 @@ __device__ __forceinline__ T cubic_regular_node(T v0, T v1, T v2, T v3, const Cu
 template <typename T>
 struct CubicDimRect {
   int sat;
-  bool linear;
-  bool fma_linear;  // recursive arm fuses the linearized branch (rectilinear_recursive.rs:467,527)
+  int linear;      // OutsideLow/OutsideHigh with linearize_extrapolation
+  int fma_linear;  // recursive arm fuses the linearized branch (rectilinear_recursive.rs:467,527)
   T t;
   // cd(y0,y1,y2,hA,hB) = a*b + c*d, a = hA/(hA+hB), b = (y2-y1)/hB, c = hB/(hB+hA), d = (y1-y0)/hA
   //   None: k0 = cd(v0,v1,v2, h01/h12, 1),  k1 = cd(v1,v2,v3, 1, h23/h12)

@@ -30,6 +30,15 @@ struct GridDesc {
   size_t nvals = 0;
   const void* grid[8] = {nullptr};  // device, rectilinear axes
   size_t grid_total = 0;            // sum of n[d]
+  // Rectilinear axes as one device image: per axis the coordinates (8-byte aligned) followed by
+  // the bucket table ((M+1) x u32), see interpn_device.h::Axis.  Staged into LDS when small.
+  const void* axis_image = nullptr;
+  unsigned axis_image_bytes = 0;
+  unsigned axis_g_off[8] = {0};    // byte offsets inside the image
+  unsigned axis_tab_off[8] = {0};
+  int axis_buckets[8] = {0};       // M per axis, 0 = no table
+  double axis_g0[8] = {0};
+  double axis_scale[8] = {0};
   // Optional bricked copy of `vals` (3-D multilinear f64 only; see k_linear3_brick.hip):
   // 2 x 2 x 4 element bricks of one 128-B line, brick steps (brick_step[0], brick_step[1], 3).
   const void* bricks = nullptr;
@@ -64,6 +73,10 @@ void brick3_geometry(const int n[3], int si, int sj, unsigned nb[3], size_t* byt
 hipError_t build_bricks3(const GridDesc& g, void* bricks, hipStream_t stream);
 hipError_t launch_linear3_brick(const GridDesc& g, const double* const* obs, double* out, size_t npts,
                                 unsigned long long* first_bad, hipStream_t stream);
+
+// Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
+template <typename T>
+hipError_t build_buckets(const T* g, int n, int M, T g0, T scale, unsigned* tab, hipStream_t stream);
 
 // check_bounds: OR into flag[0] whether any of x[0..n) violates [lo, hi] by atol or more
 // (src/multilinear/regular.rs:168-171).

@@ -36,17 +36,50 @@ struct RegularArgs {
   int linearize;
 };
 
+// Axis image (GridDesc::axis_image) as kernel arguments.
+template <typename T, int N>
+struct AxisArgs {
+  const unsigned char* image;  // device
+  unsigned image_bytes;
+  unsigned g_off[N];
+  unsigned tab_off[N];
+  int n[N];
+  int M[N];
+  T g0[N];
+  T scale[N];
+  int use_lds;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ Axis<T> make_axis(const AxisArgs<T, N>& a, const unsigned char* base, int d) {
+  Axis<T> ax;
+  ax.g = reinterpret_cast<const T*>(base + a.g_off[d]);
+  ax.tab = reinterpret_cast<const unsigned*>(base + a.tab_off[d]);
+  ax.n = a.n[d];
+  ax.M = a.M[d];
+  ax.g0 = a.g0[d];
+  ax.scale = a.scale[d];
+  return ax;
+}
+
+// Copy the axis image into LDS (whole workgroup), 4 bytes per thread and step.
+template <typename T, int N>
+__device__ __forceinline__ void stage_axes(const AxisArgs<T, N>& a, unsigned char* lds) {
+  const unsigned words = a.image_bytes >> 2;
+  const unsigned* src = reinterpret_cast<const unsigned*>(a.image);
+  unsigned* dst = reinterpret_cast<unsigned*>(lds);
+  for (unsigned k = threadIdx.x; k < words; k += kBlock) dst[k] = src[k];
+  __syncthreads();
+}
+
 template <typename T, int N>
 struct RectArgs {
   const T* vals;
   const T* obs[N];
   T* out;
   size_t npts;
-  const T* grid[N];
-  int n[N];
-  unsigned lds_off[N];  // element offset of each axis inside the LDS image
+  AxisArgs<T, N> ax;
   unsigned stride[N];
-  int use_lds;
   int linearize;
 };
 
@@ -97,7 +130,8 @@ __global__ void __launch_bounds__(kBlock) k_linear_regular(const RegularArgs<T, 
 // ===========================================================================
 // multilinear::rectilinear — src/multilinear/rectilinear.rs:210-231, :244-370
 template <typename T, int N, bool FMA, int U, bool LDS>
-__device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a, const T* lds) {
+__device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a, const unsigned char* lds) {
+  const unsigned char* axbase = LDS ? lds : a.ax.image;
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   for (size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x; i0 < a.npts; i0 += nthreads * U) {
     T x[U][N];
@@ -114,13 +148,13 @@ __device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a,
       base[u] = 0;
 #pragma unroll
       for (int d = 0; d < N; ++d) {
-        const T* g = LDS ? (lds + a.lds_off[d]) : a.grid[d];
-        const int pp = partition_point_lt<T>(g, a.n[d], x[u][d]);  // rectilinear.rs:363
+        const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
+        const int pp = axis_partition_point<T>(ax, x[u][d]);  // rectilinear.rs:363
         int loc = pp - 1;
         loc = loc > 0 ? loc : 0;
-        loc = loc < a.n[d] - 2 ? loc : a.n[d] - 2;  // rectilinear.rs:365-367
-        const T x0 = g[loc];
-        const T x1 = g[loc + 1];
+        loc = loc < ax.n - 2 ? loc : ax.n - 2;  // rectilinear.rs:365-367
+        const T x0 = ax.g[loc];
+        const T x1 = ax.g[loc + 1];
         const T step = x1 - x0;
         t[u][d] = (x[u][d] - x0) / step;  // rectilinear.rs:310-313 (same value at every node of dim d)
         base[u] += (unsigned)loc * a.stride[d];
@@ -138,22 +172,12 @@ __device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a,
   }
 }
 
-template <typename T, int N>
-__device__ __forceinline__ void stage_grids(const RectArgs<T, N>& a, T* lds) {
-#pragma unroll
-  for (int d = 0; d < N; ++d) {
-    for (int k = threadIdx.x; k < a.n[d]; k += kBlock) lds[a.lds_off[d] + k] = a.grid[d][k];
-  }
-  __syncthreads();
-}
-
 template <typename T, int N, bool FMA, int U>
 __global__ void __launch_bounds__(kBlock) k_linear_rectilinear(const RectArgs<T, N> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* lds = reinterpret_cast<T*>(smem_raw);
-  if (a.use_lds) {
-    stage_grids<T, N>(a, lds);
-    linear_rectilinear_body<T, N, FMA, U, true>(a, lds);
+  if (a.ax.use_lds) {
+    stage_axes<T, N>(a.ax, smem_raw);
+    linear_rectilinear_body<T, N, FMA, U, true>(a, smem_raw);
   } else {
     linear_rectilinear_body<T, N, FMA, U, false>(a, nullptr);
   }
@@ -199,7 +223,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_regular(const RegularArgs<T, N
       const T index_one_loc = mul_add<false>(a.step[d], (T)(loc + 1), a.start[d]);
       const T t = (x - index_one_loc) / a.step[d];
       dim[d].sat = sat;
-      dim[d].linear = outside && a.linearize;
+      dim[d].linear = (outside && a.linearize) ? 1 : 0;
       dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
       base += (unsigned)loc * a.stride[d];
     }
@@ -219,9 +243,11 @@ struct CubicRectNode {
   }
 };
 
-template <typename T, typename GridPtr>
-__device__ __forceinline__ int cubic_rect_locate(GridPtr g, int n, T x, int linearize, bool fma_linear, CubicDimRect<T>& d) {
-  const int iloc = partition_point_lt<T>(g, n, x) - 2;  // rectilinear.rs:377
+template <typename T>
+__device__ __forceinline__ int cubic_rect_locate(const Axis<T>& ax, T x, int linearize, bool fma_linear, CubicDimRect<T>& d) {
+  const T* g = ax.g;
+  const int n = ax.n;
+  const int iloc = axis_partition_point<T>(ax, x) - 2;  // rectilinear.rs:377
   int loc = iloc > 0 ? iloc : 0;
   loc = loc < n - 4 ? loc : n - 4;  // rectilinear.rs:379-381
   bool outside = false;
@@ -230,14 +256,15 @@ __device__ __forceinline__ int cubic_rect_locate(GridPtr g, int n, T x, int line
   else if (iloc == n - 2) { d.sat = kSatHigh; outside = true; }
   else if (iloc == n - 3) { d.sat = kSatHigh; }
   else { d.sat = kSatNone; }
-  d.linear = outside && linearize;
-  d.fma_linear = fma_linear;
+  d.linear = (outside && linearize) ? 1 : 0;
+  d.fma_linear = fma_linear ? 1 : 0;
   cubic_rect_dim_setup<T>(g, loc, x, d);
   return loc;
 }
 
 template <typename T, int N, bool FMA, bool LDS>
-__device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, const T* lds) {
+__device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, const unsigned char* lds) {
+  const unsigned char* axbase = LDS ? lds : a.ax.image;
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
     CubicDimRect<T> dim[N];
@@ -245,8 +272,8 @@ __device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, 
 #pragma unroll
     for (int d = 0; d < N; ++d) {
       const T x = a.obs[d][i];
-      const T* g = LDS ? (lds + a.lds_off[d]) : a.grid[d];
-      const int loc = cubic_rect_locate<T>(g, a.n[d], x, a.linearize, /*fma_linear=*/false, dim[d]);
+      const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
+      const int loc = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);
       base += (unsigned)loc * a.stride[d];
     }
     typedef CubicRectNode<T, FMA> Node;
@@ -258,10 +285,9 @@ __device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, 
 template <typename T, int N, bool FMA>
 __global__ void __launch_bounds__(kBlock) k_cubic_rectilinear(const RectArgs<T, N> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* lds = reinterpret_cast<T*>(smem_raw);
-  if (a.use_lds) {
-    stage_grids<T, N>(a, lds);
-    cubic_rectilinear_body<T, N, FMA, true>(a, lds);
+  if (a.ax.use_lds) {
+    stage_axes<T, N>(a.ax, smem_raw);
+    cubic_rectilinear_body<T, N, FMA, true>(a, smem_raw);
   } else {
     cubic_rectilinear_body<T, N, FMA, false>(a, nullptr);
   }
@@ -291,6 +317,16 @@ struct GenericArgs {
   int fma_linear;  // cubic rectilinear: linearized branch fused (recursive arm, N >= 5)
 };
 
+// Out-of-line node evaluators for the runtime-N kernel (keeps its code size bounded).
+template <bool FMA, typename T>
+__device__ __attribute__((noinline)) T cubic_rect_node_ool(T v0, T v1, T v2, T v3, int sat, int linear, int fma_linear,
+                                                           T t, T r0, T a0, T c0, T r1, T a1, T c1) {
+  CubicDimRect<T> dr;
+  dr.sat = sat; dr.linear = linear; dr.fma_linear = fma_linear; dr.t = t;
+  dr.r0 = r0; dr.a0 = a0; dr.c0 = c0; dr.r1 = r1; dr.a1 = a1; dr.c1 = c1;
+  return cubic_rect_node<FMA, T>(v0, v1, v2, v3, dr);
+}
+
 template <typename T, int METHOD, int KIND, bool FMA>
 __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
   constexpr int FP = METHOD == kLinear ? 2 : 4;
@@ -300,7 +336,9 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
     T tlin[kMaxDims];
     CubicDimRegular<T> dreg[kMaxDims];
-    CubicDimRect<T> drect[kMaxDims];
+    // per-dimension state of the rectilinear cubic node, kept as separate arrays (runtime-indexed)
+    int rc_sat[kMaxDims], rc_lin[kMaxDims];
+    T rc_t[kMaxDims], rc_r0[kMaxDims], rc_a0[kMaxDims], rc_c0[kMaxDims], rc_r1[kMaxDims], rc_a1[kMaxDims], rc_c1[kMaxDims];
     unsigned long long base = 0;
     bool ok = true;
     for (int d = 0; d < N; ++d) {
@@ -328,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
           const T iol = mul_add<false>(a.step[d], (T)(loc + 1), a.start[d]);
           const T t = (x - iol) / a.step[d];
           dreg[d].sat = sat;
-          dreg[d].linear = outside && a.linearize;
+          dreg[d].linear = (outside && a.linearize) ? 1 : 0;
           dreg[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
         }
       } else {
@@ -342,7 +380,13 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
           const T step = x1 - x0;
           tlin[d] = (x - x0) / step;
         } else {
-          loc = cubic_rect_locate<T>(g, a.n[d], x, a.linearize, a.fma_linear != 0, drect[d]);
+          Axis<T> ax;
+          ax.g = g; ax.tab = nullptr; ax.n = a.n[d]; ax.M = 0; ax.g0 = (T)0; ax.scale = (T)0;
+          CubicDimRect<T> dr;
+          loc = cubic_rect_locate<T>(ax, x, a.linearize, a.fma_linear != 0, dr);
+          rc_sat[d] = dr.sat; rc_lin[d] = dr.linear; rc_t[d] = dr.t;
+          rc_r0[d] = dr.r0; rc_a0[d] = dr.a0; rc_c0[d] = dr.c0;
+          rc_r1[d] = dr.r1; rc_a1[d] = dr.a1; rc_c1[d] = dr.c1;
         }
       }
       base += (unsigned long long)loc * a.stride[d];
@@ -357,7 +401,8 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
       } else if constexpr (KIND == kRegular) {
         return cubic_regular_node<FMA, T>(v[0], v[1], v[2], v[3], dreg[d]);
       } else {
-        return cubic_rect_node<FMA, T>(v[0], v[1], v[2], v[3], drect[d]);
+        return cubic_rect_node_ool<FMA, T>(v[0], v[1], v[2], v[3], rc_sat[d], rc_lin[d], a.fma_linear, rc_t[d],
+                                           rc_r0[d], rc_a0[d], rc_c0[d], rc_r1[d], rc_a1[d], rc_c1[d]);
       }
     };
 
@@ -375,6 +420,9 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
         }
       }
     }
+#ifdef INTERPN_DEBUG_PRINT
+    if (i < 16) printf("i=%d base=%llu v=%g %g %g %g res=%g\n", (int)i, base, (double)store[N-1][0], (double)store[N-1][1], (double)store[N-1][2], (double)store[N-1][3], (double)node(store[N - 1], N - 1));
+#endif
     a.out[i] = node(store[N - 1], N - 1);
   }
 }

@@ -25,6 +25,30 @@ hipError_t launch_check_bounds(const T* x, size_t n, T lo, T hi, T atol, unsigne
   return hipGetLastError();
 }
 
+// tab[b] = first k with bucket_of(g[k]) >= b, b = 0..M (bucket_of is non-decreasing in k for a
+// sorted axis, so a binary search finds it); tab[M] = n.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_buckets(const T* __restrict__ g, int n, int M, T g0, T scale,
+                                                          unsigned* __restrict__ tab) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b > M) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (bucket_of<T>(g[mid], g0, scale, M) < b) lo = mid + 1; else hi = mid;
+  }
+  tab[b] = (unsigned)lo;
+}
+
+template <typename T>
+hipError_t build_buckets(const T* g, int n, int M, T g0, T scale, unsigned* tab, hipStream_t stream) {
+  const unsigned blocks = (unsigned)((M + 1 + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL((k_build_buckets<T>), dim3(blocks), dim3(kBlock), 0, stream, g, n, M, g0, scale, tab);
+  return hipGetLastError();
+}
+template hipError_t build_buckets<double>(const double*, int, int, double, double, unsigned*, hipStream_t);
+template hipError_t build_buckets<float>(const float*, int, int, float, float, unsigned*, hipStream_t);
+
 template hipError_t launch_check_bounds<double>(const double*, size_t, double, double, double, unsigned*, hipStream_t);
 template hipError_t launch_check_bounds<float>(const float*, size_t, float, float, float, unsigned*, hipStream_t);
 

@@ -10,7 +10,7 @@
 // become a single L2 request.  Pieces are transposed back through LDS and every lane finishes
 // its own point with the reference's arithmetic, so results are bit-identical to the C-order
 // kernels (same values, same operation order).
-#include "interpn_kernels.h"
+#include "rect_args.h"
 
 namespace interpn {
 
@@ -22,11 +22,9 @@ struct Brick3Args {
   size_t npts;
   double start[3];
   double step[3];
-  const double* grid[3];
   int n[3];
-  unsigned lds_off[3];
+  AxisArgs<double, 3> ax;
   unsigned nbj, nbk;
-  int use_lds;
 };
 
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -48,14 +46,9 @@ __global__ void __launch_bounds__(kBlock) k_linear3_brick(const Brick3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   d2u* lds_piece = reinterpret_cast<d2u*>(smem_raw);                                   // [quad][r][kPieceRow]
   unsigned* lds_off = reinterpret_cast<unsigned*>(smem_raw + kBlock * kPieceRow * 16);  // [quad][piece][r]
-  const double* lds_grid = reinterpret_cast<const double*>(smem_raw + kBlock * kPieceRow * 16 + kBlock * 16);
-  if (RECT && a.use_lds) {
-    double* w = const_cast<double*>(lds_grid);
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-      for (int k = threadIdx.x; k < a.n[d]; k += kBlock) w[a.lds_off[d] + k] = a.grid[d][k];
-    __syncthreads();
-  }
+  unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * 16 + kBlock * 16;
+  if (RECT && a.ax.use_lds) stage_axes<double, 3>(a.ax, lds_axes);
+  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
   const unsigned lane = threadIdx.x;
   const unsigned q = lane & 3;
   const unsigned quad = lane >> 2;
@@ -71,12 +64,12 @@ __global__ void __launch_bounds__(kBlock) k_linear3_brick(const Brick3Args a) {
     for (int d = 0; d < 3; ++d) {
       if (RECT) {
         const double x = live ? a.obs[d][i0] : 0.0;
-        const double* g = a.use_lds ? (lds_grid + a.lds_off[d]) : a.grid[d];
-        int l = partition_point_lt<double>(g, a.n[d], x) - 1;  // multilinear/rectilinear.rs:363
+        const Axis<double> ax = make_axis<double, 3>(a.ax, axis_base, d);
+        int l = axis_partition_point<double>(ax, x) - 1;       // multilinear/rectilinear.rs:363
         l = l > 0 ? l : 0;
         l = l < a.n[d] - 2 ? l : a.n[d] - 2;                   // rectilinear.rs:365-367
-        const double x0 = g[l];
-        const double x1 = g[l + 1];
+        const double x0 = ax.g[l];
+        const double x1 = ax.g[l + 1];
         const double step = x1 - x0;
         t[d] = (x - x0) / step;                                // rectilinear.rs:310-313
         loc[d] = l;
@@ -181,24 +174,19 @@ hipError_t launch_linear3_brick(const GridDesc& g, const double* const* obs, dou
   a.out = out;
   a.first_bad = first_bad;
   a.npts = npts;
-  unsigned off = 0;
   for (int d = 0; d < 3; ++d) {
     a.obs[d] = obs[d];
     a.start[d] = g.start[d];
     a.step[d] = g.step[d];
-    a.grid[d] = static_cast<const double*>(g.grid[d]);
     a.n[d] = g.n[d];
-    a.lds_off[d] = off;
-    off += (unsigned)g.n[d];
   }
   a.nbj = g.brick_nb[1];
   a.nbk = g.brick_nb[2];
   size_t lds = (size_t)kBlock * kPieceRow * 16 + (size_t)kBlock * 16;
-  a.use_lds = 0;
-  if (g.kind == kRectilinear) {
-    const size_t gb = (size_t)off * sizeof(double);
-    if (gb <= kMaxGridLdsBytes) { a.use_lds = 1; lds += gb; }
-  }
+  a.ax.use_lds = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  if (g.kind == kRectilinear) lds += fill_axis_args<double, 3>(g, a.ax);
   const unsigned blocks = grid_blocks(npts, 1, g.cfg);
   if (g.kind == kRegular)
     return g.fma ? launch_steps<false, true>(g, a, lds, blocks, stream) : launch_steps<false, false>(g, a, lds, blocks, stream);

@@ -5,6 +5,22 @@
 namespace interpn {
 
 template <typename T, int N>
+inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax) {
+  ax.image = static_cast<const unsigned char*>(g.axis_image);
+  ax.image_bytes = g.axis_image_bytes;
+  for (int d = 0; d < N; ++d) {
+    ax.g_off[d] = g.axis_g_off[d];
+    ax.tab_off[d] = g.axis_tab_off[d];
+    ax.n[d] = g.n[d];
+    ax.M[d] = g.axis_buckets[d];
+    ax.g0[d] = (T)g.axis_g0[d];
+    ax.scale[d] = (T)g.axis_scale[d];
+  }
+  ax.use_lds = g.axis_image_bytes <= kMaxGridLdsBytes;
+  return ax.use_lds ? g.axis_image_bytes : 0;
+}
+
+template <typename T, int N>
 inline size_t fill_rect_args(const GridDesc& g, const T* const* obs, T* out, size_t npts, RectArgs<T, N>& a) {
   a.vals = static_cast<const T*>(g.vals);
   a.out = out;
@@ -15,17 +31,8 @@ inline size_t fill_rect_args(const GridDesc& g, const T* const* obs, T* out, siz
     a.stride[d] = acc;
     acc *= (unsigned)g.n[d];
   }
-  unsigned off = 0;
-  for (int d = 0; d < N; ++d) {
-    a.obs[d] = obs[d];
-    a.grid[d] = static_cast<const T*>(g.grid[d]);
-    a.n[d] = g.n[d];
-    a.lds_off[d] = off;
-    off += (unsigned)g.n[d];
-  }
-  const size_t lds_bytes = (size_t)off * sizeof(T);
-  a.use_lds = lds_bytes <= kMaxGridLdsBytes;
-  return a.use_lds ? lds_bytes : 0;
+  for (int d = 0; d < N; ++d) a.obs[d] = obs[d];
+  return fill_axis_args<T, N>(g, a.ax);
 }
 
 }  // namespace interpn

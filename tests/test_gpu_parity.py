@@ -93,6 +93,21 @@ def test_linear3_brick_layouts(oracle, monkeypatch, kind, layout, axis):
         assert np.all(got[4321:] == -1.0) and np.all(got[:4321] != -1.0)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_generic_kernel_at_low_n(oracle, monkeypatch, method, kind, n, dtype):
+    """The runtime-N kernel (normally N >= 7 linear / N >= 5 cubic) forced onto small N, where the
+    templated kernels and the oracle's flattened arm give the answer: for N <= 4 no FMA site
+    differs between the arms except the two the kernel takes as flags, which follow N."""
+    monkeypatch.setenv("INTERPN_HIP_FORCE_GENERIC", "1")
+    m = 5 if method == "linear" else 6
+    case = synthetic_case(method, kind, n, [m + d for d in range(n)], 20_011, 500 + n, dtype, linearize=True,
+                          extrap=0.3)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
 def test_no_fma_flavour(oracle):
     """interpn_hip_set_fma(0) == the reference built without the `fma` feature."""
     from interpn_amd import _lib
