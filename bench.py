@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--grid", type=int, default=GRID_N, help="grid points per axis")
     ap.add_argument("--cpu-sample", type=int, default=0, help="points for the CPU baseline (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # Test aids for a 1-GPU box: run the multi-rank control flow with every rank on cuda:0 over
+    # gloo (RCCL refuses two ranks on one device).  The driver never passes these.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--same-device", action="store_true")
     return ap.parse_args()
 
 
@@ -90,10 +94,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: interpn_amd has no CPU path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     P = args.points
     n = args.grid
@@ -108,7 +118,12 @@ def main():
         vals_host = np.random.default_rng(1).uniform(-1.0, 1.0, n**NDIMS)
         vals_dev.copy_(torch.from_numpy(vals_host))
     if world > 1:
-        dist.broadcast(vals_dev, src=0)
+        if args.backend == "nccl":
+            dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
+        else:
+            stage = vals_dev.cpu()
+            dist.broadcast(stage, src=0)
+            vals_dev.copy_(stage)
     it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals_dev, device=local_rank,
                                           dtype=np.float64)
 
@@ -146,7 +161,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])

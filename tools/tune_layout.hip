@@ -220,9 +220,13 @@ int main(int argc, char** argv) {
   for (int d = 0; d < 3; ++d) {
     uint64_t s = 0x9E3779B97F4A7C15ull * (d + 1);
     for (size_t i = 0; i < P; ++i) { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; hx[i] = -1.0 + 2.0 * (double)(z >> 11) * (1.0 / 9007199254740992.0); }
-    CK(hipMalloc(&dx[d], P * 8)); CK(hipMemcpy(dx[d], hx.data(), P * 8, hipMemcpyHostToDevice));
+    if (getenv("UNCACHED_OBS")) { CK(hipExtMallocWithFlags((void**)&dx[d], P * 8, hipDeviceMallocUncached)); }
+    else CK(hipMalloc(&dx[d], P * 8));
+    CK(hipMemcpy(dx[d], hx.data(), P * 8, hipMemcpyHostToDevice));
   }
-  CK(hipMalloc(&dout, P * 8)); CK(hipMalloc(&dref, P * 8));
+  if (getenv("UNCACHED_OUT")) { CK(hipExtMallocWithFlags((void**)&dout, P * 8, hipDeviceMallocUncached)); }
+  else CK(hipMalloc(&dout, P * 8));
+  CK(hipMalloc(&dref, P * 8));
   Args a; a.vals = dv; a.out = dref; a.npts = P; a.start = -1.0; a.step = 2.0 / (n - 1); a.rinv = 1.0 / a.step; a.n = n; a.nbj = a.nbk = 0; a.in_mask = ~(size_t)0; a.out_mask = ~(size_t)0;
   for (int d = 0; d < 3; ++d) a.obs[d] = dx[d];
   printf("P=%zu grid=%d^3 (%.1f MiB row-major)\n", P, n, G * 8 / 1048576.0);
