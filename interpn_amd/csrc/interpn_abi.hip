@@ -168,7 +168,7 @@ int resolve_device(int device, int* out) {
   return INTERPN_HIP_OK;
 }
 
-// Bricked copy of the grid for the 3-D multilinear f64 kernels (k_linear3_brick.hip).  The layout
+// Bricked copy of the grid for the multilinear kernels with 3 <= N <= 6 (k_linear_brick.hip).  The layout
 // is chosen by where the table will live: fully overlapped bricks (one line per cell, 5.3x the
 // grid) while that still fits the 4 MiB XCD L2 or once the grid is far beyond it anyway (served
 // by the 256 MiB Infinity Cache, where fewer lines per point matter most); in between, the
@@ -176,7 +176,7 @@ int resolve_device(int device, int* out) {
 // overrides (tuning).
 int maybe_build_bricks(interpn_hip_interp* h) {
   GridDesc& g = h->desc;
-  if (!(g.method == kLinear && g.dtype == kF64 && g.ndims == 3)) return INTERPN_HIP_OK;
+  if (!(g.method == kLinear && g.ndims >= 3 && g.ndims <= 6)) return INTERPN_HIP_OK;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
   int si = 0, sj = 0;
@@ -187,9 +187,9 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     const size_t MiB = (size_t)1 << 20;
     unsigned nb[3];
     size_t b11, b12, b22;
-    brick3_geometry(g.n, 1, 1, nb, &b11);
-    brick3_geometry(g.n, 1, 2, nb, &b12);
-    brick3_geometry(g.n, 2, 2, nb, &b22);
+    brick_geometry(g, 1, 1, nb, &b11);
+    brick_geometry(g, 1, 2, nb, &b12);
+    brick_geometry(g, 2, 2, nb, &b22);
     if (b11 <= 3 * MiB) { si = 1; sj = 1; }
     else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
     else if (b22 <= 4 * MiB) { si = 2; sj = 2; }
@@ -198,16 +198,16 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     else return INTERPN_HIP_OK;  // very large grids stay on the C-order kernel
   }
   size_t bytes;
-  brick3_geometry(g.n, si, sj, g.brick_nb, &bytes);
+  brick_geometry(g, si, sj, g.brick_nb, &bytes);
   // brick element offsets are 32-bit in the kernel
-  if (bytes / sizeof(double) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
+  if (bytes / (g.dtype == kF64 ? 8 : 4) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) return INTERPN_HIP_OK;
   g.brick_step[0] = si;
   g.brick_step[1] = sj;
   hipError_t e = hipMalloc(&h->bricks_owned, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
-  HIP_TRY(build_bricks3(g, h->bricks_owned, nullptr));
+  HIP_TRY(build_bricks(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   g.bricks = h->bricks_owned;
   return INTERPN_HIP_OK;
@@ -385,9 +385,13 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
 
 hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
                       unsigned long long* first_bad, hipStream_t stream) {
-  if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC"))
-    return launch_linear3_brick(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts,
-                                first_bad, stream);
+  if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+    if (g.dtype == kF64)
+      return launch_linear_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
+                                         npts, first_bad, stream);
+    return launch_linear_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
+                                      first_bad, stream);
+  }
   if (g.dtype == kF64)
     return launch<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts, first_bad, stream);
   return launch<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts, first_bad, stream);

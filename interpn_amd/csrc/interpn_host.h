@@ -39,8 +39,8 @@ struct GridDesc {
   int axis_buckets[8] = {0};       // M per axis, 0 = no table
   double axis_g0[8] = {0};
   double axis_scale[8] = {0};
-  // Optional bricked copy of `vals` (3-D multilinear f64 only; see k_linear3_brick.hip):
-  // 2 x 2 x 4 element bricks of one 128-B line, brick steps (brick_step[0], brick_step[1], 3).
+  // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
+  // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   const void* bricks = nullptr;
   int brick_step[2] = {2, 2};
   unsigned brick_nb[3] = {0, 0, 0};
@@ -68,11 +68,12 @@ template <typename T>
 hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                           unsigned long long* first_bad, hipStream_t stream);
 
-// Bricked 3-D multilinear path (f64).
-void brick3_geometry(const int n[3], int si, int sj, unsigned nb[3], size_t* bytes);
-hipError_t build_bricks3(const GridDesc& g, void* bricks, hipStream_t stream);
-hipError_t launch_linear3_brick(const GridDesc& g, const double* const* obs, double* out, size_t npts,
-                                unsigned long long* first_bad, hipStream_t stream);
+// Bricked multilinear path (k_linear_brick.hip).
+void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes);
+hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
+template <typename T>
+hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
+                               unsigned long long* first_bad, hipStream_t stream);
 
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>

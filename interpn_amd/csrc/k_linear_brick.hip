@@ -1,0 +1,301 @@
+// N-D multilinear (N >= 3; regular and rectilinear; f64 and f32) on a bricked copy of the grid
+// with a quad-cooperative gather.
+//
+// Why: with the grid in C order a point's 2^N corners lie on 2^(N-1) different 128-B lines, and on
+// MI355X the per-XCD L2 -> L1 line rate (16 lines/clk/XCD, ~2.7e11 lines/s chip-wide), not HBM,
+// bounds the kernel (profiles/r01_tune_*).  Here the handle keeps a second
+// copy of the grid in which the LAST THREE dimensions (i, j, k) are cut into 2 x 2 x KW bricks of
+// one 128-B line each (KW = 4 for f64, 8 for f32), stepped KW-1 along k (a k-pair never leaves a
+// brick row) and 1 or 2 along i and j (overlapping bricks = duplicated planes / rows); leading
+// dimensions, if any, index whole brick tables.  A 3-D cell then spans 1 (steps 1,1), 1.5 (1,2)
+// or 2.25 (2,2) lines instead of 4.25.  Because the TCP only merges lanes of the same instruction,
+// the four lanes of a quad fetch the four (i,j) k-pairs of ONE point per load instruction, so
+// pieces on the same line become a single L2 request; the pieces are transposed back through LDS
+// and every lane finishes its own point with the reference's arithmetic and operation order
+// (leading dimensions are reduced first, exactly as dims 0..N-4 are in the reference's tree,
+// src/multilinear/regular.rs:347-403), so results are bit-identical to the C-order kernels.
+#include "rect_args.h"
+
+namespace interpn {
+
+template <typename T> struct BrickGeom {
+  static constexpr int KW = 32 / (int)sizeof(T);  // elements per brick row (32 B)
+  static constexpr int SK = KW - 1;               // brick step along k
+  static constexpr int ELEMS = 4 * KW;            // elements per brick (128 B)
+};
+
+template <typename T, int N>
+struct BrickArgs {
+  const T* bricks;
+  const T* obs[N];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  T start[N];
+  T step[N];
+  int n[N];
+  AxisArgs<T, N> ax;
+  unsigned lead_stride[N > 3 ? N - 3 : 1];  // elements of the brick table per unit of a leading index
+  unsigned nbj, nbk;
+};
+
+template <typename T, int SI, int SJ>
+__device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj) {
+  constexpr int KW = BrickGeom<T>::KW;
+  int bi, oi, bj, oj;
+  if (SI == 1) { bi = i; oi = di; }
+  else { bi = i >> 1; oi = (i & 1) + di; if (oi == 2) { bi += 1; oi = 0; } }
+  if (SJ == 1) { bj = j; oj = dj; }
+  else { bj = j >> 1; oj = (j & 1) + dj; if (oj == 2) { bj += 1; oj = 0; } }
+  return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
+}
+
+constexpr int kPieceRow = 5;  // piece slots per point row in LDS (4 used + 1 pad against bank conflicts)
+
+template <typename T>
+struct Cell {
+  T v[2][2][2];  // [di][dj][dk]
+};
+
+// One cooperative gather: lane q of a quad loads piece q of the quad's points r = 0..3 (offsets in
+// `toff`, plus the wave-uniform `delta` of the current leading-dimension combination), then the
+// 4x4 piece matrix is transposed through LDS so that every lane owns its point's four pieces.
+template <typename T>
+__device__ __forceinline__ Cell<T> gather_cell(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
+                                               typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q) {
+  typedef typename LeafVec<T, 2>::type P;
+  P pc[4];
+  pc[0] = *reinterpret_cast<const P*>(bricks + toff.x + delta);
+  pc[1] = *reinterpret_cast<const P*>(bricks + toff.y + delta);
+  pc[2] = *reinterpret_cast<const P*>(bricks + toff.z + delta);
+  pc[3] = *reinterpret_cast<const P*>(bricks + toff.w + delta);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pc[r];
+  __builtin_amdgcn_wave_barrier();
+  Cell<T> c;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const P w = lds_piece[(quad * 4 + q) * kPieceRow + p];
+    c.v[p >> 1][p & 1][0] = w.x;
+    c.v[p >> 1][p & 1][1] = w.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return c;
+}
+
+// Reduce leading dimensions 0..D-1 (dim 0 innermost), element-wise on the 8 trailing corners.
+template <typename T, int D, bool FMA>
+struct LeadReduce {
+  __device__ __forceinline__ static Cell<T> run(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
+                                                const unsigned* lead_stride, const T* t,
+                                                typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q) {
+    const Cell<T> a = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta, lead_stride, t, lds_piece, quad, q);
+    const Cell<T> b = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta + lead_stride[D - 1], lead_stride, t, lds_piece, quad, q);
+    Cell<T> r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const T y0 = a.v[e >> 2][(e >> 1) & 1][e & 1];
+      const T dy = b.v[e >> 2][(e >> 1) & 1][e & 1] - y0;
+      r.v[e >> 2][(e >> 1) & 1][e & 1] = mul_add<FMA>(t[D - 1], dy, y0);  // regular.rs:378-385
+    }
+    return r;
+  }
+};
+template <typename T, bool FMA>
+struct LeadReduce<T, 0, FMA> {
+  __device__ __forceinline__ static Cell<T> run(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
+                                                const unsigned*, const T*, typename LeafVec<T, 2>::type* lds_piece,
+                                                unsigned quad, unsigned q) {
+    return gather_cell<T>(bricks, toff, delta, lds_piece, quad, q);
+  }
+};
+
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ>
+__global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
+  typedef typename LeafVec<T, 2>::type P;
+  constexpr int L = N - 3;
+  constexpr int SK = BrickGeom<T>::SK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
+  unsigned* lds_off = reinterpret_cast<unsigned*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
+  unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
+  if (RECT && a.ax.use_lds) stage_axes<T, N>(a.ax, lds_axes);
+  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
+  const unsigned lane = threadIdx.x;
+  const unsigned q = lane & 3;
+  const unsigned quad = lane >> 2;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  for (size_t it = 0; it < niter; ++it) {
+    // Every lane runs every iteration (dead lanes still fetch pieces for their quad).
+    const size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    const bool live = i0 < a.npts;
+    T t[N];
+    int loc[N];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      if (RECT) {
+        const T x = live ? a.obs[d][i0] : (T)0;
+        const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
+        int l = axis_partition_point<T>(ax, x) - 1;  // multilinear/rectilinear.rs:363
+        l = l > 0 ? l : 0;
+        l = l < a.n[d] - 2 ? l : a.n[d] - 2;         // rectilinear.rs:365-367
+        const T x0 = ax.g[l];
+        const T x1 = ax.g[l + 1];
+        const T step = x1 - x0;
+        t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
+        loc[d] = l;
+      } else {
+        const T x = live ? a.obs[d][i0] : a.start[d];
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);          // multilinear/regular.rs:415-418
+        const int l = clamp_loc<T>(floc, a.n[d] - 2);                     // regular.rs:420-422
+        const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);          // regular.rs:334-337
+        t[d] = (x - izl) / a.step[d];                                     // regular.rs:339
+        loc[d] = l;
+      }
+    }
+    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i0);
+    // Offsets of my point's four pieces (lower corner of the leading dims included) -> LDS,
+    // transposed: lane q reads piece q of points 0..3.
+    unsigned lead = 0;
+#pragma unroll
+    for (int d = 0; d < L; ++d) lead += (unsigned)loc[d] * a.lead_stride[d];
+    const unsigned bk = (unsigned)loc[N - 1] / (unsigned)SK;
+    const unsigned kpart = bk * (unsigned)BrickGeom<T>::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
+    __builtin_amdgcn_wave_barrier();
+    const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
+    const Cell<T> c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
+    // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
+    T r[2];
+#pragma unroll
+    for (int dk = 0; dk < 2; ++dk) {
+      const T c0 = mul_add<FMA>(t[N - 3], c.v[1][0][dk] - c.v[0][0][dk], c.v[0][0][dk]);
+      const T c1 = mul_add<FMA>(t[N - 3], c.v[1][1][dk] - c.v[0][1][dk], c.v[0][1][dk]);
+      r[dk] = mul_add<FMA>(t[N - 2], c1 - c0, c0);
+    }
+    const T res = mul_add<FMA>(t[N - 1], r[1] - r[0], r[0]);
+    if (live) a.out[i0] = res;
+  }
+}
+
+// Brick table builder: one thread per brick element.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ vals, T* __restrict__ bricks, size_t nlead,
+                                                         int n0, int n1, int n2, int si, int sj, unsigned nbi, unsigned nbj,
+                                                         unsigned nbk) {
+  constexpr int KW = BrickGeom<T>::KW;
+  constexpr int EL = BrickGeom<T>::ELEMS;
+  const size_t per_lead = (size_t)nbi * nbj * nbk * EL;
+  const size_t total = nlead * per_lead;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const size_t lead = e / per_lead;
+    size_t b = e - lead * per_lead;
+    const unsigned within = (unsigned)(b % EL);
+    b /= EL;
+    const unsigned bk = (unsigned)(b % nbk); b /= nbk;
+    const unsigned bj = (unsigned)(b % nbj); b /= nbj;
+    const unsigned bi = (unsigned)b;
+    const int i = (int)bi * si + (int)(within / (2 * KW));
+    const int j = (int)bj * sj + (int)((within / KW) & 1);
+    const int k = (int)bk * (KW - 1) + (int)(within % KW);
+    T v = (T)0;
+    if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];
+    bricks[e] = v;
+  }
+}
+
+void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes) {
+  const int N = g.ndims;
+  const int kw = g.dtype == kF64 ? 4 : 8;
+  nb[0] = (unsigned)((g.n[N - 3] - 2) / si + 2);
+  nb[1] = (unsigned)((g.n[N - 2] - 2) / sj + 2);
+  nb[2] = (unsigned)((g.n[N - 1] - 2) / (kw - 1) + 2);
+  size_t lead = 1;
+  for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
+  *bytes = lead * nb[0] * nb[1] * nb[2] * 128;
+}
+
+hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
+  const int N = g.ndims;
+  size_t lead = 1;
+  for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
+  const size_t elems = lead * g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (g.dtype == kF64 ? 16 : 32);
+  size_t blocks = (elems + kBlock - 1) / kBlock;
+  if (blocks > 65535) blocks = 65535;
+  if (g.dtype == kF64)
+    hipLaunchKernelGGL(k_build_bricks<double>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                       static_cast<const double*>(g.vals), static_cast<double*>(bricks), lead, g.n[N - 3], g.n[N - 2],
+                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
+  else
+    hipLaunchKernelGGL(k_build_bricks<float>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                       static_cast<const float*>(g.vals), static_cast<float*>(bricks), lead, g.n[N - 3], g.n[N - 2],
+                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
+  return hipGetLastError();
+}
+
+template <typename T, int N, bool RECT, bool FMA>
+static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
+  const int si = g.brick_step[0], sj = g.brick_step[1];
+  if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  return hipGetLastError();
+}
+
+template <typename T, int N>
+static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
+                           hipStream_t stream) {
+  typedef typename LeafVec<T, 2>::type P;
+  BrickArgs<T, N> a;
+  a.bricks = static_cast<const T*>(g.bricks);
+  a.out = out;
+  a.first_bad = first_bad;
+  a.npts = npts;
+  for (int d = 0; d < N; ++d) {
+    a.obs[d] = obs[d];
+    a.start[d] = (T)g.start[d];
+    a.step[d] = (T)g.step[d];
+    a.n[d] = g.n[d];
+  }
+  a.nbj = g.brick_nb[1];
+  a.nbk = g.brick_nb[2];
+  unsigned acc = g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (unsigned)BrickGeom<T>::ELEMS;
+  a.lead_stride[0] = 0;
+  for (int d = N - 4; d >= 0; --d) {
+    a.lead_stride[d] = acc;
+    acc *= (unsigned)g.n[d];
+  }
+  size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16;
+  a.ax.use_lds = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
+  const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  if (g.kind == kRegular)
+    return g.fma ? launch_steps<T, N, false, true>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, false, false>(g, a, lds, blocks, stream);
+  return g.fma ? launch_steps<T, N, true, true>(g, a, lds, blocks, stream)
+               : launch_steps<T, N, true, false>(g, a, lds, blocks, stream);
+}
+
+template <typename T>
+hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
+                               unsigned long long* first_bad, hipStream_t stream) {
+  switch (g.ndims) {
+    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream);
+    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream);
+    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream);
+    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_linear_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_linear_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
+
+}  // namespace interpn

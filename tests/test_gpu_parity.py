@@ -72,22 +72,26 @@ def test_recursive_arms(oracle, method, kind, n):
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 @pytest.mark.parametrize("layout", ["off", "11", "12", "22"])
-@pytest.mark.parametrize("axis", [[2, 2, 2], [3, 4, 5], [17, 9, 32], [64, 64, 64], [8, 7, 3]], ids=str)
-def test_linear3_brick_layouts(oracle, monkeypatch, kind, layout, axis):
-    """3-D multilinear f64 runs on a bricked copy of the grid with a quad-cooperative gather
-    (k_linear3_brick.hip); every brick overlap scheme and the C-order kernel must give the same
-    bits, including the 2-point axes, odd sizes and NaN / out-of-range coordinates."""
+@pytest.mark.parametrize("axis", [[2, 2, 2], [3, 4, 5], [17, 9, 32], [64, 64, 64], [8, 7, 3], [5, 9, 8, 17],
+                                  [2, 3, 2, 2, 9], [3, 2, 4, 3, 5, 4]], ids=str)
+def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
+    """Multilinear N = 3..6 runs on a bricked copy of the grid with a quad-cooperative gather
+    (k_linear_brick.hip); every brick overlap scheme and the C-order kernel must give the same
+    bits, including 2-point axes, odd sizes, leading dimensions and NaN / out-of-range
+    coordinates."""
     monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
-    case = synthetic_case("linear", kind, 3, axis, 70_001, 900 + sum(axis), np.float64, extrap=0.3,
+    n = len(axis)
+    case = synthetic_case("linear", kind, n, axis, 40_001, 900 + sum(axis), dtype, extrap=0.3,
                           specials=min(axis) >= 8)
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
-    if kind == "regular":
-        case.obs[2][4321] = np.nan
+    if kind == "regular" and dtype == np.float64:
+        case.obs[n - 1][4321] = np.nan
         from interpn_amd import raw
 
-        got = np.full(70_001, -1.0)
+        got = np.full(40_001, -1.0)
         with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
             raw.interpn_linear_regular_f64(case.dims, case.starts, case.steps, case.vals, case.obs, got)
         assert np.all(got[4321:] == -1.0) and np.all(got[:4321] != -1.0)
