@@ -1,0 +1,216 @@
+// N-D multicubic (N = 2..4; regular and rectilinear; f64 and f32) on a tiled copy of the grid with
+// a 16-lane cooperative gather.
+//
+// A cubic point reads a 4^N footprint.  In C order that is 4^(N-1) rows of 4 elements, each on its
+// own 128-B line (76 lines/point in 4-D), and the kernel is bound by the L2 -> L1 line rate
+// (DESIGN.md section 4).  Here the handle keeps a copy of the grid in which the FIRST TWO dimensions
+// (i, j) — the ones the reference reduces first — are cut into 4 x 4 tiles (128 B in f64), stepped
+// 4, 2 or 1 (overlapping tiles = duplicated rows/columns) so that a 4 x 4 footprint spans 3.06,
+// 2.25 ... 1 tiles; the remaining dimensions index whole tiled planes.  The 16 lanes of a group
+// fetch the 16 elements of ONE point's (i, j) footprint per load instruction (elements on one
+// line become one L2 request), 16 instructions cover the group's 16 points, the 16 x 16 element
+// matrix is transposed through LDS, and every lane reduces its own footprint: dim 0, then dim 1,
+// then the plane dimensions in order — the reference's tree (src/multicubic/regular.rs:368-421),
+// so results are bit-identical to the C-order kernels.
+#pragma once
+#include "rect_args.h"
+
+
+namespace interpn {
+
+template <typename T, int N>
+struct CubicBrickArgs {
+  const T* bricks;
+  const T* obs[N];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  T start[N];
+  T step[N];
+  int n[N];
+  AxisArgs<T, N> ax;
+  unsigned plane_stride[N];  // d >= 2: table elements per unit index of dim d
+  unsigned nbj;
+  int linearize;
+};
+
+#ifdef INTERPN_DEBUG_OFFSETS
+__device__ unsigned g_debug_limit;
+#endif
+
+constexpr int kCubRow = 18;  // elements per LDS row (16 used; 18 keeps 16-B alignment and spreads banks)
+
+template <int S>
+__device__ __forceinline__ void tile_coord(int i0, int e, int* b, int* o) {
+  if (S == 1) { *b = i0; *o = e; return; }
+  int bb = S == 4 ? (i0 >> 2) : (i0 >> 1);
+  int oo = (i0 - bb * S) + e;
+  if (oo >= 4) { bb += 1; oo -= S; }
+  *b = bb;
+  *o = oo;
+}
+
+template <typename T, bool RECT> struct CubicDimSel;
+template <typename T> struct CubicDimSel<T, false> { typedef CubicDimRegular<T> type; };
+template <typename T> struct CubicDimSel<T, true> { typedef CubicDimRect<T> type; };
+
+template <bool RECT, bool FMA, typename T>
+__device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typename CubicDimSel<T, RECT>::type& d) {
+  if constexpr (RECT) return cubic_rect_node<FMA, T>(v0, v1, v2, v3, d);
+  else return cubic_regular_node<FMA, T>(v0, v1, v2, v3, d);
+}
+
+// Gather one (i, j) footprint plane at table offset `delta` for all lanes, reduce dims 0 and 1.
+template <typename T, bool RECT, bool FMA>
+__device__ __forceinline__ T gather_plane(const T* __restrict__ bricks, const unsigned* toff, unsigned delta, T __attribute__((may_alias))* lds_data,
+                                          unsigned group, unsigned me, const typename CubicDimSel<T, RECT>::type* dim) {
+  T val[16];
+#ifdef INTERPN_DEBUG_OFFSETS
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (toff[r] + delta >= g_debug_limit) printf("OOB lane %u group %u me %u r %d toff %u delta %u limit %u\n", threadIdx.x, group, me, r, toff[r], delta, g_debug_limit);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) val[r] = (toff[r] + delta < g_debug_limit) ? bricks[toff[r] + delta] : (T)0;
+#else
+#pragma unroll
+  for (int r = 0; r < 16; ++r) val[r] = bricks[toff[r] + delta];
+#endif
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds_data[(group * 16 + r) * kCubRow + me] = val[r];
+  wave_sync();
+  T v[16];
+  const T __attribute__((may_alias))* row = lds_data + (group * 16 + me) * kCubRow;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = row[e];
+  wave_sync();
+  // element e = ei*4 + ej; reduce dim 0 (i) for every j, then dim 1 (j)
+  T w[4];
+#pragma unroll
+  for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
+  return cubic_node_sel<RECT, FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+}
+
+// Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
+template <typename T, int D, bool RECT, bool FMA>
+struct PlaneReduce {
+  __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
+                                          const unsigned* plane_stride, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
+                                          const typename CubicDimSel<T, RECT>::type* dim) {
+    T s[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      s[o] = PlaneReduce<T, D - 1, RECT, FMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D], plane_stride, lds_data,
+                                                   group, me, dim);
+    return cubic_node_sel<RECT, FMA, T>(s[0], s[1], s[2], s[3], dim[D]);
+  }
+};
+template <typename T, bool RECT, bool FMA>
+struct PlaneReduce<T, 1, RECT, FMA> {
+  __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
+                                          const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
+                                          const typename CubicDimSel<T, RECT>::type* dim) {
+    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim);
+  }
+};
+
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ>
+__global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, N> a) {
+  typedef typename CubicDimSel<T, RECT>::type DimT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // One region, used first for the offset transpose (u32) and then for the data transposes (T).
+  typedef T __attribute__((may_alias)) lds_T;
+  lds_T* lds_data = reinterpret_cast<lds_T*>(smem_raw);
+  lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw);
+  constexpr size_t kRegion = (size_t)kBlock * kCubRow * sizeof(T) > (size_t)kBlock * kCubRow * 4
+                                 ? (size_t)kBlock * kCubRow * sizeof(T) : (size_t)kBlock * kCubRow * 4;
+  unsigned char* lds_axes = smem_raw + kRegion;
+  if (RECT && a.ax.use_lds) stage_axes<T, N>(a.ax, lds_axes);
+  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
+  const unsigned lane = threadIdx.x;
+  const unsigned me = lane & 15;
+  const unsigned group = lane >> 4;
+  // The offset matrix of a group lives inside the SAME bytes as its data matrix (both regions are
+  // private to the group's wave): index it with the data matrix' group stride.
+  const unsigned goff = group * (unsigned)(16 * kCubRow * sizeof(T) / 4);
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  for (size_t it = 0; it < niter; ++it) {
+    const size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    const bool live = i0 < a.npts;
+    DimT dim[N];
+    int loc[N];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      if constexpr (RECT) {
+        const T x = live ? a.obs[d][i0] : (T)0;
+        const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
+        loc[d] = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
+      } else {
+        const T x = live ? a.obs[d][i0] : a.start[d];
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
+        ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
+        const T nn = (T)a.n[d];
+        const int l = clamp_loc<T>(floc - (T)1, a.n[d] - 4);      // regular.rs:440-442
+        int sat;
+        bool outside;
+        if (floc < (T)0) { sat = kSatLow; outside = true; }       // regular.rs:445-466 on floc = iloc + 1
+        else if (floc == (T)0) { sat = kSatLow; outside = false; }
+        else if (floc > nn - (T)2) { sat = kSatHigh; outside = true; }
+        else if (floc == nn - (T)2) { sat = kSatHigh; outside = false; }
+        else { sat = kSatNone; outside = false; }
+        const T index_one_loc = mul_add<false>(a.step[d], (T)(l + 1), a.start[d]);  // regular.rs:356-360, never fused
+        const T t = (x - index_one_loc) / a.step[d];
+        dim[d].sat = sat;
+        dim[d].linear = (outside && a.linearize) ? 1 : 0;
+        dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
+        loc[d] = l;
+      }
+    }
+    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i0);
+    // Offsets of my point's 16 footprint elements (plane base included) -> LDS, transposed.
+    unsigned pbase = 0;
+#pragma unroll
+    for (int d = 2; d < N; ++d) pbase += (unsigned)loc[d] * a.plane_stride[d];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int bi, oi, bj, oj;
+      tile_coord<SI>(loc[0], e >> 2, &bi, &oi);
+      tile_coord<SJ>(loc[1], e & 3, &bj, &oj);
+      lds_off[goff + e * kCubRow + me] = pbase + ((unsigned)(bi * (int)a.nbj + bj) * 16u) + (unsigned)(oi * 4 + oj);
+    }
+    wave_sync();
+    unsigned toff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
+    wave_sync();
+    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim);
+    if (live) a.out[i0] = res;
+  }
+}
+
+// Tiled table builder.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_cubic_tiles(const T* __restrict__ vals, T* __restrict__ tiles, size_t nplanes,
+                                                              int n0, int n1, int si, int sj, unsigned nbi, unsigned nbj) {
+  const size_t per_plane = (size_t)nbi * nbj * 16;
+  const size_t total = nplanes * per_plane;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const size_t plane = e / per_plane;
+    size_t b = e - plane * per_plane;
+    const unsigned within = (unsigned)(b & 15);
+    b >>= 4;
+    const unsigned bj = (unsigned)(b % nbj);
+    const unsigned bi = (unsigned)(b / nbj);
+    const int i = (int)bi * si + (int)(within >> 2);
+    const int j = (int)bj * sj + (int)(within & 3);
+    T v = (T)0;
+    // vals is C-ordered (i, j, plane...) with the plane dims fastest: index = (i*n1 + j)*nplanes + plane
+    if (i < n0 && j < n1) v = vals[((size_t)i * n1 + j) * nplanes + plane];
+    tiles[e] = v;
+  }
+}
+
+
+}  // namespace interpn

@@ -174,8 +174,54 @@ int resolve_device(int device, int* out) {
 // by the 256 MiB Infinity Cache, where fewer lines per point matter most); in between, the
 // cheaper overlaps that keep most of the table L2-resident.  INTERPN_HIP_BRICKS=off|11|12|22
 // overrides (tuning).
+// Tiled copy for the multicubic kernels (k_cubic_brick.hip), N = 2..4: dims 0,1 in 4 x 4 tiles.
+// Candidates are ranked by a two-level cost model: lines per point x (L2 hit ? 1/2.7e11 : 1/6.2e10 s),
+// with the hit fraction ~ min(1, 3 MiB / table bytes) — the measured L2 and Infinity-Cache line
+// rates.  INTERPN_HIP_BRICKS=off|44|24|22|14|11 overrides.
+int maybe_build_cubic_tiles(interpn_hip_interp* h) {
+  GridDesc& g = h->desc;
+  const char* env = getenv("INTERPN_HIP_BRICKS");
+  if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
+  static const int cand[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 4}, {1, 1}};
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  int best = -1;
+  double best_cost = 0;
+  const size_t esz = g.dtype == kF64 ? 8 : 4;
+  for (int c = 0; c < 5; ++c) {
+    const int si = cand[c][0], sj = cand[c][1];
+    if (env && strlen(env) == 2 && !(env[0] - '0' == si && env[1] - '0' == sj)) continue;
+    unsigned nb[2];
+    size_t bytes;
+    cubic_tile_geometry(g, si, sj, nb, &bytes);
+    if (bytes / esz >= 0xFFFFFFFFull || bytes > free_b / 2 || bytes > ((size_t)4 << 30)) continue;
+    const double e_i = si == 4 ? 1.75 : (si == 2 ? 1.5 : 1.0);
+    const double e_j = sj == 4 ? 1.75 : (sj == 2 ? 1.5 : 1.0);
+    double planes = 1;
+    for (int d = 2; d < g.ndims; ++d) planes *= 4;
+    const double lines = planes * e_i * e_j;
+    double hit = (3.0 * 1048576.0) / (double)bytes;
+    if (hit > 1) hit = 1;
+    const double cost = lines * (hit / 2.7e11 + (1 - hit) / 6.2e10);
+    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  if (best < 0) return INTERPN_HIP_OK;
+  size_t bytes;
+  g.brick_step[0] = cand[best][0];
+  g.brick_step[1] = cand[best][1];
+  cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], g.brick_nb, &bytes);
+  g.brick_nb[2] = 1;
+  hipError_t e = hipMalloc(&h->bricks_owned, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
+  HIP_TRY(build_cubic_tiles(g, h->bricks_owned, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  g.bricks = h->bricks_owned;
+  return INTERPN_HIP_OK;
+}
+
 int maybe_build_bricks(interpn_hip_interp* h) {
   GridDesc& g = h->desc;
+  if (g.method == kCubic && g.ndims >= 2 && g.ndims <= 4) return maybe_build_cubic_tiles(h);
   if (!(g.method == kLinear && g.ndims >= 3 && g.ndims <= 6)) return INTERPN_HIP_OK;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
@@ -385,6 +431,13 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
 
 hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
                       unsigned long long* first_bad, hipStream_t stream) {
+  if (g.bricks && npts && g.method == kCubic && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+    if (g.dtype == kF64)
+      return launch_cubic_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
+                                        npts, first_bad, stream);
+    return launch_cubic_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
+                                     first_bad, stream);
+  }
   if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
     if (g.dtype == kF64)
       return launch_linear_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),

@@ -27,6 +27,19 @@ constexpr unsigned long long kNoBadIndex = ~0ull;
 
 enum Sat : int { kSatNone = 0, kSatLow = 1, kSatHigh = 2 };  // src/multicubic/mod.rs:59-66 (Inside/Outside kept apart in `outside`)
 
+// Order LDS traffic between the lanes of ONE wave (exchange patterns where lane A stores and
+// lane B loads).  The hardware executes a wave's DS instructions in order; what must be stopped is
+// the compiler moving accesses across the exchange point: llvm.amdgcn.wave.barrier alone is
+// IntrNoMem, so it is paired with a wavefront-scope fence.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// LDS words that are also accessed through another element type (type-based alias analysis off).
+typedef unsigned __attribute__((may_alias)) lds_u32;
+
 // ---------------------------------------------------------------------------
 // Scalar helpers
 template <typename T> __device__ __forceinline__ T dev_fma(T a, T b, T c);

@@ -75,6 +75,13 @@ template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                                unsigned long long* first_bad, hipStream_t stream);
 
+// Tiled multicubic path (k_cubic_brick.hip): dims 0,1 in 4 x 4 tiles stepped brick_step[0..1].
+void cubic_tile_geometry(const GridDesc& g, int si, int sj, unsigned nb[2], size_t* bytes);
+hipError_t build_cubic_tiles(const GridDesc& g, void* tiles, hipStream_t stream);
+template <typename T>
+hipError_t launch_cubic_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
+                              unsigned long long* first_bad, hipStream_t stream);
+
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>
 hipError_t build_buckets(const T* g, int n, int M, T g0, T scale, unsigned* tab, hipStream_t stream);

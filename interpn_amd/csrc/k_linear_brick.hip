@@ -71,7 +71,7 @@ __device__ __forceinline__ Cell<T> gather_cell(const T* __restrict__ bricks, con
   pc[3] = *reinterpret_cast<const P*>(bricks + toff.w + delta);
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pc[r];
-  __builtin_amdgcn_wave_barrier();
+  wave_sync();
   Cell<T> c;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ Cell<T> gather_cell(const T* __restrict__ bricks, con
     c.v[p >> 1][p & 1][0] = w.x;
     c.v[p >> 1][p & 1][1] = w.y;
   }
-  __builtin_amdgcn_wave_barrier();
+  wave_sync();
   return c;
 }
 
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   constexpr int SK = BrickGeom<T>::SK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
-  unsigned* lds_off = reinterpret_cast<unsigned*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
+  lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
   unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
   if (RECT && a.ax.use_lds) stage_axes<T, N>(a.ax, lds_axes);
   const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
     const Cell<T> c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
     // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.

@@ -98,6 +98,22 @@ def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("layout", ["off", "44", "24", "22", "14", "11"])
+@pytest.mark.parametrize("axis", [[4, 4], [9, 6], [4, 5, 4], [13, 7, 6], [5, 4, 6, 7], [8, 9, 4, 5]], ids=str)
+def test_cubic_tile_layouts(oracle, monkeypatch, dtype, linearize, kind, layout, axis):
+    """Multicubic N = 2..4 runs on a tiled copy of the grid (dims 0,1 in 4 x 4 tiles) with a 16-lane
+    cooperative gather (k_cubic_brick.hip); every tile overlap scheme and the C-order kernel must
+    give the same bits, including 4-point axes (single tile) and heavy extrapolation."""
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
+    n = len(axis)
+    case = synthetic_case("cubic", kind, n, axis, 20_003, 1300 + sum(axis), dtype, linearize=linearize, extrap=0.3,
+                          specials=min(axis) >= 8)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("n", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 @pytest.mark.parametrize("method", ["linear", "cubic"])
