@@ -230,18 +230,26 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     si = env[0] - '0';
     sj = env[1] - '0';
   } else {
+    // Measured on MI355X (tools/sweep_layouts.py, 3-D f64, 16^3 .. 384^3): the fully overlapped
+    // layout (one line per cell) wins at every size — L2-resident, Infinity-Cache-resident and even
+    // HBM-resident tables (random 128-B lines stream from HBM at > 5 TB/s) — except in a narrow band
+    // around an 11 MiB table (64^3), where (1,2) keeps more of the table in the 4 MiB L2.
     const size_t MiB = (size_t)1 << 20;
     unsigned nb[3];
     size_t b11, b12, b22;
     brick_geometry(g, 1, 1, nb, &b11);
     brick_geometry(g, 1, 2, nb, &b12);
     brick_geometry(g, 2, 2, nb, &b22);
-    if (b11 <= 3 * MiB) { si = 1; sj = 1; }
-    else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
-    else if (b22 <= 4 * MiB) { si = 2; sj = 2; }
-    else if (b11 <= 192 * MiB) { si = 1; sj = 1; }
-    else if (b22 <= (size_t)2048 * MiB) { si = 2; sj = 2; }
-    else return INTERPN_HIP_OK;  // very large grids stay on the C-order kernel
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    const size_t esz = g.dtype == kF64 ? 8 : 4;
+    auto fits = [&](size_t b) { return b <= free_b / 4 && b <= ((size_t)16 << 30) && b / esz < 0xFFFFFFFFull; };
+    if (fits(b11)) {
+      if (b11 > 6 * MiB && b11 <= 16 * MiB && b12 <= 8 * MiB) { si = 1; sj = 2; }
+      else { si = 1; sj = 1; }
+    } else if (fits(b12)) { si = 1; sj = 2; }
+    else if (fits(b22)) { si = 2; sj = 2; }
+    else return INTERPN_HIP_OK;  // stay on the C-order kernel
   }
   size_t bytes;
   brick_geometry(g, si, sj, g.brick_nb, &bytes);
