@@ -58,6 +58,7 @@ typedef enum interpn_hip_status {
   INTERPN_HIP_ERR_UNREPRESENTABLE = 7,   /* "Unrepresentable coordinate value"          multilinear/regular.rs:418 */
   INTERPN_HIP_ERR_TOO_MANY_DIMS = 8,     /* "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions." */
   INTERPN_HIP_ERR_REFERENCE_PANIC = 9,   /* the reference would panic here */
+  INTERPN_HIP_ERR_TOO_MANY_DIMS_6 = 10,  /* "Dimension exceeds maximum (6)."           nearest/regular.rs:97 */
   /* statuses of this implementation */
   INTERPN_HIP_ERR_INVALID_ARGUMENT = 32, /* null pointer, unknown enum value, dtype mismatch */
   INTERPN_HIP_ERR_UNSUPPORTED = 33,      /* axis longer than 2^31-257 points (f32: 2^24) */
@@ -66,7 +67,7 @@ typedef enum interpn_hip_status {
   INTERPN_HIP_ERR_HIP = 36               /* any other HIP runtime failure (see interpn_hip_last_hip_error) */
 } interpn_hip_status;
 
-enum { INTERPN_HIP_LINEAR = 0, INTERPN_HIP_CUBIC = 1 };        /* method */
+enum { INTERPN_HIP_LINEAR = 0, INTERPN_HIP_CUBIC = 1, INTERPN_HIP_NEAREST = 2 }; /* method */
 enum { INTERPN_HIP_MEM_HOST = 0, INTERPN_HIP_MEM_DEVICE = 1 }; /* where a buffer lives */
 
 const char* interpn_hip_strerror(int status);
@@ -93,6 +94,10 @@ int interpn_hip_device_count(void);
  *                                      linearize_extrapolation, obs, out)  src/python.rs:243-251
  * interpn_hip_cubic_rectilinear_*   <- multicubic::rectilinear::interpn(grids, vals,
  *                                      linearize_extrapolation, obs, out)  src/python.rs:277-283
+ * interpn_hip_nearest_regular_*     <- nearest::regular::interpn(dims, starts, steps, vals, obs, out)
+ *                                      src/python.rs:162-169   (N <= 6)
+ * interpn_hip_nearest_rectilinear_* <- nearest::rectilinear::interpn(grids, vals, obs, out)
+ *                                      src/python.rs:192
  * ---------------------------------------------------------------------------------------- */
 #define INTERPN_HIP_DECLARE_ONESHOT(T, SUFFIX)                                                            \
   int interpn_hip_linear_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,             \
@@ -110,7 +115,15 @@ int interpn_hip_device_count(void);
   int interpn_hip_cubic_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,             \
                                              size_t ngrids, const T* vals, size_t nvals,                 \
                                              int linearize_extrapolation, const T* const* obs,           \
-                                             const size_t* obs_lens, size_t nobs, T* out, size_t nout);
+                                             const size_t* obs_lens, size_t nobs, T* out, size_t nout);      \
+  int interpn_hip_nearest_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,            \
+                                           size_t nstarts, const T* steps, size_t nsteps, const T* vals, \
+                                           size_t nvals, const T* const* obs, const size_t* obs_lens,    \
+                                           size_t nobs, T* out, size_t nout);                            \
+  int interpn_hip_nearest_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens,           \
+                                               size_t ngrids, const T* vals, size_t nvals,               \
+                                               const T* const* obs, const size_t* obs_lens, size_t nobs, \
+                                               T* out, size_t nout);
 
 INTERPN_HIP_DECLARE_ONESHOT(double, f64)
 INTERPN_HIP_DECLARE_ONESHOT(float, f32)
@@ -122,7 +135,7 @@ INTERPN_HIP_DECLARE_ONESHOT(float, f32)
  * `.interp(obs, out)` (regular.rs:268-283 etc.).  This is the surface the Python classes'
  * `.eval()` sits on (src/interpn/multilinear_regular.py:101-168).
  *
- * `method`  INTERPN_HIP_LINEAR | INTERPN_HIP_CUBIC
+ * `method`  INTERPN_HIP_LINEAR | INTERPN_HIP_CUBIC | INTERPN_HIP_NEAREST
  * `vals_mem` INTERPN_HIP_MEM_HOST: `vals` is copied to the device;
  *            INTERPN_HIP_MEM_DEVICE: `vals` is a device pointer on `device`, borrowed (e.g. the
  *            buffer an RCCL broadcast just filled on this rank).

@@ -14,7 +14,8 @@ from typing import Literal
 import numpy as np
 
 from . import _lib, raw
-from .classes import MulticubicRectilinear, MulticubicRegular, MultilinearRectilinear, MultilinearRegular
+from .classes import (MulticubicRectilinear, MulticubicRegular, MultilinearRectilinear, MultilinearRegular,
+                      NearestRectilinear, NearestRegular)
 from .handle import Interpolator
 
 __version__ = "0.1.0"
@@ -28,6 +29,8 @@ __all__ = [
     "MultilinearRectilinear",
     "MulticubicRegular",
     "MulticubicRectilinear",
+    "NearestRegular",
+    "NearestRectilinear",
 ]
 
 
@@ -36,7 +39,7 @@ def interpn(
     grids: Sequence,
     vals,
     *,
-    method: Literal["linear", "cubic"] = "linear",
+    method: Literal["linear", "cubic", "nearest"] = "linear",
     out=None,
     linearize_extrapolation: bool = True,
     assume_regular: bool = False,
@@ -49,7 +52,6 @@ def interpn(
     ravelled and made contiguous, the dtype is taken from `vals` (float64 / float32), a grid is
     treated as regular iff every axis has exactly equal spacing (`_check_regular`, :197-203)
     or `assume_regular` is set, and the call dispatches to the matching raw function (:135-192).
-    `method="nearest"` is outside the hot path this package implements and raises ValueError.
     """
     # src/interpn/__init__.py:86-88 (the reference's `out or ...` raises on multi-element arrays;
     # `is None` is what it means)
@@ -87,6 +89,11 @@ def interpn(
             getattr(raw, f"interpn_linear_regular_{sfx}")(dims, starts, steps, vals, obs, out)
         else:
             getattr(raw, f"interpn_linear_rectilinear_{sfx}")(grids, vals, obs, out)
+    elif method == "nearest":
+        if is_regular:
+            getattr(raw, f"interpn_nearest_regular_{sfx}")(dims, starts, steps, vals, obs, out)
+        else:
+            getattr(raw, f"interpn_nearest_rectilinear_{sfx}")(grids, vals, obs, out)
     elif method == "cubic":
         if is_regular:
             getattr(raw, f"interpn_cubic_regular_{sfx}")(dims, starts, steps, vals, linearize_extrapolation, obs, out)

@@ -17,9 +17,11 @@ LIB_PATH = os.path.join(_HERE, "libinterpn_hip.so")
 OK = 0
 ERR_UNREPRESENTABLE = 7
 ERR_REFERENCE_PANIC = 9
+ERR_TOO_MANY_DIMS_6 = 10
 ERR_INVALID_ARGUMENT = 32
 
-LINEAR, CUBIC = 0, 1
+LINEAR, CUBIC, NEAREST = 0, 1, 2
+METHODS = {"linear": LINEAR, "cubic": CUBIC, "nearest": NEAREST}
 MEM_HOST, MEM_DEVICE = 0, 1
 
 _lib = None
@@ -84,6 +86,10 @@ def load() -> ctypes.CDLL:
             sz, c_size_t, p, c_size_t, p, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
         getattr(lib, f"interpn_hip_linear_rectilinear_{sfx}").argtypes = [
             pp, sz, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_nearest_regular_{sfx}").argtypes = [
+            sz, c_size_t, p, c_size_t, p, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
+        getattr(lib, f"interpn_hip_nearest_rectilinear_{sfx}").argtypes = [
+            pp, sz, c_size_t, p, c_size_t, pp, sz, c_size_t, p, c_size_t]
         getattr(lib, f"interpn_hip_cubic_regular_{sfx}").argtypes = [
             sz, c_size_t, p, c_size_t, p, c_size_t, p, c_size_t, c_int, pp, sz, c_size_t, p, c_size_t]
         getattr(lib, f"interpn_hip_cubic_rectilinear_{sfx}").argtypes = [
@@ -121,7 +127,7 @@ def raise_for_status(status: int) -> None:
     if status == OK:
         return
     msg = strerror(status)
-    if status < ERR_REFERENCE_PANIC:
+    if status < ERR_REFERENCE_PANIC or status == ERR_TOO_MANY_DIMS_6:
         raise AssertionError(msg)
     if status == ERR_REFERENCE_PANIC:
         raise ReferencePanic(msg)

@@ -230,6 +230,39 @@ class MultilinearRectilinear(_RectilinearBase):
         return cls(grids=[_as_flat(x, dtype) for x in grids], vals=_as_flat(vals.flatten(), dtype))
 
 
+class NearestRegular(_RegularBase):
+    """Nearest-neighbour interpolation on a regular grid in up to 6 dimensions
+    (src/interpn/nearest_regular.py)."""
+
+    _method = "nearest"
+
+    def _validate(self):
+        assert self.ndims() <= 6 and self.ndims() >= 1, "Number of dimensions must be at least 1 and no more than 6"
+        super()._validate()
+
+    @classmethod
+    def new(cls, dims, starts, steps, vals) -> "NearestRegular":
+        dtype = vals.dtype
+        return cls(dims=dims, starts=_as_flat(starts.flatten(), dtype), steps=_as_flat(steps.flatten(), dtype),
+                   vals=_as_flat(vals.flatten(), dtype))
+
+
+class NearestRectilinear(_RectilinearBase):
+    """Nearest-neighbour interpolation on a rectilinear grid in up to 6 dimensions
+    (src/interpn/nearest_rectilinear.py)."""
+
+    _method = "nearest"
+
+    def _validate(self):
+        assert self.ndims() <= 6 and self.ndims() >= 1, "Number of dimensions must be at least 1 and no more than 6"
+        super()._validate()
+
+    @classmethod
+    def new(cls, grids, vals) -> "NearestRectilinear":
+        dtype = vals.dtype
+        return cls(grids=[_as_flat(x, dtype) for x in grids], vals=_as_flat(vals.flatten(), dtype))
+
+
 class MulticubicRegular(_RegularBase):
     """Cubic Hermite interpolation on a regular grid (src/interpn/multicubic_regular.py:24).
     `linearize_extrapolation` defaults to True as in the reference (:59)."""

@@ -95,7 +95,10 @@ namespace {
 template <typename T>
 int validate_regular(int method, const size_t* dims, size_t ndims, const T* starts, size_t nstarts,
                      const T* steps, size_t nsteps, size_t nvals) {
-  if (method == kLinear) {
+  if (method == kNearest) {
+    if (nstarts != ndims || nsteps != ndims) return INTERPN_HIP_ERR_DIM_MISMATCH;  // nearest/regular.rs:50
+    if (ndims < 1 || ndims > 6) return INTERPN_HIP_ERR_TOO_MANY_DIMS_6;            // nearest/regular.rs:97
+  } else if (method == kLinear) {
     // multilinear/regular.rs:60 — obs.len() is checked by the caller of this helper
     if (nstarts != ndims || nsteps != ndims) return INTERPN_HIP_ERR_DIM_MISMATCH;
     if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // regular.rs:111-113
@@ -109,9 +112,9 @@ int validate_regular(int method, const size_t* dims, size_t ndims, const T* star
   if (!checked_product(dims, ndims, &prod)) return INTERPN_HIP_ERR_REFERENCE_PANIC;
   if (method == kCubic && !(nstarts == ndims && nsteps == ndims)) return INTERPN_HIP_ERR_DIM_MISMATCH;
   if (nvals != prod) return INTERPN_HIP_ERR_DIM_MISMATCH;  // regular.rs:239 / multicubic/regular.rs:254
-  const size_t minlen = method == kLinear ? 2 : 4;
+  const size_t minlen = method == kCubic ? 4 : 2;
   for (size_t i = 0; i < ndims; ++i)
-    if (dims[i] < minlen) return method == kLinear ? INTERPN_HIP_ERR_MIN_TWO_ENTRIES : INTERPN_HIP_ERR_MIN_FOUR_ENTRIES;
+    if (dims[i] < minlen) return method == kCubic ? INTERPN_HIP_ERR_MIN_FOUR_ENTRIES : INTERPN_HIP_ERR_MIN_TWO_ENTRIES;
   for (size_t i = 0; i < ndims; ++i)
     if (!(steps[i] > (T)0)) return INTERPN_HIP_ERR_NOT_MONOTONIC;  // regular.rs:248
   for (size_t i = 0; i < ndims; ++i)
@@ -122,14 +125,16 @@ int validate_regular(int method, const size_t* dims, size_t ndims, const T* star
 template <typename T>
 int validate_rectilinear(int method, const T* const* grids, const size_t* grid_lens, size_t ngrids, size_t nvals) {
   const size_t ndims = ngrids;
-  if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // rectilinear.rs:77-79
+  if (method == kNearest) {
+    if (ndims < 1 || ndims > 6) return INTERPN_HIP_ERR_TOO_MANY_DIMS_6;  // nearest/rectilinear.rs:59
+  } else if (ndims < 1 || ndims > 8) return INTERPN_HIP_ERR_TOO_MANY_DIMS;  // rectilinear.rs:77-79
   if (!grids || !grid_lens) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   size_t prod;
   if (!checked_product(grid_lens, ndims, &prod)) return INTERPN_HIP_ERR_REFERENCE_PANIC;
   if (nvals != prod) return INTERPN_HIP_ERR_DIM_MISMATCH;  // rectilinear.rs:186 / multicubic/rectilinear.rs:208
-  const size_t minlen = method == kLinear ? 2 : 4;
+  const size_t minlen = method == kCubic ? 4 : 2;
   for (size_t i = 0; i < ndims; ++i)
-    if (grid_lens[i] < minlen) return method == kLinear ? INTERPN_HIP_ERR_MIN_2_ENTRIES : INTERPN_HIP_ERR_MIN_4_ENTRIES;
+    if (grid_lens[i] < minlen) return method == kCubic ? INTERPN_HIP_ERR_MIN_4_ENTRIES : INTERPN_HIP_ERR_MIN_2_ENTRIES;
   for (size_t i = 0; i < ndims; ++i) {
     if (!grids[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
     if (!(grids[i][1] > grids[i][0])) return INTERPN_HIP_ERR_NOT_MONOTONIC;  // rectilinear.rs:195
@@ -297,7 +302,7 @@ int create_regular(int method, const size_t* dims, size_t ndims, const T* starts
                    interpn_hip_interp** handle) {
   if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   *handle = nullptr;
-  if (method != kLinear && method != kCubic) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (method != kLinear && method != kCubic && method != kNearest) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   int st = validate_regular<T>(method, dims, ndims, starts, nstarts, steps, nsteps, nvals);
   if (st) return st;
@@ -337,7 +342,7 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
                        size_t nvals, int vals_mem, int linearize, int device, interpn_hip_interp** handle) {
   if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   *handle = nullptr;
-  if (method != kLinear && method != kCubic) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (method != kLinear && method != kCubic && method != kNearest) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   int st = validate_rectilinear<T>(method, grids, grid_lens, ngrids, nvals);
   if (st) return st;
@@ -428,6 +433,7 @@ template <typename T>
 hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
                   hipStream_t stream) {
   if (npts == 0) return hipSuccess;
+  if (g.method == kNearest) return launch_nearest<T>(g, obs, out, npts, first_bad, stream);
   const bool force_generic = getenv("INTERPN_HIP_FORCE_GENERIC") != nullptr;  // testing aid
   if (force_generic || !fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
   if (g.method == kLinear)
@@ -528,6 +534,7 @@ const char* interpn_hip_strerror(int status) {
     case INTERPN_HIP_ERR_UNREPRESENTABLE: return "Unrepresentable coordinate value";
     case INTERPN_HIP_ERR_TOO_MANY_DIMS:
       return "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions.";
+    case INTERPN_HIP_ERR_TOO_MANY_DIMS_6: return "Dimension exceeds maximum (6).";
     case INTERPN_HIP_ERR_REFERENCE_PANIC: return "the reference implementation panics on this input (slice length mismatch or integer overflow)";
     case INTERPN_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
     case INTERPN_HIP_ERR_UNSUPPORTED: return "grid axis too long for the device kernels";
@@ -733,6 +740,35 @@ int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const s
   }
 DEFINE_ONESHOT(double, f64)
 DEFINE_ONESHOT(float, f32)
+
+#define DEFINE_NEAREST(T, SUFFIX)                                                                             \
+  int interpn_hip_nearest_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts, size_t nstarts, \
+                                           const T* steps, size_t nsteps, const T* vals, size_t nvals,       \
+                                           const T* const* obs, const size_t* obs_lens, size_t nobs, T* out, \
+                                           size_t nout) {                                                    \
+    /* nearest/regular.rs:50 */                                                                               \
+    if (nstarts != ndims || nsteps != ndims || nobs != ndims) return INTERPN_HIP_ERR_DIM_MISMATCH;           \
+    ONESHOT_PRECHECK(kNearest, ndims, validate_regular<T>(kNearest, dims, ndims, starts, nstarts, steps, nsteps, nvals)) \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_regular<T>(kNearest, dims, ndims, starts, nstarts, steps, nsteps, vals, nvals,           \
+                               INTERPN_HIP_MEM_HOST, 0, -1, &h);                                             \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }                                                                                                           \
+  int interpn_hip_nearest_rectilinear_##SUFFIX(const T* const* grids, const size_t* grid_lens, size_t ngrids, \
+                                               const T* vals, size_t nvals, const T* const* obs,             \
+                                               const size_t* obs_lens, size_t nobs, T* out, size_t nout) {   \
+    /* nearest/rectilinear.rs:43 */                                                                           \
+    if (nobs != ngrids) return INTERPN_HIP_ERR_DIM_MISMATCH;                                                 \
+    ONESHOT_PRECHECK(kNearest, ngrids, validate_rectilinear<T>(kNearest, grids, grid_lens, ngrids, nvals))   \
+    interpn_hip_interp* h = nullptr;                                                                         \
+    int st = create_rectilinear<T>(kNearest, grids, grid_lens, ngrids, vals, nvals, INTERPN_HIP_MEM_HOST, 0, \
+                                   -1, &h);                                                                  \
+    if (st) return st;                                                                                       \
+    ONESHOT_TAIL(T)                                                                                          \
+  }
+DEFINE_NEAREST(double, f64)
+DEFINE_NEAREST(float, f32)
 
 #define DEFINE_BOUNDS(T, SUFFIX)                                                                              \
   int interpn_hip_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,           \

@@ -7,7 +7,7 @@
 
 namespace interpn {
 
-enum Method : int { kLinear = 0, kCubic = 1 };
+enum Method : int { kLinear = 0, kCubic = 1, kNearest = 2 };
 enum Kind : int { kRegular = 0, kRectilinear = 1 };
 enum DType : int { kF64 = 0, kF32 = 1 };
 
@@ -64,6 +64,10 @@ hipError_t launch_cubic_regular(const GridDesc& g, const T* const* obs, T* out, 
 template <typename T>
 hipError_t launch_cubic_rectilinear(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                                     unsigned long long* first_bad, hipStream_t stream);
+// nearest-neighbour (src/nearest/*.rs), N = 1..6
+template <typename T>
+hipError_t launch_nearest(const GridDesc& g, const T* const* obs, T* out, size_t npts,
+                          unsigned long long* first_bad, hipStream_t stream);
 template <typename T>
 hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                           unsigned long long* first_bad, hipStream_t stream);
@@ -94,6 +98,7 @@ hipError_t launch_check_bounds(const T* x, size_t n, T lo, T hi, T atol, unsigne
 // True when the templated (flattened-arm) kernels apply: N within the flattened range of the
 // reference's dispatch and the grid indexable with 32 bits.
 inline bool fast_path(const GridDesc& g) {
+  if (g.method == kNearest) return true;
   const int maxn = g.method == kLinear ? 6 : 4;
   return g.ndims >= 1 && g.ndims <= maxn && g.nvals < 0xFFFFFFFFull;
 }

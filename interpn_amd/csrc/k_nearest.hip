@@ -1,0 +1,118 @@
+// nearest::regular / nearest::rectilinear (reference: src/nearest/regular.rs:41-101, :234-317;
+// src/nearest/rectilinear.rs:36-60, :193-262).  The same per-dimension index stage as the
+// multilinear kernels, then ONE gather per point: the node at origin + (dt <= 0.5 ? 0 : 1).
+// 64-bit indexing throughout (a single gather, nothing to save with 32-bit offsets).
+#include "rect_args.h"
+
+namespace interpn {
+
+template <typename T, int N>
+struct NearestArgs {
+  const T* vals;
+  const T* obs[N];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  T start[N];
+  T step[N];
+  int n[N];
+  unsigned long long stride[N];
+  AxisArgs<T, N> ax;
+};
+
+template <typename T, int N, bool RECT, bool FMA, bool LDS>
+__device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const unsigned char* lds) {
+  const unsigned char* axbase = LDS ? lds : a.ax.image;
+  const T half = (T)1 / ((T)1 + (T)1);
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
+    unsigned long long idx = 0;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const T x = a.obs[d][i];
+      int loc;
+      T dt;
+      if (RECT) {
+        const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
+        loc = axis_partition_point<T>(ax, x) - 1;  // nearest/rectilinear.rs:259
+        loc = loc > 0 ? loc : 0;
+        loc = loc < ax.n - 2 ? loc : ax.n - 2;
+        const T x0 = ax.g[loc];
+        const T x1 = ax.g[loc + 1];
+        const T step = x1 - x0;
+        dt = (x - x0) / step;  // rectilinear.rs:223-227
+      } else {
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);  // nearest/regular.rs:306-309
+        loc = clamp_loc<T>(floc, a.n[d] - 2);
+        const T izl = mul_add<FMA>(a.step[d], (T)loc, a.start[d]);  // regular.rs:272-275
+        dt = (x - izl) / a.step[d];
+      }
+      const int offset = (dt <= half) ? 0 : 1;  // regular.rs:283-287 (NaN compares false => 1)
+      idx += (unsigned long long)(loc + offset) * a.stride[d];
+    }
+    if (!RECT && !ok) atomicMin(a.first_bad, (unsigned long long)i);
+    a.out[i] = a.vals[idx];
+  }
+}
+
+template <typename T, int N, bool RECT, bool FMA>
+__global__ void __launch_bounds__(kBlock) k_nearest(const NearestArgs<T, N> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (RECT && a.ax.use_lds) {
+    stage_axes<T, N>(a.ax, smem_raw);
+    nearest_body<T, N, RECT, FMA, true>(a, smem_raw);
+  } else {
+    nearest_body<T, N, RECT, FMA, false>(a, nullptr);
+  }
+}
+
+template <typename T, int N>
+static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
+                           hipStream_t stream) {
+  NearestArgs<T, N> a;
+  a.vals = static_cast<const T*>(g.vals);
+  a.out = out;
+  a.first_bad = first_bad;
+  a.npts = npts;
+  unsigned long long acc = 1;
+  for (int d = N - 1; d >= 0; --d) {
+    a.obs[d] = obs[d];
+    a.start[d] = (T)g.start[d];
+    a.step[d] = (T)g.step[d];
+    a.n[d] = g.n[d];
+    a.stride[d] = acc;
+    acc *= (unsigned long long)g.n[d];
+  }
+  size_t lds = 0;
+  a.ax.use_lds = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax);
+  const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+#define GO(RECT, FMA) hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a)
+  if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
+  else GO(true, true);  // no FMA site in the rectilinear path
+#undef GO
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_nearest(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
+                          hipStream_t stream) {
+  switch (g.ndims) {
+    case 1: return launch_n<T, 1>(g, obs, out, npts, first_bad, stream);
+    case 2: return launch_n<T, 2>(g, obs, out, npts, first_bad, stream);
+    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream);
+    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream);
+    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream);
+    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_nearest<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_nearest<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
+
+}  // namespace interpn

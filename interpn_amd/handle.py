@@ -56,7 +56,7 @@ class Interpolator:
         vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
         h = c_void_p()
         st = getattr(lib, f"interpn_hip_create_regular_{sfx}")(
-            _lib.LINEAR if method == "linear" else _lib.CUBIC, d, nd, starts.ctypes.data_as(POINTER(ct)),
+            _lib.METHODS[method], d, nd, starts.ctypes.data_as(POINTER(ct)),
             starts.size, steps.ctypes.data_as(POINTER(ct)), steps.size, vptr, nvals, mem,
             int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
         _lib.raise_for_status(st)
@@ -72,7 +72,7 @@ class Interpolator:
         vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
         h = c_void_p()
         st = getattr(lib, f"interpn_hip_create_rectilinear_{sfx}")(
-            _lib.LINEAR if method == "linear" else _lib.CUBIC, gptr, glen, ng, vptr, nvals, mem,
+            _lib.METHODS[method], gptr, glen, ng, vptr, nvals, mem,
             int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
         _lib.raise_for_status(st)
         return cls(h.value, dtype, ng, keep if mem == _lib.MEM_DEVICE else None)

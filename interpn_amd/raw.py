@@ -71,7 +71,7 @@ def _ptr(a, dtype):
     return a.ctypes.data_as(POINTER(_ctype(dtype)))
 
 
-def _linear_regular(dtype, sfx, dims, starts, steps, vals, obs, out):
+def _linear_regular(dtype, sfx, dims, starts, steps, vals, obs, out, fam="linear"):
     lib = _lib.load()
     d, nd = _dims(dims)
     starts = _check_arr("starts", starts, dtype)
@@ -79,19 +79,19 @@ def _linear_regular(dtype, sfx, dims, starts, steps, vals, obs, out):
     vals = _check_arr("vals", vals, dtype)
     out = _check_arr("out", out, dtype, writable=True)
     optr, olen, nobs, _keep = _slice_of_slices("obs", obs, dtype)
-    st = getattr(lib, f"interpn_hip_linear_regular_{sfx}")(
+    st = getattr(lib, f"interpn_hip_{fam}_regular_{sfx}")(
         d, nd, _ptr(starts, dtype), starts.size, _ptr(steps, dtype), steps.size, _ptr(vals, dtype), vals.size,
         optr, olen, nobs, _ptr(out, dtype), out.size)
     _lib.raise_for_status(st)
 
 
-def _linear_rectilinear(dtype, sfx, grids, vals, obs, out):
+def _linear_rectilinear(dtype, sfx, grids, vals, obs, out, fam="linear"):
     lib = _lib.load()
     vals = _check_arr("vals", vals, dtype)
     out = _check_arr("out", out, dtype, writable=True)
     gptr, glen, ng, _k1 = _slice_of_slices("grids", grids, dtype)
     optr, olen, nobs, _k2 = _slice_of_slices("obs", obs, dtype)
-    st = getattr(lib, f"interpn_hip_linear_rectilinear_{sfx}")(
+    st = getattr(lib, f"interpn_hip_{fam}_rectilinear_{sfx}")(
         gptr, glen, ng, _ptr(vals, dtype), vals.size, optr, olen, nobs, _ptr(out, dtype), out.size)
     _lib.raise_for_status(st)
 
@@ -173,6 +173,22 @@ def interpn_linear_rectilinear_f32(grids, vals, obs, out) -> None:
     _linear_rectilinear(np.float32, "f32", grids, vals, obs, out)
 
 
+def interpn_nearest_regular_f64(dims, starts, steps, vals, obs, out) -> None:
+    _linear_regular(np.float64, "f64", dims, starts, steps, vals, obs, out, fam="nearest")
+
+
+def interpn_nearest_regular_f32(dims, starts, steps, vals, obs, out) -> None:
+    _linear_regular(np.float32, "f32", dims, starts, steps, vals, obs, out, fam="nearest")
+
+
+def interpn_nearest_rectilinear_f64(grids, vals, obs, out) -> None:
+    _linear_rectilinear(np.float64, "f64", grids, vals, obs, out, fam="nearest")
+
+
+def interpn_nearest_rectilinear_f32(grids, vals, obs, out) -> None:
+    _linear_rectilinear(np.float32, "f32", grids, vals, obs, out, fam="nearest")
+
+
 def interpn_cubic_regular_f64(dims, starts, steps, vals, linearize_extrapolation, obs, out) -> None:
     _cubic_regular(np.float64, "f64", dims, starts, steps, vals, linearize_extrapolation, obs, out)
 
@@ -210,6 +226,10 @@ __all__ = [
     "interpn_linear_regular_f32",
     "interpn_linear_rectilinear_f64",
     "interpn_linear_rectilinear_f32",
+    "interpn_nearest_regular_f64",
+    "interpn_nearest_regular_f32",
+    "interpn_nearest_rectilinear_f64",
+    "interpn_nearest_rectilinear_f32",
     "interpn_cubic_regular_f64",
     "interpn_cubic_regular_f32",
     "interpn_cubic_rectilinear_f64",

@@ -2,7 +2,7 @@
 // TEST INFRASTRUCTURE — NOT PRODUCT CODE.
 //
 // CPU restatement ("oracle") of the batched per-observation-point hot path of
-// jlogan03/interpn v0.8.2.  Only `tests/`, `__graft_entry__.smoke()` and the
+// jlogan03/interpn v0.8.2 (multilinear, multicubic, and the nearest-neighbour sibling).  Only `tests/`, `__graft_entry__.smoke()` and the
 // `cpu_baseline` leg of `bench.py` may load this library; the product path
 // (interpn_amd/csrc, include/interpn_hip.h) never links, loads or calls it.
 //
@@ -45,6 +45,7 @@ enum Status : int {
   ERR_UNREPRESENTABLE = 7,      // "Unrepresentable coordinate value"
   ERR_TOO_MANY_DIMS = 8,        // "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions."
   ERR_REFERENCE_PANIC = 9,      // the reference would panic (slice->array try_into().unwrap(), usize overflow)
+  ERR_TOO_MANY_DIMS_6 = 10,     // "Dimension exceeds maximum (6)."  (nearest)
 };
 
 constexpr int MAXDIMS = 8;  // src/python.rs:10
@@ -466,6 +467,84 @@ int cubic_rectilinear(const T* const* grids, const size_t* grid_lens, size_t ngr
   return OK;
 }
 
+// nearest::regular — src/nearest/regular.rs:41-101 (dispatch, N = 1..6), :163-195 (new),
+// :206-222 (interp), :234-317 (interp_one / get_loc).
+template <typename T, bool FMA>
+int nearest_regular(const size_t* dims, size_t ndims, const T* starts, size_t nstarts, const T* steps,
+                    size_t nsteps, const T* vals, size_t nvals, const T* const* obs, const size_t* obs_lens,
+                    size_t nobs, T* out, size_t nout, size_t* first_bad) {
+  if (nstarts != ndims || nsteps != ndims || nobs != ndims) return ERR_DIM_MISMATCH;  // regular.rs:50
+  if (ndims < 1 || ndims > 6) return ERR_TOO_MANY_DIMS_6;                              // regular.rs:97
+  const int n = (int)ndims;
+  size_t prod;
+  if (!checked_product(dims, ndims, &prod)) return ERR_REFERENCE_PANIC;
+  if (nvals != prod) return ERR_DIM_MISMATCH;                                   // regular.rs:177
+  for (int i = 0; i < n; ++i) if (dims[i] < 2) return ERR_MIN_TWO_ENTRIES;      // regular.rs:182
+  for (int i = 0; i < n; ++i) if (!(steps[i] > (T)0)) return ERR_NOT_MONOTONIC;  // regular.rs:187
+  for (int i = 0; i < n; ++i) if (obs_lens[i] != nout) return ERR_DIM_MISMATCH;  // regular.rs:210
+  Point<T> p;
+  fill_dimprod(p, dims, n);
+  const T half = (T)1 / ((T)1 + (T)1);
+  for (size_t k = 0; k < nout; ++k) {
+    size_t idx = 0;
+    for (int i = 0; i < n; ++i) {
+      T x = obs[i][k];
+      T floc = std::floor((x - starts[i]) / steps[i]);  // regular.rs:306
+      int64_t iloc;
+      if (!to_isize(floc, &iloc)) { *first_bad = k; return ERR_UNREPRESENTABLE; }
+      int64_t nn = (int64_t)dims[i];
+      int64_t dimmax = nn - 2 > 0 ? nn - 2 : 0;
+      int64_t loc = iloc > 0 ? iloc : 0;
+      loc = loc < dimmax ? loc : dimmax;
+      T origin_f = (T)loc;
+      T index_zero_loc = mul_add<FMA>(steps[i], origin_f, starts[i]);  // regular.rs:272-275
+      T dt = (x - index_zero_loc) / steps[i];
+      size_t offset = (dt <= half) ? 0 : 1;  // regular.rs:283-287 (NaN -> 1)
+      idx += ((size_t)loc + offset) * p.dimprod[i];
+    }
+    out[k] = vals[idx];
+  }
+  return OK;
+}
+
+// nearest::rectilinear — src/nearest/rectilinear.rs:36-60, :120-147 (new), :193-246 (interp_one).
+template <typename T>
+int nearest_rectilinear(const T* const* grids, const size_t* grid_lens, size_t ngrids, const T* vals, size_t nvals,
+                        const T* const* obs, const size_t* obs_lens, size_t nobs, T* out, size_t nout) {
+  const size_t ndims = ngrids;
+  if (nobs != ndims) return ERR_DIM_MISMATCH;
+  if (ndims < 1 || ndims > 6) return ERR_TOO_MANY_DIMS_6;
+  const int n = (int)ndims;
+  size_t prod;
+  if (!checked_product(grid_lens, ndims, &prod)) return ERR_REFERENCE_PANIC;
+  if (nvals != prod) return ERR_DIM_MISMATCH;
+  for (int i = 0; i < n; ++i) if (grid_lens[i] < 2) return ERR_MIN_2_ENTRIES;
+  for (int i = 0; i < n; ++i) if (!(grids[i][1] > grids[i][0])) return ERR_NOT_MONOTONIC;
+  for (int i = 0; i < n; ++i) if (obs_lens[i] != nout) return ERR_DIM_MISMATCH;
+  Point<T> p;
+  fill_dimprod(p, grid_lens, n);
+  const T half = (T)1 / ((T)1 + (T)1);
+  for (size_t k = 0; k < nout; ++k) {
+    size_t idx = 0;
+    for (int i = 0; i < n; ++i) {
+      T x = obs[i][k];
+      int64_t iloc = (int64_t)partition_point_lt(grids[i], grid_lens[i], x) - 1;  // rectilinear.rs:259
+      int64_t nn = (int64_t)grid_lens[i];
+      int64_t dimmax = nn - 2 > 0 ? nn - 2 : 0;
+      int64_t loc = iloc > 0 ? iloc : 0;
+      loc = loc < dimmax ? loc : dimmax;
+      T x0 = grids[i][loc];
+      T x1 = grids[i][loc + 1];
+      T step = x1 - x0;
+      T dt = (x - x0) / step;  // rectilinear.rs:223-227
+      size_t offset = (dt <= half) ? 0 : 1;
+      idx += ((size_t)loc + offset) * p.dimprod[i];
+    }
+    out[k] = vals[idx];
+  }
+  return OK;
+}
+
 // check_bounds — src/multilinear/regular.rs:145-182, rectilinear.rs:109-134.
 template <typename T>
 int check_bounds_regular(const size_t* dims, size_t ndims, const T* starts, const T* steps,
@@ -554,6 +633,22 @@ extern "C" {
                : cubic_rectilinear<T, false>(grids, grid_lens, ngrids, vals, nvals, linearize, obs,      \
                                              obs_lens, nobs, out, nout, first_bad);                      \
   }                                                                                                       \
+  int oracle_nearest_regular_##SUFFIX(int fma, const size_t* dims, size_t ndims, const T* starts,        \
+                                      size_t nstarts, const T* steps, size_t nsteps, const T* vals,      \
+                                      size_t nvals, const T* const* obs, const size_t* obs_lens,         \
+                                      size_t nobs, T* out, size_t nout, size_t* first_bad) {             \
+    return fma ? nearest_regular<T, true>(dims, ndims, starts, nstarts, steps, nsteps, vals, nvals, obs, \
+                                          obs_lens, nobs, out, nout, first_bad)                          \
+               : nearest_regular<T, false>(dims, ndims, starts, nstarts, steps, nsteps, vals, nvals,     \
+                                           obs, obs_lens, nobs, out, nout, first_bad);                   \
+  }                                                                                                       \
+  int oracle_nearest_rectilinear_##SUFFIX(int fma, const T* const* grids, const size_t* grid_lens,       \
+                                          size_t ngrids, const T* vals, size_t nvals,                    \
+                                          const T* const* obs, const size_t* obs_lens, size_t nobs,      \
+                                          T* out, size_t nout, size_t* first_bad) {                      \
+    (void)fma; (void)first_bad;                                                                          \
+    return nearest_rectilinear<T>(grids, grid_lens, ngrids, vals, nvals, obs, obs_lens, nobs, out, nout); \
+  }                                                                                                       \
   int oracle_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,            \
                                            const T* steps, const T* const* obs, const size_t* obs_lens,  \
                                            size_t nobs, T atol, uint8_t* out, size_t nout) {             \
@@ -583,6 +678,7 @@ const char* oracle_strerror(int status) {
     case ERR_TOO_MANY_DIMS:
       return "Dimension exceeds maximum (8). Use interpolator struct directly for higher dimensions.";
     case ERR_REFERENCE_PANIC: return "reference would panic (slice length / integer overflow)";
+    case ERR_TOO_MANY_DIMS_6: return "Dimension exceeds maximum (6).";
     default: return "unknown status";
   }
 }

@@ -153,6 +153,39 @@ def cubic_rectilinear(grids, vals, linearize_extrapolation, obs, out, fma=True):
     return out
 
 
+def nearest_regular(dims, starts, steps, vals, obs, out, fma=True):
+    dtype = out.dtype
+    ct, sfx = _ct(dtype)
+    starts, steps, vals = _arr(starts, dtype), _arr(steps, dtype), _arr(vals, dtype)
+    obs = [_arr(o, dtype) for o in obs]
+    optr, olen = _ptrs(obs, ct)
+    fb = c_size_t(0)
+    fn = getattr(lib(), f"oracle_nearest_regular_{sfx}")
+    st = fn(c_int(int(fma)), _sizes(dims), c_size_t(len(dims)), starts.ctypes.data_as(POINTER(ct)),
+            c_size_t(starts.size), steps.ctypes.data_as(POINTER(ct)), c_size_t(steps.size),
+            vals.ctypes.data_as(POINTER(ct)), c_size_t(vals.size), optr, olen, c_size_t(len(obs)),
+            out.ctypes.data_as(POINTER(ct)), c_size_t(out.size), ctypes.byref(fb))
+    _finish(st, fb)
+    return out
+
+
+def nearest_rectilinear(grids, vals, obs, out, fma=True):
+    dtype = out.dtype
+    ct, sfx = _ct(dtype)
+    grids = [_arr(g, dtype) for g in grids]
+    vals = _arr(vals, dtype)
+    obs = [_arr(o, dtype) for o in obs]
+    gptr, glen = _ptrs(grids, ct)
+    optr, olen = _ptrs(obs, ct)
+    fb = c_size_t(0)
+    fn = getattr(lib(), f"oracle_nearest_rectilinear_{sfx}")
+    st = fn(c_int(int(fma)), gptr, glen, c_size_t(len(grids)), vals.ctypes.data_as(POINTER(ct)),
+            c_size_t(vals.size), optr, olen, c_size_t(len(obs)), out.ctypes.data_as(POINTER(ct)),
+            c_size_t(out.size), ctypes.byref(fb))
+    _finish(st, fb)
+    return out
+
+
 def check_bounds_regular(dims, starts, steps, obs, atol, out):
     dtype = np.asarray(starts).dtype
     ct, sfx = _ct(dtype)

@@ -9,7 +9,11 @@ import numpy as np
 def run_oracle(oracle, case, fma=True, dtype=None):
     dtype = dtype or case.vals.dtype
     out = np.zeros(case.obs[0].size, dtype=dtype)
-    if case.method == "linear" and case.kind == "regular":
+    if case.method == "nearest" and case.kind == "regular":
+        oracle.nearest_regular(case.dims, case.starts, case.steps, case.vals, case.obs, out, fma=fma)
+    elif case.method == "nearest":
+        oracle.nearest_rectilinear(case.grids, case.vals, case.obs, out, fma=fma)
+    elif case.method == "linear" and case.kind == "regular":
         oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, case.obs, out, fma=fma)
     elif case.method == "linear":
         oracle.linear_rectilinear(case.grids, case.vals, case.obs, out, fma=fma)
@@ -29,7 +33,11 @@ def run_hip_raw(case, dtype=None):
     cv = lambda a: np.ascontiguousarray(a, dtype=dtype)
     out = np.zeros(case.obs[0].size, dtype=dtype)
     obs = [cv(o) for o in case.obs]
-    if case.method == "linear" and case.kind == "regular":
+    if case.method == "nearest" and case.kind == "regular":
+        getattr(raw, f"interpn_nearest_regular_{sfx}")(case.dims, cv(case.starts), cv(case.steps), cv(case.vals), obs, out)
+    elif case.method == "nearest":
+        getattr(raw, f"interpn_nearest_rectilinear_{sfx}")([cv(g) for g in case.grids], cv(case.vals), obs, out)
+    elif case.method == "linear" and case.kind == "regular":
         getattr(raw, f"interpn_linear_regular_{sfx}")(case.dims, cv(case.starts), cv(case.steps), cv(case.vals), obs, out)
     elif case.method == "linear":
         getattr(raw, f"interpn_linear_rectilinear_{sfx}")([cv(g) for g in case.grids], cv(case.vals), obs, out)

@@ -230,6 +230,90 @@ def py_on_grid_cases():
     return out
 
 
+def _nearest_regular_index(value, start, step, size):
+    """The reference tests' own helper: src/nearest/regular.rs:324-338 (unfused arithmetic) and
+    test/test_nearest_regular.py:5-10."""
+    floc = np.floor((value - start) / step)
+    origin = int(max(0, min(floc, size - 2)))
+    dt = (value - (start + step * origin)) / step
+    return origin if dt <= 0.5 else min(origin + 1, size - 1)
+
+
+def _nearest_rect_index(value, grid):
+    """src/nearest/rectilinear.rs:274-283."""
+    iloc = int(np.sum(grid < value)) - 1  # partition_point(|x| x < value) - 1 on a sorted grid
+    origin = int(max(0, min(iloc, grid.size - 2)))
+    dt = (value - grid[origin]) / (grid[origin + 1] - grid[origin])
+    return origin if dt <= 0.5 else origin + 1
+
+
+def nearest_cases():
+    """src/nearest/regular.rs:344-417, rectilinear.rs:285-390 and test/test_nearest_*.py."""
+    out = []
+    rng = np.random.default_rng(20260106)
+    for kind in ("regular", "rectilinear"):
+        for n in range(1, 7):
+            xs = _axes(n, 2, rng if kind == "rectilinear" else None)
+            u = seq_sum(meshgrid_ref(xs))
+            obs, pts = _obs_mesh(n, 3)
+            exp = np.zeros(pts.shape[0])
+            for d in range(n):
+                if kind == "regular":
+                    start, step = xs[d][0], xs[d][1] - xs[d][0]
+                    idx = [_nearest_regular_index(v, start, step, 2) for v in pts[:, d]]
+                    exp = exp + np.array([start + step * i for i in idx])
+                else:
+                    idx = [_nearest_rect_index(v, xs[d]) for v in pts[:, d]]
+                    exp = exp + xs[d][idx]
+            out.append(Case(f"near_{kind}_sum_N{n}", "nearest", kind, xs, u, obs, exp, 1e-12,
+                            ref=f"src/nearest/{kind}.rs"))
+        # hat function, exact equality
+        y = np.array([0.0, 1.0, 0.0])
+        x = np.array([0.0, 1.0, 2.0])
+        o = linspace_ref(-2.0, 4.0, 100)
+        if kind == "regular":
+            exp = np.array([y[_nearest_regular_index(v, 0.0, 1.0, 3)] for v in o])
+        else:
+            exp = np.array([y[_nearest_rect_index(v, x)] for v in o])
+        out.append(Case(f"near_{kind}_hat", "nearest", kind, [x], y, [o], exp, 0.0, ref=f"src/nearest/{kind}.rs"))
+    # rectilinear 2d small (rectilinear.rs:285-313)
+    x = linspace_ref(-1.0, 1.0, 3)
+    y = np.array([0.5, 0.6])
+    xy = meshgrid_ref([x, y])
+    z = xy[:, 0] + xy[:, 1]
+    xo = linspace_ref(-10.0, 10.0, 5)
+    pts = meshgrid_ref([xo, xo])
+    exp = np.array([x[_nearest_rect_index(p[0], x)] + y[_nearest_rect_index(p[1], y)] for p in pts])
+    out.append(Case("near_rectilinear_2d_small", "nearest", "rectilinear", [x, y], z,
+                    [np.ascontiguousarray(pts[:, 0]), np.ascontiguousarray(pts[:, 1])], exp, 1e-12,
+                    ref="src/nearest/rectilinear.rs:285"))
+    # Python tests (exact equality, f64 and f32)
+    for dtype in (np.float64, np.float32):
+        tag = "f64" if dtype == np.float64 else "f32"
+        x = np.linspace(0.0, 6.0, 4).astype(dtype)
+        y = np.linspace(-3.0, 3.0, 3).astype(dtype)
+        xg, yg = np.meshgrid(x, y, indexing="ij")
+        zg = (xg - 2.0 * yg).astype(dtype)
+        obs = [np.array([0.1, 1.6, 2.9, 5.0], dtype=dtype), np.array([-3.0, -1.2, 0.4, 2.4], dtype=dtype)]
+        starts = np.array([x[0], y[0]]).astype(dtype)
+        steps = np.array([x[1] - x[0], y[1] - y[0]]).astype(dtype)
+        exp = np.array([zg[_nearest_regular_index(float(a), float(starts[0]), float(steps[0]), 4),
+                           _nearest_regular_index(float(b), float(starts[1]), float(steps[1]), 3)]
+                        for a, b in zip(obs[0], obs[1])], dtype=dtype)
+        out.append(Case(f"py_near_regular_{tag}", "nearest", "regular", [x, y], zg.flatten(), obs, exp, 0.0,
+                        ref="test/test_nearest_regular.py"))
+        x = np.array([0.0, 1.0, 3.5, 4.0], dtype=dtype)
+        y = np.array([-2.0, -0.5, 0.1], dtype=dtype)
+        xg, yg = np.meshgrid(x, y, indexing="ij")
+        zg = (xg + yg**2).astype(dtype)
+        obs = [np.array([0.2, 2.8, 3.8], dtype=dtype), np.array([-1.5, -0.2, 0.4], dtype=dtype)]
+        exp = np.array([zg[_nearest_rect_index(float(a), x), _nearest_rect_index(float(b), y)]
+                        for a, b in zip(obs[0], obs[1])], dtype=dtype)
+        out.append(Case(f"py_near_rectilinear_{tag}", "nearest", "rectilinear", [x, y], zg.flatten(), obs, exp, 0.0,
+                        ref="test/test_nearest_rectilinear.py"))
+    return out
+
+
 def all_cases(max_lin_n: int = 8, max_cub_n: int = 5):
     cases = []
     for kind in ("regular", "rectilinear"):
@@ -240,6 +324,7 @@ def all_cases(max_lin_n: int = 8, max_cub_n: int = 5):
     cases.append(rect_2d_small_case())
     cases += const2_cases()
     cases += py_on_grid_cases()
+    cases += nearest_cases()
     return cases
 
 

@@ -15,7 +15,7 @@ from tests.helpers import rel_err, run_hip_raw, run_oracle, synthetic_case
 
 pytestmark = pytest.mark.gpu
 
-TOL = {("linear", np.float64): 1e-12, ("cubic", np.float64): 1e-10, ("linear", np.float32): 1e-6,
+TOL = {("nearest", np.float64): 0.0, ("nearest", np.float32): 0.0, ("linear", np.float64): 1e-12, ("cubic", np.float64): 1e-10, ("linear", np.float32): 1e-6,
        ("cubic", np.float32): 1e-6}
 
 
@@ -126,6 +126,45 @@ def test_generic_kernel_at_low_n(oracle, monkeypatch, method, kind, n, dtype):
     case = synthetic_case(method, kind, n, [m + d for d in range(n)], 20_011, 500 + n, dtype, linearize=True,
                           extrap=0.3)
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_nearest_random(oracle, kind, n, dtype):
+    """nearest::{regular,rectilinear} (SURVEY.md section 8 f3): index stage of the multilinear path +
+    one gather; must pick the same node as the reference, ties (dt == 0.5) and NaN included."""
+    axis = {1: [257], 2: [33, 64], 3: [17, 9, 32], 4: [7, 9, 5, 12], 5: [4, 5, 3, 6, 7], 6: [3, 4, 2, 5, 3, 4]}[n]
+    case = synthetic_case("nearest", kind, n, axis, 100_003, 1500 + n, dtype, extrap=0.2)
+    # exact midpoints between nodes (dt == 0.5 -> lower node)
+    for d in range(n):
+        g = case.grids[d]
+        case.obs[d][100:100 + g.size - 1] = ((g[:-1].astype(np.float64) + g[1:].astype(np.float64)) / 2).astype(dtype)
+    if kind == "rectilinear":
+        case.obs[0][77] = np.nan  # NaN -> cell 0, dt NaN -> upper node, no error
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+def test_nearest_api_levels(oracle):
+    """test/test_nearest_regular.py and test_nearest_rectilinear.py: raw, interpn(method="nearest"),
+    class .eval and JSON round trip agree exactly; 7-D input is rejected with the reference's message."""
+    import interpn_amd
+
+    for c in kat.nearest_cases():
+        if not c.name.startswith("py_"):
+            continue
+        want = run_oracle(oracle, c, True)
+        kat.check(c, want)
+        if c.kind == "regular":
+            it = interpn_amd.NearestRegular.new(c.dims, c.starts, c.steps, c.vals)
+        else:
+            it = interpn_amd.NearestRectilinear.new(c.grids, c.vals)
+        assert np.array_equal(it.eval(c.obs), want)
+        assert np.array_equal(type(it).model_validate_json(it.model_dump_json()).eval(c.obs), want)
+        assert np.array_equal(interpn_amd.interpn(obs=c.obs, grids=c.grids, vals=c.vals, method="nearest"), want)
+    with pytest.raises(AssertionError, match=r"Dimension exceeds maximum \(6\)\."):
+        interpn_amd.raw.interpn_nearest_regular_f64([2] * 7, np.zeros(7), np.ones(7), np.zeros(128),
+                                                    [np.zeros(3)] * 7, np.zeros(3))
 
 
 def test_no_fma_flavour(oracle):

@@ -10,7 +10,11 @@ from tests import kat
 def run_oracle(oracle, case, fma, dtype=None):
     dtype = dtype or case.vals.dtype
     out = np.zeros(case.obs[0].size, dtype=dtype)
-    if case.method == "linear" and case.kind == "regular":
+    if case.method == "nearest" and case.kind == "regular":
+        oracle.nearest_regular(case.dims, case.starts, case.steps, case.vals, case.obs, out, fma=fma)
+    elif case.method == "nearest":
+        oracle.nearest_rectilinear(case.grids, case.vals, case.obs, out, fma=fma)
+    elif case.method == "linear" and case.kind == "regular":
         oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, case.obs, out, fma=fma)
     elif case.method == "linear":
         oracle.linear_rectilinear(case.grids, case.vals, case.obs, out, fma=fma)
@@ -22,7 +26,7 @@ def run_oracle(oracle, case, fma, dtype=None):
 
 
 RUST_CASES = [c for c in kat.all_cases(8, 6) if not c.name.startswith("py_")]
-PY_CASES = [c for c in kat.all_cases(1, 1) if c.name.startswith("py_")]
+PY_CASES = [c for c in kat.all_cases(1, 1) if c.name.startswith("py_")]  # incl. py_near_*
 
 
 @pytest.mark.parametrize("fma", [False, True], ids=["nofma", "fma"])
