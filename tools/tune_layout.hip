@@ -187,6 +187,59 @@ __global__ void __launch_bounds__(1024) k_stream16(const double2* x, const doubl
   }
 }
 
+// Cell-major layout: every cell's 8 corners as 64 contiguous, 64-B aligned bytes (8x the grid):
+// piece p = (di,dj) at cell*8 + p*2.  Quad-cooperative gather as in k_coop.
+template <bool NOSTREAM>
+__global__ void __launch_bounds__(256) k_coop_cell(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[256 * 80 + 256 * 16];
+  const unsigned lane = threadIdx.x, q = lane & 3, quad = lane >> 2;
+  d2u* lds_piece = reinterpret_cast<d2u*>(lds_raw);
+  unsigned* lds_off = reinterpret_cast<unsigned*>(lds_raw + 256 * 80);
+  const size_t nthreads = (size_t)gridDim.x * 256;
+  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  for (size_t it = 0; it < niter; ++it) {
+    const size_t i0 = it * nthreads + (size_t)blockIdx.x * 256 + lane;
+    const bool live = i0 < a.npts;
+    double x[3], t[3]; int loc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (NOSTREAM) {
+        unsigned long long z = (i0 * 3 + d) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        x[d] = -1.0 + 2.0 * (double)(z >> 11) * (1.0 / 9007199254740992.0);
+      } else x[d] = live ? a.obs[d][i0] : a.start;
+      double floc = __builtin_floor((x[d] - a.start) / a.step);
+      floc = floc > 0 ? floc : 0; int l = (int)floc; l = l < a.n - 2 ? l : a.n - 2; loc[d] = l;
+      t[d] = (x[d] - __builtin_fma(a.step, (double)l, a.start)) / a.step;
+    }
+    const unsigned cell = ((unsigned)loc[0] * (a.n - 1) + loc[1]) * (a.n - 1) + loc[2];
+    lds_off[quad * 4 + q] = cell * 8u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint4 cb = *reinterpret_cast<uint4*>(&lds_off[quad * 4]);
+    d2u pc[4];
+    pc[0] = *(const d2u*)(a.vals + cb.x + q * 2);
+    pc[1] = *(const d2u*)(a.vals + cb.y + q * 2);
+    pc[2] = *(const d2u*)(a.vals + cb.z + q * 2);
+    pc[3] = *(const d2u*)(a.vals + cb.w + q * 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * 5 + q] = pc[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double v[2][2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { d2u w = lds_piece[(quad * 4 + q) * 5 + p]; v[p >> 1][p & 1][0] = w.x; v[p >> 1][p & 1][1] = w.y; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double r[2];
+#pragma unroll
+    for (int dk = 0; dk < 2; ++dk) {
+      double c0 = __builtin_fma(t[0], v[1][0][dk] - v[0][0][dk], v[0][0][dk]);
+      double c1 = __builtin_fma(t[0], v[1][1][dk] - v[0][1][dk], v[0][1][dk]);
+      r[dk] = __builtin_fma(t[1], c1 - c0, c0);
+    }
+    double res = __builtin_fma(t[2], r[1] - r[0], r[0]);
+    if (NOSTREAM) { if (res == 123.456) a.out[i0] = res; } else if (live) a.out[i0] = res;
+  }
+}
+
 static std::vector<double> make_bricks(const std::vector<double>& v, int n, int SI, int SJ, int SK, unsigned& nbi, unsigned& nbj, unsigned& nbk) {
   nbi = (n - 2) / SI + 2; nbj = (n - 2) / SJ + 2; nbk = (n - 2) / SK + 2;
   std::vector<double> b((size_t)nbi * nbj * nbk * 16, 0.0);
@@ -231,6 +284,40 @@ int main(int argc, char** argv) {
   for (int d = 0; d < 3; ++d) a.obs[d] = dx[d];
   printf("P=%zu grid=%d^3 (%.1f MiB row-major)\n", P, n, G * 8 / 1048576.0);
   const unsigned BLK = 2048 * 2;
+  if (argc > 3 && argv[3][0] == 'e') {  // cell-major 64-B layout vs fully overlapped bricks
+    a.out = dref;
+    hipLaunchKernelGGL((k_lay<0, 2, 2, 4, LD_PLAIN, false>), dim3(BLK), dim3(256), 0, 0, a); CK(hipDeviceSynchronize());
+    a.out = dout;
+    {
+      unsigned nbi, nbj, nbk;
+      std::vector<double> b = make_bricks(hv, n, 1, 1, 3, nbi, nbj, nbk);
+      double* db; CK(hipMalloc(&db, b.size() * 8)); CK(hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice));
+      Args c = a; c.vals = db; c.nbj = nbj; c.nbk = nbk;
+      char name[128]; snprintf(name, sizeof name, "coop brick(1,1,3) %.1f MiB full", b.size() * 8 / 1048576.0);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<1, 1, 3, false>), dim3(BLK), dim3(256), 0, 0, c); }, P);
+      time_it("coop brick(1,1,3) gather-only", [&] { hipLaunchKernelGGL((k_coop<1, 1, 3, true>), dim3(BLK), dim3(256), 0, 0, c); }, P);
+      CK(hipFree(db));
+    }
+    {
+      size_t nc = (size_t)(n - 1) * (n - 1) * (n - 1);
+      std::vector<double> cm(nc * 8);
+      for (int i = 0; i < n - 1; ++i) for (int j = 0; j < n - 1; ++j) for (int k = 0; k < n - 1; ++k)
+        for (int p = 0; p < 4; ++p) for (int dk = 0; dk < 2; ++dk)
+          cm[(((size_t)i * (n - 1) + j) * (n - 1) + k) * 8 + p * 2 + dk] = hv[((size_t)(i + (p >> 1)) * n + (j + (p & 1))) * n + k + dk];
+      double* dc; CK(hipMalloc(&dc, cm.size() * 8)); CK(hipMemcpy(dc, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
+      Args c = a; c.vals = dc;
+      CK(hipMemset(dout, 0, P * 8));
+      char name[128]; snprintf(name, sizeof name, "coop cell-major 64B %.1f MiB full", cm.size() * 8 / 1048576.0);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop_cell<false>), dim3(BLK), dim3(256), 0, 0, c); }, P);
+      std::vector<double> ref(1 << 20), got(1 << 20);
+      CK(hipMemcpy(ref.data(), dref, ref.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(got.data(), dout, got.size() * 8, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t q = 0; q < got.size(); ++q) bad += got[q] != ref[q];
+      snprintf(name, sizeof name, "coop cell-major 64B gather-only [mismatch %zu]", bad);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop_cell<true>), dim3(BLK), dim3(256), 0, 0, c); }, P);
+      CK(hipFree(dc));
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 's') {  // streaming-rate calibration
     for (int blk : {1024, 2048, 4096, 8192}) {
       char name[128];
