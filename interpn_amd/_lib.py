@@ -36,28 +36,29 @@ class ReferencePanic(RuntimeError):
 
 
 def _preload_hip_runtime() -> None:
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
-    libamdhip64.so.7, the same as /opt/rocm's).  If libinterpn_hip.so were loaded first it would
-    bind to /opt/rocm's copy and a later `import torch` would bring up a second runtime that
-    cannot open the device ("no ROCm-capable device is detected").  Loading torch's copy first
-    (by path, without importing torch) makes both bind to the same runtime."""
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and
+    libhsa-runtime64.so (same sonames as /opt/rocm's).  If libinterpn_hip.so were loaded first it
+    would bind to /opt/rocm's copies, and a later `import torch` would bring up a second runtime:
+    observed as "no ROCm-capable device is detected" or as a hang inside `import torch`.  Loading
+    only torch's libamdhip64.so by path is not enough (its HSA runtime then comes from /opt/rocm
+    and torch later loads its own).  So when torch is installed it is imported first — the order
+    every working configuration has — and libinterpn_hip.so binds to the runtime torch loaded.
+    INTERPN_AMD_NO_TORCH_PRELOAD=1 skips this (processes that never import torch)."""
     import importlib.util
     import sys
 
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("INTERPN_AMD_NO_TORCH_PRELOAD"):
         return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec is None or not spec.origin:
+    if spec is None:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass  # fall back to the system runtime
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass  # fall back to the system runtime
 
 
 def load() -> ctypes.CDLL:

@@ -263,6 +263,77 @@ def test_classes_and_helper(oracle):
             assert any(it.check_bounds(far, dtype(1e-6)))
 
 
+def test_interpn_helper_contract(oracle):
+    """src/interpn/__init__.py:48-194: N-D observation arrays are ravelled and the result takes
+    their shape; `out=` is written in place; exact-equal spacing selects the regular path, anything
+    else the rectilinear one; check_bounds raises ValueError; f32 follows `vals`."""
+    import interpn_amd
+
+    rng = np.random.default_rng(5)
+    x, y = np.linspace(-1, 1, 9), np.linspace(0, 3, 7)
+    vals = rng.uniform(-1, 1, (9, 7))
+    obs = [rng.uniform(-1.2, 1.2, (13, 11)), rng.uniform(-0.3, 3.3, (13, 11))]
+    flat = [o.ravel() for o in obs]
+    for method, fn_reg, fn_rect, extra in (
+            ("linear", oracle.linear_regular, oracle.linear_rectilinear, ()),
+            ("cubic", oracle.cubic_regular, oracle.cubic_rectilinear, (True,)),
+            ("nearest", oracle.nearest_regular, oracle.nearest_rectilinear, ())):
+        want = np.zeros(flat[0].size)
+        starts, steps = np.array([x[0], y[0]]), np.array([x[1] - x[0], y[1] - y[0]])
+        is_regular = interpn_amd._check_regular([x, y])
+        if is_regular:
+            fn_reg([9, 7], starts, steps, vals.ravel(), *extra, flat, want)
+        else:
+            fn_rect([x, y], vals.ravel(), *extra, flat, want)
+        got = interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals, method=method)
+        assert got.shape == (13, 11) and np.array_equal(got.ravel(), want)
+        buf = np.zeros((13, 11))
+        ret = interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals, method=method, out=buf)
+        assert np.array_equal(buf.ravel(), want) and ret.shape == (13, 11)
+        # assume_regular skips the spacing check and uses grid[1]-grid[0] (:107)
+        want2 = np.zeros(flat[0].size)
+        fn_reg([9, 7], starts, steps, vals.ravel(), *extra, flat, want2)
+        got2 = interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals, method=method, assume_regular=True)
+        assert np.array_equal(got2.ravel(), want2)
+        # a perturbed axis goes down the rectilinear path
+        xr = x.copy(); xr[3] += 1e-3
+        want3 = np.zeros(flat[0].size)
+        fn_rect([xr, y], vals.ravel(), *extra, flat, want3)
+        got3 = interpn_amd.interpn(obs=obs, grids=[xr, y], vals=vals, method=method)
+        assert np.array_equal(got3.ravel(), want3)
+    with pytest.raises(ValueError, match="violate interpolator bounds"):
+        interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals, check_bounds=True)
+    inside = [np.clip(obs[0], -1, 1), np.clip(obs[1], 0, 3)]
+    interpn_amd.interpn(obs=inside, grids=[x, y], vals=vals, check_bounds=True)
+    got32 = interpn_amd.interpn(obs=[o.astype(np.float32) for o in obs], grids=[x.astype(np.float32), y.astype(np.float32)],
+                                vals=vals.astype(np.float32))
+    assert got32.dtype == np.float32
+    with pytest.raises(AssertionError, match="defined only for float32 and float64"):
+        interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals.astype(np.int32))
+
+
+def test_class_eval_on_torch_tensors(oracle):
+    """`.eval` of the classes accepts torch CUDA tensors: points never leave the device."""
+    import torch
+
+    import interpn_amd
+
+    rng = np.random.default_rng(8)
+    dims, starts, steps = [12, 9, 10], np.array([-1.0, 0.0, 2.0]), np.array([0.2, 0.5, 0.1])
+    vals = rng.uniform(-1, 1, 12 * 9 * 10)
+    obs = [rng.uniform(starts[d] - 0.1, starts[d] + steps[d] * (dims[d] - 1) + 0.1, 50_000) for d in range(3)]
+    want = np.zeros(50_000)
+    oracle.cubic_regular(dims, starts, steps, vals, True, obs, want)
+    it = interpn_amd.MulticubicRegular.new(dims, starts, steps, vals)
+    got = it.eval([torch.from_numpy(o).cuda() for o in obs])
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+    bad = [torch.from_numpy(o).cuda() for o in obs]
+    bad[1][123] = float("nan")
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+        it.eval(bad)
+    assert ei.value.first_bad_index == 123
+
+
 def test_check_bounds_matches_oracle(oracle):
     from interpn_amd import raw
 
