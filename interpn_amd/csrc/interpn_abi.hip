@@ -227,6 +227,22 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
 int maybe_build_bricks(interpn_hip_interp* h) {
   GridDesc& g = h->desc;
   if (g.method == kCubic && g.ndims >= 2 && g.ndims <= 4) return maybe_build_cubic_tiles(h);
+  if (g.method == kLinear && g.ndims == 2) {
+    const char* env2 = getenv("INTERPN_HIP_BRICKS");
+    if (env2 && !strcmp(env2, "off")) return INTERPN_HIP_OK;
+    size_t bytes2;
+    brick2_geometry(g, g.brick_nb, &bytes2);
+    g.brick_nb[2] = 1;
+    size_t free2 = 0, total2 = 0;
+    if (hipMemGetInfo(&free2, &total2) != hipSuccess) free2 = (size_t)8 << 30;
+    if (bytes2 > free2 / 4 || bytes2 / (g.dtype == kF64 ? 8 : 4) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
+    hipError_t e2 = hipMalloc(&h->bricks_owned, bytes2);
+    if (e2 != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
+    HIP_TRY(build_bricks2(g, h->bricks_owned, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    g.bricks = h->bricks_owned;
+    return INTERPN_HIP_OK;
+  }
   if (!(g.method == kLinear && g.ndims >= 3 && g.ndims <= 6)) return INTERPN_HIP_OK;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
@@ -451,6 +467,13 @@ hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size
                                         npts, first_bad, stream);
     return launch_cubic_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
                                      first_bad, stream);
+  }
+  if (g.bricks && npts && g.ndims == 2 && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+    if (g.dtype == kF64)
+      return launch_linear2_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
+                                          npts, first_bad, stream);
+    return launch_linear2_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
+                                       first_bad, stream);
   }
   if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
     if (g.dtype == kF64)

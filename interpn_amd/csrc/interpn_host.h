@@ -79,6 +79,13 @@ template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                                unsigned long long* first_bad, hipStream_t stream);
 
+// Bricked 2-D multilinear path (k_linear2_brick.hip): 2 x KW2 bricks, steps (1, KW2-1).
+void brick2_geometry(const GridDesc& g, unsigned nb[2], size_t* bytes);
+hipError_t build_bricks2(const GridDesc& g, void* bricks, hipStream_t stream);
+template <typename T>
+hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
+                                unsigned long long* first_bad, hipStream_t stream);
+
 // Tiled multicubic path (k_cubic_brick.hip): dims 0,1 in 4 x 4 tiles stepped brick_step[0..1].
 void cubic_tile_geometry(const GridDesc& g, int si, int sj, unsigned nb[2], size_t* bytes);
 hipError_t build_cubic_tiles(const GridDesc& g, void* tiles, hipStream_t stream);

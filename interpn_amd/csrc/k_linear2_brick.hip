@@ -1,0 +1,184 @@
+// 2-D multilinear (regular and rectilinear, f64 and f32) on a bricked copy of the grid with a
+// lane-pair cooperative gather.
+//
+// In C order the four corners of a 2-D cell lie on two rows = two 128-B lines.  Here the grid is
+// re-laid in bricks of 2 rows x KW2 columns (KW2 = 8 for f64, 16 for f32; one 128-B line), stepped
+// 1 along i (every row pair is stored) and KW2-1 along j (a j-pair never leaves a brick row), i.e.
+// 2 * KW2/(KW2-1) = 2.3x the grid, so that a cell's corners are one line.  The two lanes of a pair
+// fetch the two row pieces of ONE point per load instruction (same line => one L2 request), then
+// swap the piece they hold for the other point with a quad-permute DPP move — no LDS.  Arithmetic
+// and operation order are the reference's (src/multilinear/regular.rs:296-404), results are
+// bit-identical to the C-order kernel.
+#include "rect_args.h"
+
+namespace interpn {
+
+template <typename T> struct Brick2Geom {
+  static constexpr int KW = 64 / (int)sizeof(T);  // columns per brick row (64 B)
+  static constexpr int SJ = KW - 1;
+  static constexpr int ELEMS = 2 * KW;            // 128 B
+};
+
+template <typename T>
+struct Brick2Args {
+  const T* bricks;
+  const T* obs[2];
+  T* out;
+  unsigned long long* first_bad;
+  size_t npts;
+  T start[2];
+  T step[2];
+  int n[2];
+  AxisArgs<T, 2> ax;
+  unsigned nbj;
+};
+
+// swap with the neighbouring lane (lane ^ 1): quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned dpp_swap1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float dpp_swap1(float v) { return __uint_as_float(dpp_swap1(__float_as_uint(v))); }
+__device__ __forceinline__ double dpp_swap1(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = dpp_swap1((unsigned)b), hi = dpp_swap1((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename T, bool RECT, bool FMA>
+__global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a) {
+  typedef typename LeafVec<T, 2>::type P;
+  constexpr int KW = Brick2Geom<T>::KW;
+  constexpr int SJ = Brick2Geom<T>::SJ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (RECT && a.ax.use_lds) stage_axes<T, 2>(a.ax, smem_raw);
+  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? smem_raw : a.ax.image;
+  const unsigned lane = threadIdx.x;
+  const unsigned q = lane & 1;  // which row piece this lane fetches
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  for (size_t it = 0; it < niter; ++it) {
+    const size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    const bool live = i0 < a.npts;
+    T t[2];
+    int loc[2];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      if (RECT) {
+        const T x = live ? a.obs[d][i0] : (T)0;
+        const Axis<T> ax = make_axis<T, 2>(a.ax, axis_base, d);
+        int l = axis_partition_point<T>(ax, x) - 1;  // multilinear/rectilinear.rs:363
+        l = l > 0 ? l : 0;
+        l = l < a.n[d] - 2 ? l : a.n[d] - 2;
+        const T x0 = ax.g[l];
+        const T x1 = ax.g[l + 1];
+        const T step = x1 - x0;
+        t[d] = (x - x0) / step;
+        loc[d] = l;
+      } else {
+        const T x = live ? a.obs[d][i0] : a.start[d];
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
+        const int l = clamp_loc<T>(floc, a.n[d] - 2);
+        const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);
+        t[d] = (x - izl) / a.step[d];
+        loc[d] = l;
+      }
+    }
+    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i0);
+    // brick (bi = i, bj = j / SJ); my point's pair starts at column j - bj*SJ of both rows
+    const unsigned bj = (unsigned)loc[1] / (unsigned)SJ;
+    const unsigned mine = ((unsigned)loc[0] * a.nbj + bj) * (unsigned)Brick2Geom<T>::ELEMS + ((unsigned)loc[1] - bj * (unsigned)SJ);
+    const unsigned theirs = dpp_swap1(mine);
+    // instruction r fetches point r of the pair (r = 0: even lane's point, r = 1: odd lane's)
+    const unsigned off0 = (q == 0 ? mine : theirs) + q * (unsigned)KW;
+    const unsigned off1 = (q == 0 ? theirs : mine) + q * (unsigned)KW;
+    const P p0 = *reinterpret_cast<const P*>(a.bricks + off0);
+    const P p1 = *reinterpret_cast<const P*>(a.bricks + off1);
+    // I keep the piece of my own point and trade the other one
+    const P keep = q == 0 ? p0 : p1;
+    const P send = q == 0 ? p1 : p0;
+    P recv;
+    recv.x = dpp_swap1(send.x);
+    recv.y = dpp_swap1(send.y);
+    const P row0 = q == 0 ? keep : recv;  // row i   : v(i, j), v(i, j+1)
+    const P row1 = q == 0 ? recv : keep;  // row i+1
+    // reference tree: dim 0 first for each j, then dim 1 (multilinear/regular.rs:347-403)
+    const T c0 = mul_add<FMA>(t[0], row1.x - row0.x, row0.x);
+    const T c1 = mul_add<FMA>(t[0], row1.y - row0.y, row0.y);
+    const T res = mul_add<FMA>(t[1], c1 - c0, c0);
+    if (live) a.out[i0] = res;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_bricks2(const T* __restrict__ vals, T* __restrict__ bricks, int n0, int n1,
+                                                          unsigned nbi, unsigned nbj) {
+  constexpr int KW = Brick2Geom<T>::KW;
+  constexpr int EL = Brick2Geom<T>::ELEMS;
+  const size_t total = (size_t)nbi * nbj * EL;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const unsigned within = (unsigned)(e % EL);
+    const size_t b = e / EL;
+    const unsigned bj = (unsigned)(b % nbj);
+    const unsigned bi = (unsigned)(b / nbj);
+    const int i = (int)bi + (int)(within / KW);
+    const int j = (int)bj * (KW - 1) + (int)(within % KW);
+    T v = (T)0;
+    if (i < n0 && j < n1) v = vals[(size_t)i * n1 + j];
+    bricks[e] = v;
+  }
+}
+
+void brick2_geometry(const GridDesc& g, unsigned nb[2], size_t* bytes) {
+  const int kw = g.dtype == kF64 ? 8 : 16;
+  nb[0] = (unsigned)(g.n[0] - 1);
+  nb[1] = (unsigned)((g.n[1] - 2) / (kw - 1) + 1);
+  *bytes = (size_t)nb[0] * nb[1] * 128;
+}
+
+hipError_t build_bricks2(const GridDesc& g, void* bricks, hipStream_t stream) {
+  const size_t elems = (size_t)g.brick_nb[0] * g.brick_nb[1] * (g.dtype == kF64 ? 16 : 32);
+  size_t blocks = (elems + kBlock - 1) / kBlock;
+  if (blocks > 65535) blocks = 65535;
+  if (g.dtype == kF64)
+    hipLaunchKernelGGL(k_build_bricks2<double>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const double*>(g.vals),
+                       static_cast<double*>(bricks), g.n[0], g.n[1], g.brick_nb[0], g.brick_nb[1]);
+  else
+    hipLaunchKernelGGL(k_build_bricks2<float>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const float*>(g.vals),
+                       static_cast<float*>(bricks), g.n[0], g.n[1], g.brick_nb[0], g.brick_nb[1]);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
+                                hipStream_t stream) {
+  Brick2Args<T> a;
+  a.bricks = static_cast<const T*>(g.bricks);
+  a.out = out;
+  a.first_bad = first_bad;
+  a.npts = npts;
+  for (int d = 0; d < 2; ++d) {
+    a.obs[d] = obs[d];
+    a.start[d] = (T)g.start[d];
+    a.step[d] = (T)g.step[d];
+    a.n[d] = g.n[d];
+  }
+  a.nbj = g.brick_nb[1];
+  size_t lds = 0;
+  a.ax.use_lds = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax);
+  const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+#define GO(RECT, FMA) hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a)
+  if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
+  else { if (g.fma) GO(true, true); else GO(true, false); }
+#undef GO
+  return hipGetLastError();
+}
+
+template hipError_t launch_linear2_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_linear2_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
+
+}  // namespace interpn

@@ -98,6 +98,29 @@ def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("layout", ["off", "on"])
+@pytest.mark.parametrize("axis", [[2, 2], [2, 9], [3, 8], [9, 2], [16, 17], [33, 15], [7, 100], [257, 129]], ids=str)
+def test_linear2_brick(oracle, monkeypatch, dtype, kind, layout, axis):
+    """2-D multilinear on 2 x KW2 bricks with a lane-pair gather (k_linear2_brick.hip): same bits as
+    the C-order kernel; axis lengths around the brick step (7 / 15 columns), odd point counts, NaN."""
+    if layout == "off":
+        monkeypatch.setenv("INTERPN_HIP_BRICKS", "off")
+    else:
+        monkeypatch.delenv("INTERPN_HIP_BRICKS", raising=False)
+    case = synthetic_case("linear", kind, 2, axis, 30_001, 1700 + sum(axis), dtype, extrap=0.3, specials=min(axis) >= 8)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+    if kind == "regular" and dtype == np.float64:
+        case.obs[0][2999] = np.inf
+        from interpn_amd import raw
+
+        got = np.full(30_001, -1.0)
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+            raw.interpn_linear_regular_f64(case.dims, case.starts, case.steps, case.vals, case.obs, got)
+        assert np.all(got[2999:] == -1.0) and np.all(got[:2999] != -1.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 @pytest.mark.parametrize("layout", ["off", "44", "24", "22", "14", "11"])
