@@ -160,6 +160,23 @@ __device__ __forceinline__ int axis_partition_point(const Axis<T>& ax, T x) {
   return partition_point_lt<T>(ax.g, ax.n, x);
 }
 
+// Cell of a multilinear / nearest query on a rectilinear axis: loc = clamp(partition_point - 1,
+// 0, n-2) and the two bracketing coordinates g[loc], g[loc+1] (multilinear/rectilinear.rs:353-370
+// and :310-311).  (A speculative variant that fetched the four coordinates around the bucket start
+// with independent reads and selected x0/x1 from registers was measured SLOWER — cfg3 2.01 vs
+// 1.80 ms: the search is bound by the number of bank-conflicting LDS gathers on the tiny axis
+// image, not by their dependency chain — so the short scan below stays.)
+template <typename T>
+__device__ __forceinline__ int axis_cell(const Axis<T>& ax, T x, T* x0, T* x1) {
+  const int n = ax.n;
+  int l = axis_partition_point<T>(ax, x) - 1;
+  l = l > 0 ? l : 0;
+  l = l < n - 2 ? l : n - 2;
+  *x0 = ax.g[l];
+  *x1 = ax.g[l + 1];
+  return l;
+}
+
 // ---------------------------------------------------------------------------
 // Linear tree: reduce dims 0..D-1 (dim 0 innermost) on a W-wide leaf of the last dim.
 // Same dependency tree as src/multilinear/regular.rs:347-393 / regular_recursive.rs:348-389.

@@ -149,12 +149,8 @@ __device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a,
 #pragma unroll
       for (int d = 0; d < N; ++d) {
         const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
-        const int pp = axis_partition_point<T>(ax, x[u][d]);  // rectilinear.rs:363
-        int loc = pp - 1;
-        loc = loc > 0 ? loc : 0;
-        loc = loc < ax.n - 2 ? loc : ax.n - 2;  // rectilinear.rs:365-367
-        const T x0 = ax.g[loc];
-        const T x1 = ax.g[loc + 1];
+        T x0, x1;
+        const int loc = axis_cell<T>(ax, x[u][d], &x0, &x1);  // rectilinear.rs:353-370, :310-311
         const T step = x1 - x0;
         t[u][d] = (x[u][d] - x0) / step;  // rectilinear.rs:310-313 (same value at every node of dim d)
         base[u] += (unsigned)loc * a.stride[d];

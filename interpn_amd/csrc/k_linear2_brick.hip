@@ -67,11 +67,8 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
       if (RECT) {
         const T x = live ? a.obs[d][i0] : (T)0;
         const Axis<T> ax = make_axis<T, 2>(a.ax, axis_base, d);
-        int l = axis_partition_point<T>(ax, x) - 1;  // multilinear/rectilinear.rs:363
-        l = l > 0 ? l : 0;
-        l = l < a.n[d] - 2 ? l : a.n[d] - 2;
-        const T x0 = ax.g[l];
-        const T x1 = ax.g[l + 1];
+        T x0, x1;
+        const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
         const T step = x1 - x0;
         t[d] = (x - x0) / step;
         loc[d] = l;

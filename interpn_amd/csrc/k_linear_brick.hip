@@ -50,7 +50,10 @@ __device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int 
   return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
 }
 
-constexpr int kPieceRow = 5;  // piece slots per point row in LDS (4 used + 1 pad against bank conflicts)
+#ifndef INTERPN_PIECE_ROW
+#define INTERPN_PIECE_ROW 5
+#endif
+constexpr int kPieceRow = INTERPN_PIECE_ROW;  // piece slots per point row in LDS (4 used + 1 pad against bank conflicts)
 
 template <typename T>
 struct Cell {
@@ -138,11 +141,8 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
       if (RECT) {
         const T x = live ? a.obs[d][i0] : (T)0;
         const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-        int l = axis_partition_point<T>(ax, x) - 1;  // multilinear/rectilinear.rs:363
-        l = l > 0 ? l : 0;
-        l = l < a.n[d] - 2 ? l : a.n[d] - 2;         // rectilinear.rs:365-367
-        const T x0 = ax.g[l];
-        const T x1 = ax.g[l + 1];
+        T x0, x1;
+        const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
         const T step = x1 - x0;
         t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
         loc[d] = l;

@@ -35,11 +35,8 @@ __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const u
       T dt;
       if (RECT) {
         const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
-        loc = axis_partition_point<T>(ax, x) - 1;  // nearest/rectilinear.rs:259
-        loc = loc > 0 ? loc : 0;
-        loc = loc < ax.n - 2 ? loc : ax.n - 2;
-        const T x0 = ax.g[loc];
-        const T x1 = ax.g[loc + 1];
+        T x0, x1;
+        loc = axis_cell<T>(ax, x, &x0, &x1);  // nearest/rectilinear.rs:248-262, :223-224
         const T step = x1 - x0;
         dt = (x - x0) / step;  // rectilinear.rs:223-227
       } else {
