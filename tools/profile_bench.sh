@@ -25,7 +25,7 @@ def counter(dirname, kernel_substr):
     return sum(vals) / len(vals) if vals else None
 res = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    res[c + '_bench_KiB'] = counter('pmc_' + c, 'k_linear3_brick') or counter('pmc_' + c, 'k_linear_regular')
+    res[c + '_bench_KiB'] = counter('pmc_' + c, 'k_linear_brick<double, 3') or counter('pmc_' + c, 'k_linear_regular')
     res[c + '_stream_cal_KiB'] = counter('cal_' + c, 'k_stream')
 # known byte count of the calibration kernel: reads 3 x 8 B, writes 8 B per point, 1e8 points
 P = 100_000_000
