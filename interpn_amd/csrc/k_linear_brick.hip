@@ -14,6 +14,8 @@
 // and every lane finishes its own point with the reference's arithmetic and operation order
 // (leading dimensions are reduced first, exactly as dims 0..N-4 are in the reference's tree,
 // src/multilinear/regular.rs:347-403), so results are bit-identical to the C-order kernels.
+#include <cstdlib>
+
 #include "rect_args.h"
 
 namespace interpn {
@@ -113,7 +115,11 @@ struct LeadReduce<T, 0, FMA> {
   }
 };
 
-template <typename T, int N, bool RECT, bool FMA, int SI, int SJ>
+// PPL = points per lane.  With PPL = 2 a lane owns two consecutive points, so coordinates and
+// results move as 2*sizeof(T)-byte vectors (16 B in f64): the streams then cost the L2 fewer
+// channel-cycles per line (measured -4 % at 64^3, -7 % at 32^3; tools/tune_layout ... w).  Needs all
+// obs/out pointers aligned to 2*sizeof(T); the launcher falls back to PPL = 1 otherwise.
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
   typedef typename LeafVec<T, 2>::type P;
   constexpr int L = N - 3;
@@ -127,59 +133,94 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   const unsigned lane = threadIdx.x;
   const unsigned q = lane & 3;
   const unsigned quad = lane >> 2;
+  typedef T T2 __attribute__((ext_vector_type(2)));
   const size_t nthreads = (size_t)gridDim.x * kBlock;
-  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  const size_t nslots = (a.npts + PPL - 1) / PPL;  // lane slots (PPL points each)
+  const size_t niter = (nslots + nthreads - 1) / nthreads;
   for (size_t it = 0; it < niter; ++it) {
     // Every lane runs every iteration (dead lanes still fetch pieces for their quad).
-    const size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
-    const bool live = i0 < a.npts;
-    T t[N];
-    int loc[N];
-    bool ok = true;
+    const size_t s0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    const size_t i0 = s0 * PPL;
+    T xin[PPL][N];
+    bool live[PPL];
 #pragma unroll
-    for (int d = 0; d < N; ++d) {
-      if (RECT) {
-        const T x = live ? a.obs[d][i0] : (T)0;
-        const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-        T x0, x1;
-        const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
-        const T step = x1 - x0;
-        t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
-        loc[d] = l;
-      } else {
-        const T x = live ? a.obs[d][i0] : a.start[d];
-        T floc;
-        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);          // multilinear/regular.rs:415-418
-        const int l = clamp_loc<T>(floc, a.n[d] - 2);                     // regular.rs:420-422
-        const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);          // regular.rs:334-337
-        t[d] = (x - izl) / a.step[d];                                     // regular.rs:339
-        loc[d] = l;
+    for (int h = 0; h < PPL; ++h) live[h] = i0 + h < a.npts;
+    if (PPL == 2) {
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        T2 v;
+        v.x = RECT ? (T)0 : a.start[d];
+        v.y = v.x;
+        if (live[PPL - 1]) v = *reinterpret_cast<const T2*>(a.obs[d] + i0);
+        else if (live[0]) v.x = a.obs[d][i0];
+        xin[0][d] = v.x;
+        xin[PPL - 1][d] = v.y;
       }
+    } else {
+#pragma unroll
+      for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? a.obs[d][i0] : (RECT ? (T)0 : a.start[d]);
     }
-    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i0);
-    // Offsets of my point's four pieces (lower corner of the leading dims included) -> LDS,
-    // transposed: lane q reads piece q of points 0..3.
-    unsigned lead = 0;
+    T resv[PPL];
 #pragma unroll
-    for (int d = 0; d < L; ++d) lead += (unsigned)loc[d] * a.lead_stride[d];
-    const unsigned bk = (unsigned)loc[N - 1] / (unsigned)SK;
-    const unsigned kpart = bk * (unsigned)BrickGeom<T>::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
+    for (int h = 0; h < PPL; ++h) {
+      T t[N];
+      int loc[N];
+      bool ok = true;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
-    wave_sync();
-    const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
-    const Cell<T> c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
-    // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
-    T r[2];
+      for (int d = 0; d < N; ++d) {
+        const T x = xin[h][d];
+        if (RECT) {
+          const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
+          T x0, x1;
+          const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
+          const T step = x1 - x0;
+          t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
+          loc[d] = l;
+        } else {
+          T floc;
+          ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);          // multilinear/regular.rs:415-418
+          const int l = clamp_loc<T>(floc, a.n[d] - 2);                     // regular.rs:420-422
+          const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);          // regular.rs:334-337
+          t[d] = (x - izl) / a.step[d];                                     // regular.rs:339
+          loc[d] = l;
+        }
+      }
+      if (!RECT && !ok && live[h]) atomicMin(a.first_bad, (unsigned long long)(i0 + h));
+      // Offsets of my point's four pieces (lower corner of the leading dims included) -> LDS,
+      // transposed: lane q reads piece q of points 0..3.
+      unsigned lead = 0;
 #pragma unroll
-    for (int dk = 0; dk < 2; ++dk) {
-      const T c0 = mul_add<FMA>(t[N - 3], c.v[1][0][dk] - c.v[0][0][dk], c.v[0][0][dk]);
-      const T c1 = mul_add<FMA>(t[N - 3], c.v[1][1][dk] - c.v[0][1][dk], c.v[0][1][dk]);
-      r[dk] = mul_add<FMA>(t[N - 2], c1 - c0, c0);
+      for (int d = 0; d < L; ++d) lead += (unsigned)loc[d] * a.lead_stride[d];
+      const unsigned bk = (unsigned)loc[N - 1] / (unsigned)SK;
+      const unsigned kpart = bk * (unsigned)BrickGeom<T>::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
+      wave_sync();
+      const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
+      const Cell<T> c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
+      // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
+      T r[2];
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        const T c0 = mul_add<FMA>(t[N - 3], c.v[1][0][dk] - c.v[0][0][dk], c.v[0][0][dk]);
+        const T c1 = mul_add<FMA>(t[N - 3], c.v[1][1][dk] - c.v[0][1][dk], c.v[0][1][dk]);
+        r[dk] = mul_add<FMA>(t[N - 2], c1 - c0, c0);
+      }
+      resv[h] = mul_add<FMA>(t[N - 1], r[1] - r[0], r[0]);
     }
-    const T res = mul_add<FMA>(t[N - 1], r[1] - r[0], r[0]);
-    if (live) a.out[i0] = res;
+    if (PPL == 2) {
+      if (live[PPL - 1]) {
+        T2 v;
+        v.x = resv[0];
+        v.y = resv[PPL - 1];
+        *reinterpret_cast<T2*>(a.out + i0) = v;
+      } else if (live[0]) {
+        a.out[i0] = resv[0];
+      }
+    } else if (live[0]) {
+      a.out[i0] = resv[0];
+    }
   }
 }
 
@@ -238,13 +279,23 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int N, bool RECT, bool FMA>
+template <typename T, int N, bool RECT, bool FMA, int PPL>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
-  if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1>), dim3(blocks), dim3(kBlock), lds, stream, a);
-  else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2>), dim3(blocks), dim3(kBlock), lds, stream, a);
-  else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
+}
+
+template <typename T, int N, int PPL>
+static hipError_t launch_kind(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, size_t npts, hipStream_t stream) {
+  const unsigned blocks = grid_blocks(npts, PPL, g.cfg);
+  if (g.kind == kRegular)
+    return g.fma ? launch_steps<T, N, false, true, PPL>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, false, false, PPL>(g, a, lds, blocks, stream);
+  return g.fma ? launch_steps<T, N, true, true, PPL>(g, a, lds, blocks, stream)
+               : launch_steps<T, N, true, false, PPL>(g, a, lds, blocks, stream);
 }
 
 template <typename T, int N>
@@ -275,12 +326,15 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
-  const unsigned blocks = grid_blocks(npts, 1, g.cfg);
-  if (g.kind == kRegular)
-    return g.fma ? launch_steps<T, N, false, true>(g, a, lds, blocks, stream)
-                 : launch_steps<T, N, false, false>(g, a, lds, blocks, stream);
-  return g.fma ? launch_steps<T, N, true, true>(g, a, lds, blocks, stream)
-               : launch_steps<T, N, true, false>(g, a, lds, blocks, stream);
+  // Two points per lane (vector coordinate/result accesses) for the 3-D shape when every stream is
+  // aligned to 2*sizeof(T); INTERPN_HIP_PPL=1 forces the scalar form (tuning / testing).
+  if constexpr (N == 3) {
+    bool aligned = (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0;
+    for (int d = 0; d < N; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
+    const char* env = getenv("INTERPN_HIP_PPL");
+    if (aligned && !(env && env[0] == '1')) return launch_kind<T, N, 2>(g, a, lds, npts, stream);
+  }
+  return launch_kind<T, N, 1>(g, a, lds, npts, stream);
 }
 
 template <typename T>

@@ -335,6 +335,34 @@ def test_interpn_helper_contract(oracle):
         interpn_amd.interpn(obs=obs, grids=[x, y], vals=vals.astype(np.int32))
 
 
+@pytest.mark.parametrize("npts", [1, 2, 3, 255, 256, 257, 100_001])
+def test_device_eval_alignment_and_tails(oracle, npts):
+    """3-D multilinear moves two points per lane as 16-B vectors when every stream is 16-B aligned
+    and one point per lane otherwise (k_linear_brick.hip, PPL): device tensors that start on an odd
+    element, odd point counts and single-point batches give the oracle's bits either way."""
+    import torch
+
+    import interpn_amd
+
+    rng = np.random.default_rng(21)
+    dims, starts, steps = [9, 8, 10], np.array([-1.0, 0.0, 2.0]), np.array([0.25, 0.5, 0.1])
+    vals = rng.uniform(-1, 1, 9 * 8 * 10)
+    base = [rng.uniform(starts[d] - 0.2, starts[d] + steps[d] * (dims[d] - 1) + 0.2, npts + 1) for d in range(3)]
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
+    for shift in (0, 1):  # shift = 1: obs/out start on an odd element => only 8-B aligned
+        obs_np = [b[shift:shift + npts] for b in base]
+        want = np.zeros(npts)
+        oracle.linear_regular(dims, starts, steps, vals, [np.ascontiguousarray(o) for o in obs_np], want)
+        dev = [torch.from_numpy(b).cuda()[shift:shift + npts] for b in base]
+        out_full = torch.full((npts + 2,), -5.0, dtype=torch.float64, device="cuda")
+        out = out_full[shift:shift + npts]
+        it.eval_tensors(dev, out)
+        it.finish()
+        assert np.array_equal(out.cpu().numpy(), want)
+        # nothing outside the requested range was written
+        assert float(out_full[shift + npts]) == -5.0 and (shift == 0 or float(out_full[0]) == -5.0)
+
+
 def test_class_eval_on_torch_tensors(oracle):
     """`.eval` of the classes accepts torch CUDA tensors: points never leave the device."""
     import torch

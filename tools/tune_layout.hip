@@ -187,6 +187,64 @@ __global__ void __launch_bounds__(1024) k_stream16(const double2* x, const doubl
   }
 }
 
+
+// Two points per lane: coordinates and results move as 16-B vectors (dwordx4); the quad-cooperative
+// gather is run once per point of the lane.
+template <int SI, int SJ, int SK>
+__global__ void __launch_bounds__(256) k_coop2(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[256 * 80 + 256 * 16];
+  const unsigned lane = threadIdx.x, q = lane & 3, quad = lane >> 2;
+  d2u* lds_piece = reinterpret_cast<d2u*>(lds_raw);
+  unsigned* lds_off = reinterpret_cast<unsigned*>(lds_raw + 256 * 80);
+  const size_t nthreads = (size_t)gridDim.x * 256;
+  const size_t npairs = a.npts / 2;
+  const size_t niter = (npairs + nthreads - 1) / nthreads;
+  typedef double d2a __attribute__((ext_vector_type(2)));
+  for (size_t it = 0; it < niter; ++it) {
+    const size_t j0 = it * nthreads + (size_t)blockIdx.x * 256 + lane;  // pair index
+    const bool live = j0 < npairs;
+    d2a xv[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { xv[d].x = a.start; xv[d].y = a.start; if (live) xv[d] = reinterpret_cast<const d2a*>(a.obs[d])[j0]; }
+    d2a resv;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double t[3]; int loc[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double x = h == 0 ? xv[d].x : xv[d].y;
+        double floc = __builtin_floor((x - a.start) / a.step);
+        floc = floc > 0 ? floc : 0; int l = (int)floc; l = l < a.n - 2 ? l : a.n - 2; loc[d] = l;
+        t[d] = (x - __builtin_fma(a.step, (double)l, a.start)) / a.step;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) lds_off[(quad * 4 + p) * 4 + q] = brick_addr<SI, SJ, SK>(a, loc[0], loc[1], loc[2], p >> 1, p & 1, 0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      uint4 toff = *reinterpret_cast<uint4*>(&lds_off[(quad * 4 + q) * 4]);
+      d2u pc[4];
+      pc[0] = *(const d2u*)(a.vals + toff.x); pc[1] = *(const d2u*)(a.vals + toff.y);
+      pc[2] = *(const d2u*)(a.vals + toff.z); pc[3] = *(const d2u*)(a.vals + toff.w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * 5 + q] = pc[r];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double v[2][2][2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { d2u w = lds_piece[(quad * 4 + q) * 5 + p]; v[p >> 1][p & 1][0] = w.x; v[p >> 1][p & 1][1] = w.y; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double r[2];
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        double c0 = __builtin_fma(t[0], v[1][0][dk] - v[0][0][dk], v[0][0][dk]);
+        double c1 = __builtin_fma(t[0], v[1][1][dk] - v[0][1][dk], v[0][1][dk]);
+        r[dk] = __builtin_fma(t[1], c1 - c0, c0);
+      }
+      const double res = __builtin_fma(t[2], r[1] - r[0], r[0]);
+      if (h == 0) resv.x = res; else resv.y = res;
+    }
+    if (live) reinterpret_cast<d2a*>(a.out)[j0] = resv;
+  }
+}
+
 // Cell-major layout: every cell's 8 corners as 64 contiguous, 64-B aligned bytes (8x the grid):
 // piece p = (di,dj) at cell*8 + p*2.  Quad-cooperative gather as in k_coop.
 template <bool NOSTREAM>
@@ -284,6 +342,28 @@ int main(int argc, char** argv) {
   for (int d = 0; d < 3; ++d) a.obs[d] = dx[d];
   printf("P=%zu grid=%d^3 (%.1f MiB row-major)\n", P, n, G * 8 / 1048576.0);
   const unsigned BLK = 2048 * 2;
+  if (argc > 3 && argv[3][0] == 'w') {  // wide (16-B) coordinate/result accesses, two points per lane
+    a.out = dref;
+    hipLaunchKernelGGL((k_lay<0, 2, 2, 4, LD_PLAIN, false>), dim3(BLK), dim3(256), 0, 0, a); CK(hipDeviceSynchronize());
+    a.out = dout;
+    unsigned nbi, nbj, nbk;
+    std::vector<double> b = make_bricks(hv, n, 1, 2, 3, nbi, nbj, nbk);
+    double* db; CK(hipMalloc(&db, b.size() * 8)); CK(hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice));
+    Args c = a; c.vals = db; c.nbj = nbj; c.nbk = nbk;
+    for (unsigned blk : {1024u, 2048u, 4096u}) {
+      char name[128];
+      snprintf(name, sizeof name, "coop(1,2,3) 1 pt/lane   %u blocks", blk);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<1, 2, 3, false>), dim3(blk), dim3(256), 0, 0, c); }, P);
+      CK(hipMemset(dout, 0, P * 8));
+      snprintf(name, sizeof name, "coop(1,2,3) 2 pts/lane  %u blocks", blk);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop2<1, 2, 3>), dim3(blk), dim3(256), 0, 0, c); }, P);
+    }
+    std::vector<double> ref(1 << 20), got(1 << 20);
+    CK(hipMemcpy(ref.data(), dref, ref.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(got.data(), dout, got.size() * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t q = 0; q < got.size(); ++q) bad += got[q] != ref[q];
+    printf("2 pts/lane mismatches: %zu\n", bad);
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'e') {  // cell-major 64-B layout vs fully overlapped bricks
     a.out = dref;
     hipLaunchKernelGGL((k_lay<0, 2, 2, 4, LD_PLAIN, false>), dim3(BLK), dim3(256), 0, 0, a); CK(hipDeviceSynchronize());
