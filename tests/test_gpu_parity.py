@@ -363,6 +363,39 @@ def test_device_eval_alignment_and_tails(oracle, npts):
         assert float(out_full[shift + npts]) == -5.0 and (shift == 0 or float(out_full[0]) == -5.0)
 
 
+def test_eval_device_is_graph_capturable(oracle):
+    """`interpn_hip_eval_device` enqueues exactly one kernel and performs no allocation, copy or
+    synchronisation, so it can be captured into a hipGraph and replayed on new data."""
+    import torch
+
+    import interpn_amd
+
+    rng = np.random.default_rng(31)
+    dims, starts, steps = [16, 12, 20], np.full(3, -1.0), np.array([2 / 15, 2 / 11, 2 / 19])
+    vals = rng.uniform(-1, 1, 16 * 12 * 20)
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
+    P = 200_000
+    obs = [torch.zeros(P, dtype=torch.float64, device="cuda") for _ in range(3)]
+    out = torch.zeros(P, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        it.eval_tensors(obs, out)  # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        it.eval_tensors(obs, out)
+    for rep in range(3):
+        host = [rng.uniform(-1.1, 1.1, P) for _ in range(3)]
+        for d in range(3):
+            obs[d].copy_(torch.from_numpy(host[d]))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = np.zeros(P)
+        oracle.linear_regular(dims, starts, steps, vals, host, want)
+        assert np.array_equal(out.cpu().numpy(), want), rep
+    it.finish()
+
+
 def test_class_eval_on_torch_tensors(oracle):
     """`.eval` of the classes accepts torch CUDA tensors: points never leave the device."""
     import torch
