@@ -143,11 +143,11 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
 #pragma unroll
     for (int d = 0; d < N; ++d) {
       if constexpr (RECT) {
-        const T x = live ? a.obs[d][i0] : (T)0;
+        const T x = live ? stream_load(a.obs[d] + i0) : (T)0;
         const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
         loc[d] = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
       } else {
-        const T x = live ? a.obs[d][i0] : a.start[d];
+        const T x = live ? stream_load(a.obs[d] + i0) : a.start[d];
         T floc;
         ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
         ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
     wave_sync();
     const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim);
-    if (live) a.out[i0] = res;
+    if (live) stream_store(a.out + i0, res);
   }
 }
 

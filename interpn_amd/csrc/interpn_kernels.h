@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_regular(const RegularArgs<T, 
     for (int u = 0; u < U; ++u) {
       const size_t i = i0 + (size_t)u * nthreads;
 #pragma unroll
-      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? a.obs[d][i] : a.start[d];
+      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? stream_load(a.obs[d] + i) : a.start[d];
     }
     T t[U][N];
     unsigned base[U];
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_regular(const RegularArgs<T, 
       const T y0 = r.v[0];
       const T dy = r.v[1] - y0;
       const T res = mul_add<FMA>(t[u][N - 1], dy, y0);  // regular.rs:396-402
-      if (i < a.npts) a.out[i] = res;
+      if (i < a.npts) stream_store(a.out + i, res);
     }
   }
 }
@@ -139,7 +139,7 @@ __device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a,
     for (int u = 0; u < U; ++u) {
       const size_t i = i0 + (size_t)u * nthreads;
 #pragma unroll
-      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? a.obs[d][i] : (T)0;
+      for (int d = 0; d < N; ++d) x[u][d] = (i < a.npts) ? stream_load(a.obs[d] + i) : (T)0;
     }
     T t[U][N];
     unsigned base[U];
@@ -163,7 +163,7 @@ __device__ __forceinline__ void linear_rectilinear_body(const RectArgs<T, N>& a,
       const T y0 = r.v[0];
       const T dy = r.v[1] - y0;
       const T res = mul_add<FMA>(t[u][N - 1], dy, y0);  // rectilinear.rs:339-344
-      if (i < a.npts) a.out[i] = res;
+      if (i < a.npts) stream_store(a.out + i, res);
     }
   }
 }
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_regular(const RegularArgs<T, N
     bool ok = true;
 #pragma unroll
     for (int d = 0; d < N; ++d) {
-      const T x = a.obs[d][i];
+      const T x = stream_load(a.obs[d] + i);
       T floc;
       ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);  // regular.rs:435-438
       ok &= floc != (T)-9223372036854775808.0;  // `- 1` would overflow isize: the reference panics
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_regular(const RegularArgs<T, N
     if (!ok) atomicMin(a.first_bad, (unsigned long long)i);
     typedef CubicRegularNode<T, FMA> Node;
     Leaf<T, 4> r = CubicTree<T, unsigned, N - 1, CubicDimRegular<T>, Node>::run(a.vals, base, a.stride, dim, Node());
-    a.out[i] = cubic_regular_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]);  // regular.rs:415-421
+    stream_store(a.out + i, cubic_regular_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]));  // regular.rs:415-421
   }
 }
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ void cubic_rectilinear_body(const RectArgs<T, N>& a, 
     }
     typedef CubicRectNode<T, FMA> Node;
     Leaf<T, 4> r = CubicTree<T, unsigned, N - 1, CubicDimRect<T>, Node>::run(a.vals, base, a.stride, dim, Node());
-    a.out[i] = cubic_rect_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]);  // rectilinear.rs:346-355
+    stream_store(a.out + i, cubic_rect_node<FMA, T>(r.v[0], r.v[1], r.v[2], r.v[3], dim[N - 1]));  // rectilinear.rs:346-355
   }
 }
 

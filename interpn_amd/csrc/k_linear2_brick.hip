@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       if (RECT) {
-        const T x = live ? a.obs[d][i0] : (T)0;
+        const T x = live ? stream_load(a.obs[d] + i0) : (T)0;
         const Axis<T> ax = make_axis<T, 2>(a.ax, axis_base, d);
         T x0, x1;
         const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
         t[d] = (x - x0) / step;
         loc[d] = l;
       } else {
-        const T x = live ? a.obs[d][i0] : a.start[d];
+        const T x = live ? stream_load(a.obs[d] + i0) : a.start[d];
         T floc;
         ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
         const int l = clamp_loc<T>(floc, a.n[d] - 2);
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
     const T c0 = mul_add<FMA>(t[0], row1.x - row0.x, row0.x);
     const T c1 = mul_add<FMA>(t[0], row1.y - row0.y, row0.y);
     const T res = mul_add<FMA>(t[1], c1 - c0, c0);
-    if (live) a.out[i0] = res;
+    if (live) stream_store(a.out + i0, res);
   }
 }
 

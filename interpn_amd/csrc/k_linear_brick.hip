@@ -151,14 +151,14 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         T2 v;
         v.x = RECT ? (T)0 : a.start[d];
         v.y = v.x;
-        if (live[PPL - 1]) v = *reinterpret_cast<const T2*>(a.obs[d] + i0);
-        else if (live[0]) v.x = a.obs[d][i0];
+        if (live[PPL - 1]) v = stream_load(reinterpret_cast<const T2*>(a.obs[d] + i0));
+        else if (live[0]) v.x = stream_load(a.obs[d] + i0);
         xin[0][d] = v.x;
         xin[PPL - 1][d] = v.y;
       }
     } else {
 #pragma unroll
-      for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? a.obs[d][i0] : (RECT ? (T)0 : a.start[d]);
+      for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? stream_load(a.obs[d] + i0) : (RECT ? (T)0 : a.start[d]);
     }
     T resv[PPL];
 #pragma unroll
@@ -214,12 +214,12 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         T2 v;
         v.x = resv[0];
         v.y = resv[PPL - 1];
-        *reinterpret_cast<T2*>(a.out + i0) = v;
+        stream_store(reinterpret_cast<T2*>(a.out + i0), v);
       } else if (live[0]) {
-        a.out[i0] = resv[0];
+        stream_store(a.out + i0, resv[0]);
       }
     } else if (live[0]) {
-      a.out[i0] = resv[0];
+      stream_store(a.out + i0, resv[0]);
     }
   }
 }

@@ -30,7 +30,7 @@ __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const u
     bool ok = true;
 #pragma unroll
     for (int d = 0; d < N; ++d) {
-      const T x = a.obs[d][i];
+      const T x = stream_load(a.obs[d] + i);
       int loc;
       T dt;
       if (RECT) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const u
       idx += (unsigned long long)(loc + offset) * a.stride[d];
     }
     if (!RECT && !ok) atomicMin(a.first_bad, (unsigned long long)i);
-    a.out[i] = a.vals[idx];
+    stream_store(a.out + i, a.vals[idx]);
   }
 }
 
