@@ -251,10 +251,12 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     si = env[0] - '0';
     sj = env[1] - '0';
   } else {
-    // Measured on MI355X (tools/sweep_layouts.py, 3-D f64, 16^3 .. 384^3): the fully overlapped
-    // layout (one line per cell) wins at every size — L2-resident, Infinity-Cache-resident and even
-    // HBM-resident tables (random 128-B lines stream from HBM at > 5 TB/s) — except in a narrow band
-    // around an 11 MiB table (64^3), where (1,2) keeps more of the table in the 4 MiB L2.
+    // Measured on MI355X (tools/sweep_layouts.py, 3-D f64, 24^3 .. 384^3, non-temporal streams):
+    // the fully overlapped layout (one line per cell) wins while its table is L2-sized (<= 6 MiB)
+    // and again once even the (2,2) table is far beyond the 4 MiB L2 (Infinity-Cache- or
+    // HBM-resident: random 128-B lines stream at > 5 TB/s, so fewer lines per point is all that
+    // counts).  In between (56^3 .. 80^3 in f64) the layouts that stay mostly L2-resident win:
+    // (1,2) while it fits, then (2,2).
     const size_t MiB = (size_t)1 << 20;
     unsigned nb[3];
     size_t b11, b12, b22;
@@ -266,8 +268,9 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     const size_t esz = g.dtype == kF64 ? 8 : 4;
     auto fits = [&](size_t b) { return b <= free_b / 4 && b <= ((size_t)16 << 30) && b / esz < 0xFFFFFFFFull; };
     if (fits(b11)) {
-      if (b11 > 6 * MiB && b11 <= 16 * MiB && b12 <= 8 * MiB) { si = 1; sj = 2; }
-      else { si = 1; sj = 1; }
+      if (b11 <= 6 * MiB || b22 > 6 * MiB) { si = 1; sj = 1; }
+      else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
+      else { si = 2; sj = 2; }
     } else if (fits(b12)) { si = 1; sj = 2; }
     else if (fits(b22)) { si = 2; sj = 2; }
     else return INTERPN_HIP_OK;  // stay on the C-order kernel

@@ -22,7 +22,7 @@ for _ in range(5):
     a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); ms.append(a.elapsed_time(b))
 print(sorted(ms)[2])
 ''' % ROOT
-for n in (16, 32, 40, 48, 64, 80, 96, 128, 192, 256, 384):
+for n in (16, 32, 48, 56, 64, 72, 80, 96, 128, 192, 256):
     row = {}
     for lay in ("off", "22", "12", "11", ""):
         env = dict(os.environ); env["INTERPN_HIP_BRICKS"] = lay
