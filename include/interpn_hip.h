@@ -32,6 +32,14 @@
  *   - Numerics follow the reference's `fma` cargo feature ON (what every published wheel is
  *     built with, pyproject.toml:72); interpn_hip_set_fma(0) selects the non-fused flavour
  *     (plain `cargo test`).  Results are bit-identical to the Rust code of the same flavour.
+ *   - Memory: besides the C-ordered `vals`, a handle may keep a second, re-laid copy of the grid
+ *     (cache-line bricks for multilinear N = 2..6, 4 x 4 tiles for multicubic N = 2..4; up to 16x
+ *     the grid, bounded by a quarter of the free device memory).  Environment knobs, read at handle
+ *     creation / launch, for tuning and testing only:
+ *       INTERPN_HIP_BRICKS=off|11|12|22 (linear) |44|24|22|14|11 (cubic)   force / disable a layout
+ *       INTERPN_HIP_BLOCKS_PER_CU=n     workgroups per CU the launch grid is sized for (default 8)
+ *       INTERPN_HIP_PPL=1               one point per lane in the 3-D multilinear kernel
+ *       INTERPN_HIP_FORCE_GENERIC=1     route every evaluation through the runtime-N kernel
  *   - Thread safety: all functions are re-entrant; concurrent evaluation on one handle is
  *     allowed (the grid is read-only), but the sticky first-bad-index word of a handle is
  *     shared by its in-flight device evaluations.

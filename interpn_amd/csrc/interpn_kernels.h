@@ -1,13 +1,17 @@
 // Kernels and launchers (templates).  Instantiated per method/grid kind in the *.hip files
 // next to this header so that the translation units build in parallel.
 //
-// Kernel families
+// Kernel families in this header (C-ordered grid):
 //   k_linear_regular<T,N,FMA,U>      N = 1..6   multilinear::regular      (flattened arm)
 //   k_linear_rectilinear<T,N,FMA,U>  N = 1..6   multilinear::rectilinear  (flattened arm)
 //   k_cubic_regular<T,N,FMA>         N = 1..4   multicubic::regular       (flattened arm)
 //   k_cubic_rectilinear<T,N,FMA>     N = 1..4   multicubic::rectilinear   (flattened arm)
 //   k_generic<T,METHOD,KIND,FMA>     runtime N <= 8, 64-bit indexing: the recursive arms
 //                                    (linear N = 7,8; cubic N = 5..8) and grids >= 4 GiB.
+// The kernels that carry the benchmarked shapes live next to it and read a re-laid copy of the
+// grid: k_linear_brick.hip (multilinear N = 3..6), k_linear2_brick.hip (N = 2), cubic_brick.h
+// (multicubic N = 2..4), k_nearest.hip.  The C-order kernels here remain the path for N = 1,
+// for grids whose re-laid copy does not fit, and when INTERPN_HIP_BRICKS=off.
 //
 // Launch shape: 256-thread workgroups (4 waves, one per SIMD), a grid of a few workgroups
 // per CU that strides over the observation points; U points per lane and iteration keep
