@@ -252,12 +252,22 @@ __global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ v
   }
 }
 
+// Bricks needed per dimension (cell indices run 0 .. n-2):
+//   step 1:      brick = cell index                      -> n-1 bricks
+//   step 2:      brick = i>>1, +1 when i is odd (i+1 spills into the next brick) -> (n-1)/2 + 1
+//   step KW-1 (k): the pair never leaves its brick row   -> (n-2)/(KW-1) + 1
+static unsigned bricks_along(int n, int step) {
+  if (step == 1) return (unsigned)(n - 1);
+  if (step == 2) return (unsigned)((n - 1) / 2 + 1);
+  return (unsigned)((n - 2) / step + 1);
+}
+
 void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes) {
   const int N = g.ndims;
   const int kw = g.dtype == kF64 ? 4 : 8;
-  nb[0] = (unsigned)((g.n[N - 3] - 2) / si + 2);
-  nb[1] = (unsigned)((g.n[N - 2] - 2) / sj + 2);
-  nb[2] = (unsigned)((g.n[N - 1] - 2) / (kw - 1) + 2);
+  nb[0] = bricks_along(g.n[N - 3], si);
+  nb[1] = bricks_along(g.n[N - 2], sj);
+  nb[2] = bricks_along(g.n[N - 1], kw - 1);
   size_t lead = 1;
   for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
   *bytes = lead * nb[0] * nb[1] * nb[2] * 128;
