@@ -207,7 +207,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "kernel": "interpn::k_linear3_brick<false,true,SI,SJ> (bricked grid, quad-cooperative gather)",
+                "kernel": "interpn::k_linear_brick<double,3,false,true,1,2,2> (bricked grid copy, quad-cooperative gather, 2 points/lane)",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_point": BYTES_PER_POINT,
             },

@@ -77,6 +77,16 @@ __global__ void __launch_bounds__(256) k_stream(const double* x, const double* y
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += nthreads) o[i] = x[i] + y[i] + z[i];
 }
 
+// the same stream with the product kernels' access pattern: 16 B per lane, non-temporal
+typedef double d2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_stream16nt(const d2* x, const d2* y, const d2* z, d2* o, size_t n2) {
+  const size_t nthreads = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += nthreads) {
+    d2 a = __builtin_nontemporal_load(x + i), b = __builtin_nontemporal_load(y + i), c = __builtin_nontemporal_load(z + i);
+    __builtin_nontemporal_store(a + b + c, o + i);
+  }
+}
+
 static double time_it(const char* name, std::function<void()> fn, size_t P, int reps = 7) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   fn(); CK(hipDeviceSynchronize());
@@ -115,6 +125,9 @@ int main(int argc, char** argv) {
 
   time_it("stream x+y+z (2048 blk)", [&] { hipLaunchKernelGGL(k_stream, dim3(2048), dim3(256), 0, 0, dx[0], dx[1], dx[2], dout, P); }, P);
   time_it("stream x+y+z (8192 blk)", [&] { hipLaunchKernelGGL(k_stream, dim3(8192), dim3(256), 0, 0, dx[0], dx[1], dx[2], dout, P); }, P);
+
+  time_it("stream16nt x+y+z (2048 blk)", [&] { hipLaunchKernelGGL(k_stream16nt, dim3(2048), dim3(256), 0, 0, (const d2*)dx[0], (const d2*)dx[1], (const d2*)dx[2], (d2*)dout, P / 2); }, P);
+  if (argc > 3) return 0;  // calibration only
 
 #define RUN(U, MODE, BLOCK, BLOCKS, label) time_it(label, [&] { hipLaunchKernelGGL((k_var<U, MODE, BLOCK>), dim3(BLOCKS), dim3(BLOCK), 0, 0, a, ri, ri, ri); }, P)
   RUN(2, 0, 256, 2048, "U2 full            2048x256");
