@@ -298,7 +298,11 @@ int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t 
   g.cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* env = getenv("INTERPN_HIP_BLOCKS_PER_CU")) {
     int v = atoi(env);
-    if (v >= 1 && v <= 64) g.cfg.blocks_per_cu = v;
+    if (v >= 1 && v <= 65536) g.cfg.blocks_per_cu = v;
+  }
+  if (const char* env = getenv("INTERPN_HIP_ITERS_PER_BLOCK")) {
+    int v = atoi(env);
+    if (v >= 1 && v <= 65536) g.cfg.iters_per_block = v;
   }
   g.nvals = nvals;
   if (vals_mem == INTERPN_HIP_MEM_DEVICE) {
@@ -604,7 +608,7 @@ int interpn_hip_ndims(const interpn_hip_interp* h) { return h ? h->desc.ndims : 
 int interpn_hip_device(const interpn_hip_interp* h) { return h ? h->device : -1; }
 
 int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
-  if (!h || blocks_per_cu < 1 || blocks_per_cu > 64) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (!h || blocks_per_cu < 1 || blocks_per_cu > 65536) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   h->desc.cfg.blocks_per_cu = blocks_per_cu;
   return INTERPN_HIP_OK;
 }

@@ -13,7 +13,8 @@ enum DType : int { kF64 = 0, kF32 = 1 };
 
 struct LaunchConfig {
   int num_cus = 256;       // MI355X: 8 XCDs x 32 CUs
-  int blocks_per_cu = 8;   // 256-thread workgroups resident per CU that the grid is sized for
+  int blocks_per_cu = 8;   // 256-thread workgroups resident per CU that a persistent grid is sized for
+  int iters_per_block = 0; // brick kernels: 256-wide iterations per workgroup (0 = the kernel's default)
 };
 
 struct GridDesc {
@@ -46,6 +47,18 @@ struct GridDesc {
   unsigned brick_nb[3] = {0, 0, 0};
   LaunchConfig cfg;
 };
+
+// Brick kernels cover the batch with ONE pass of small workgroups (each owning `iters` consecutive
+// 256-lane rows) instead of a persistent grid-stride loop: the dispatcher then balances the XCDs
+// dynamically (measured on 1e8 points, 64^3: 1.36 -> 1.29 ms).  Rectilinear kernels stage their
+// axes per workgroup and want a few rows each to amortise that.
+inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane) {
+  unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (g.kind == kRegular ? 1u : 8u);
+  // keep the grid below 2^30 workgroups
+  const size_t rows = (npts + (size_t)256 * points_per_lane - 1) / ((size_t)256 * points_per_lane);
+  while ((rows + iters - 1) / iters > (1u << 30)) iters *= 2;
+  return iters;
+}
 
 constexpr unsigned long long kNoBadIndexHost = ~0ull;  // value of the device first-bad-index word when no point failed
 

@@ -39,6 +39,7 @@ struct BrickArgs {
   AxisArgs<T, N> ax;
   unsigned lead_stride[N > 3 ? N - 3 : 1];  // elements of the brick table per unit of a leading index
   unsigned nbj, nbk;
+  unsigned iters;  // kBlock-wide iterations per workgroup
 };
 
 template <typename T, int SI, int SJ>
@@ -136,12 +137,14 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   const unsigned q = lane & 3;
   const unsigned quad = lane >> 2;
   typedef T T2 __attribute__((ext_vector_type(2)));
-  const size_t nthreads = (size_t)gridDim.x * kBlock;
-  const size_t nslots = (a.npts + PPL - 1) / PPL;  // lane slots (PPL points each)
-  const size_t niter = (nslots + nthreads - 1) / nthreads;
-  for (size_t it = 0; it < niter; ++it) {
+  // Block b owns the contiguous lane slots [b, b+1) * iters * kBlock (PPL points per slot); the
+  // grid covers the batch once, so the hardware dispatcher balances the load across XCDs.
+  const size_t nslots = (a.npts + PPL - 1) / PPL;
+  const size_t first = (size_t)blockIdx.x * a.iters * kBlock;
+  for (unsigned it = 0; it < a.iters; ++it) {
     // Every lane runs every iteration (dead lanes still fetch pieces for their quad).
-    const size_t s0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    const size_t s0 = first + (size_t)it * kBlock + lane;
+    if (s0 - lane >= nslots) break;  // block-uniform
     const size_t i0 = s0 * PPL;
     T xin[PPL][N];
     bool live[PPL];
@@ -301,8 +304,11 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
 }
 
 template <typename T, int N, int PPL>
-static hipError_t launch_kind(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, size_t npts, hipStream_t stream) {
-  const unsigned blocks = grid_blocks(npts, PPL, g.cfg);
+static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t npts, hipStream_t stream) {
+  a.iters = brick_iters(g, npts, PPL);
+  const size_t nslots = (npts + PPL - 1) / PPL;
+  const size_t per_block = (size_t)kBlock * a.iters;
+  const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);
   if (g.kind == kRegular)
     return g.fma ? launch_steps<T, N, false, true, PPL>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, false, false, PPL>(g, a, lds, blocks, stream);
