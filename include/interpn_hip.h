@@ -177,6 +177,19 @@ int interpn_hip_device(const interpn_hip_interp* h);
 int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const size_t* obs_lens,
                           size_t nobs, void* out, size_t nout);
 
+/* Single-process multi-GPU form of `interpn_hip_eval_host`: cuts the observation index into
+ * `nhandles` contiguous ranges (the first nout % nhandles ranges one point longer; SURVEY.md
+ * section 8(e)) and evaluates range r with handles[r] on that handle's device, one host thread per
+ * handle, no device-to-device traffic.  The handles must be distinct and describe the same
+ * interpolator (create one per device from the same grid).  Status and checks as
+ * `interpn_hip_eval_host`.  On INTERPN_HIP_ERR_UNREPRESENTABLE `*first_bad_index` (optional)
+ * receives the global index i of the first failing point; out[0..i) holds the reference's
+ * results, out[i..] is unspecified here (ranges behind the failing one ran concurrently),
+ * where the one-handle form leaves it untouched. */
+int interpn_hip_eval_host_sharded(interpn_hip_interp* const* handles, size_t nhandles,
+                                  const void* const* obs, const size_t* obs_lens, size_t nobs,
+                                  void* out, size_t nout, uint64_t* first_bad_index);
+
 /* Evaluate on device arrays (asynchronous on `stream`, a hipStream_t; NULL = default stream).
  * `obs` is a HOST array of `nobs` DEVICE pointers, each to `npoints` elements; `out` is a device
  * pointer to `npoints` elements.  Returns as soon as the kernel is enqueued. */

@@ -16,11 +16,12 @@ import numpy as np
 from . import _lib, raw
 from .classes import (MulticubicRectilinear, MulticubicRegular, MultilinearRectilinear, MultilinearRegular,
                       NearestRectilinear, NearestRegular)
-from .handle import Interpolator
+from .handle import Interpolator, eval_host_sharded
 
 __version__ = "0.1.0"
 
 __all__ = [
+    "eval_host_sharded",
     "__version__",
     "raw",
     "interpn",

@@ -108,6 +108,8 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_ndims.argtypes = [c_void_p]
     lib.interpn_hip_device.argtypes = [c_void_p]
     lib.interpn_hip_eval_host.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_size_t, c_void_p, c_size_t]
+    lib.interpn_hip_eval_host_sharded.argtypes = [POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_size_t),
+                                                  c_size_t, c_void_p, c_size_t, POINTER(c_uint64)]
     lib.interpn_hip_eval_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p]
     lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
     lib.interpn_hip_set_blocks_per_cu.argtypes = [c_void_p, c_int]

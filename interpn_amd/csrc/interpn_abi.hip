@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/interpn_hip.h"
@@ -657,18 +658,13 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   return INTERPN_HIP_ERR_UNREPRESENTABLE;
 }
 
-int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const size_t* obs_lens, size_t nobs,
-                          void* out, size_t nout) {
-  if (!h || (!obs && nobs) || (!obs_lens && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
-  int st = validate_obs(h->desc, obs_lens, nobs, nout);
-  if (st) return st;
-  if (nout == 0) return INTERPN_HIP_OK;
-  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
-  for (size_t i = 0; i < nobs; ++i)
-    if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+// Chunked host evaluation; `*bad_index` (optional) receives the local index of the first failing
+// point when the status is INTERPN_HIP_ERR_UNREPRESENTABLE.
+static int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t nout,
+                          size_t* bad_index) {
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
-  st = ensure_workspace(h, nout);
+  int st = ensure_workspace(h, nout);
   if (st) return st;
   const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
   const int nd = h->desc.ndims;
@@ -692,9 +688,74 @@ int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const s
     if (bad != kNoBadIndexHost) {
       HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(unsigned long long), s));
       HIP_TRY(hipStreamSynchronize(s));
+      if (bad_index) *bad_index = begin + (size_t)bad;
       return INTERPN_HIP_ERR_UNREPRESENTABLE;
     }
     HIP_TRY(hipStreamSynchronize(s));
+  }
+  return INTERPN_HIP_OK;
+}
+
+int interpn_hip_eval_host(interpn_hip_interp* h, const void* const* obs, const size_t* obs_lens, size_t nobs,
+                          void* out, size_t nout) {
+  if (!h || (!obs && nobs) || (!obs_lens && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  int st = validate_obs(h->desc, obs_lens, nobs, nout);
+  if (st) return st;
+  if (nout == 0) return INTERPN_HIP_OK;
+  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < nobs; ++i)
+    if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  return eval_host_impl(h, obs, nobs, out, nout, nullptr);
+}
+
+// Single-process multi-GPU form of `.interp(obs, out)`: the observation index is cut into
+// `nhandles` contiguous ranges (the first nout % nhandles ranges one point longer), range r is
+// evaluated by handles[r] on that handle's device from its own host thread.  The handles must
+// describe the same interpolator (same method/kind/dtype/ndims); the grid was replicated when
+// they were created.  No device-to-device traffic.
+int interpn_hip_eval_host_sharded(interpn_hip_interp* const* handles, size_t nhandles, const void* const* obs,
+                                  const size_t* obs_lens, size_t nobs, void* out, size_t nout,
+                                  uint64_t* first_bad_index) {
+  if (!handles || nhandles == 0 || nhandles > 1024 || (!obs && nobs) || (!obs_lens && nobs))
+    return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t r = 0; r < nhandles; ++r) {
+    if (!handles[r]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+    const GridDesc &a = handles[0]->desc, &b = handles[r]->desc;
+    if (a.method != b.method || a.kind != b.kind || a.dtype != b.dtype || a.ndims != b.ndims)
+      return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+    for (size_t q = 0; q < r; ++q)
+      if (handles[q] == handles[r]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;  // a handle has one workspace
+  }
+  int st = validate_obs(handles[0]->desc, obs_lens, nobs, nout);
+  if (st) return st;
+  if (nout == 0) return INTERPN_HIP_OK;
+  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < nobs; ++i)
+    if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  const size_t elem = handles[0]->desc.dtype == kF64 ? 8 : 4;
+  const size_t base = nout / nhandles, extra = nout % nhandles;
+  std::vector<int> status(nhandles, INTERPN_HIP_OK);
+  std::vector<size_t> bad(nhandles, 0), lo(nhandles, 0), cnt(nhandles, 0);
+  std::vector<std::thread> workers;
+  workers.reserve(nhandles);
+  for (size_t r = 0; r < nhandles; ++r) {
+    lo[r] = r * base + (r < extra ? r : extra);
+    cnt[r] = base + (r < extra ? 1 : 0);
+    if (cnt[r] == 0) continue;
+    workers.emplace_back([&, r] {
+      const void* sub[8];
+      for (size_t d = 0; d < nobs; ++d) sub[d] = (const char*)obs[d] + lo[r] * elem;
+      status[r] = eval_host_impl(handles[r], sub, nobs, (char*)out + lo[r] * elem, cnt[r], &bad[r]);
+    });
+  }
+  for (auto& w : workers) w.join();
+  // Ranges ascend with r, so the first failing range holds the globally first failing point.
+  for (size_t r = 0; r < nhandles; ++r) {
+    if (status[r] == INTERPN_HIP_ERR_UNREPRESENTABLE) {
+      if (first_bad_index) *first_bad_index = (uint64_t)(lo[r] + bad[r]);
+      return status[r];
+    }
+    if (status[r] != INTERPN_HIP_OK) return status[r];
   }
   return INTERPN_HIP_OK;
 }

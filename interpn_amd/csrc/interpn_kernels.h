@@ -437,4 +437,13 @@ inline unsigned grid_blocks(size_t npts, int points_per_thread, const LaunchConf
   return (unsigned)(want < cap ? want : cap);
 }
 
+// One pass over the batch (every workgroup runs its grid-stride loop once): the dispatcher
+// balances the XCDs dynamically.  For kernels without per-workgroup set-up (regular grids).
+inline unsigned one_pass_blocks(size_t npts, int points_per_thread) {
+  size_t per_block = (size_t)kBlock * points_per_thread;
+  size_t want = (npts + per_block - 1) / per_block;
+  if (want < 1) want = 1;
+  return (unsigned)(want < ((size_t)1 << 30) ? want : ((size_t)1 << 30));
+}
+
 }  // namespace interpn

@@ -163,3 +163,32 @@ class Interpolator:
             self.close()
         except Exception:
             pass
+
+
+def eval_host_sharded(interps, obs, out: np.ndarray) -> np.ndarray:
+    """Single-process multi-GPU `.interp(obs, out)`: contiguous ranges of the observation index,
+    one per interpolator in `interps` (create one per device from the same grid), evaluated
+    concurrently (`interpn_hip_eval_host_sharded`).  On "Unrepresentable coordinate value" the
+    AssertionError carries `first_bad_index` (global)."""
+    interps = list(interps)
+    if not interps:
+        raise ValueError("eval_host_sharded needs at least one interpolator")
+    lib = _lib.load()
+    dtype = interps[0].dtype
+    out = _check_arr("out", out, dtype, writable=True)
+    optr, olen, nobs, _keep = _slice_of_slices("obs", obs, dtype)
+    vp = (c_void_p * max(nobs, 1))()
+    for i in range(nobs):
+        vp[i] = ctypes.cast(optr[i], c_void_p)
+    hs = (c_void_p * len(interps))()
+    for i, it in enumerate(interps):
+        hs[i] = it._h
+    bad = c_uint64(0)
+    st = lib.interpn_hip_eval_host_sharded(hs, len(interps), vp, olen, nobs, out.ctypes.data_as(c_void_p), out.size,
+                                           ctypes.byref(bad))
+    if st == _lib.ERR_UNREPRESENTABLE:
+        err = AssertionError(_lib.strerror(st))
+        err.first_bad_index = bad.value
+        raise err
+    _lib.raise_for_status(st)
+    return out

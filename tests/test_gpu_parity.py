@@ -255,6 +255,60 @@ def test_eval_host_multi_chunk(oracle):
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
+@pytest.mark.parametrize("nhandles", [1, 2, 3, 5])
+@pytest.mark.parametrize("method,kind", [("linear", "regular"), ("linear", "rectilinear"), ("cubic", "regular")])
+def test_eval_host_sharded(oracle, method, kind, nhandles):
+    """Single-process multi-GPU entry (`interpn_hip_eval_host_sharded`):
+    contiguous ranges of the observation index, one handle each (all on this box's one GPU),
+    bit-identical to the one-handle result; uneven split and ranges shorter than a row."""
+    import interpn_amd
+
+    for nobs in (10_007, 3):
+        case = synthetic_case(method, kind, 3, [9, 8, 11], nobs, 21, np.float64, specials=nobs > 64)
+        want = run_oracle(oracle, case, True)
+        hs = []
+        for _ in range(nhandles):
+            if kind == "regular":
+                hs.append(interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals))
+            else:
+                hs.append(interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals))
+        try:
+            got = interpn_amd.eval_host_sharded(hs, case.obs, np.zeros(nobs))
+        finally:
+            for h in hs:
+                h.close()
+        assert_parity(case, got, want)
+
+
+def test_eval_host_sharded_first_bad_index(oracle):
+    """The first failing point over all ranges is reported with its global index; everything in
+    front of it holds the reference's results (multilinear/regular.rs:277-280)."""
+    import interpn_amd
+
+    case = synthetic_case("linear", "regular", 2, [8, 9], 9_000, 5, np.float64, specials=False)
+    k = 4_321  # inside the 2nd of 3 ranges
+    case.obs[1][k] = np.nan
+    case.obs[0][8_000] = np.inf  # a failure in a later range must not win
+    want = np.full(9_000, -123.0)
+    with pytest.raises(AssertionError) as eo:
+        oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, case.obs, want)
+    assert eo.value.first_bad == k
+    hs = [interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals) for _ in range(3)]
+    got = np.full(9_000, -123.0)
+    try:
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            interpn_amd.eval_host_sharded(hs, case.obs, got)
+        assert ei.value.first_bad_index == k
+        assert np.array_equal(got[:k], want[:k])
+        with pytest.raises(ValueError):
+            interpn_amd.eval_host_sharded([hs[0], hs[0]], case.obs, got)  # one workspace per handle
+        with pytest.raises(AssertionError, match="Dimension mismatch"):
+            interpn_amd.eval_host_sharded(hs, case.obs[:1], got)
+    finally:
+        for h in hs:
+            h.close()
+
+
 def test_classes_and_helper(oracle):
     """`.new(...).eval(obs)` and `interpn()` — the three API levels of
     test/test_multilinear_regular.py:46-93 give the same (oracle-identical) result."""
