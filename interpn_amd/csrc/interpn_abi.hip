@@ -6,14 +6,17 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/interpn_hip.h"
@@ -71,7 +74,148 @@ class DeviceGuard {
   bool changed_ = false;
 };
 
+// ---------------------------------------------------------------------------
+// Device-memory pool.  The one-shot entry points rebuild the interpolator on every call, as the
+// reference does (multilinear/regular.rs:65-71); hipMalloc/hipFree, stream and pinned-memory
+// creation would dominate small calls (measured 600 us per call against 50 us with a resident
+// handle), so freed blocks, streams and pinned status words are kept per device and reused.
+// Blocks are returned only after the device has drained (interpn_hip_destroy synchronises, as
+// hipFree would).  INTERPN_HIP_POOL_MB caps the cached bytes per device (default 1024, 0 = off).
+constexpr int kMaxPoolDevices = 64;
+
+size_t pool_size_class(size_t bytes) {
+  if (bytes < 256) return 256;
+  const int top = 63 - __builtin_clzll((unsigned long long)bytes);
+  const size_t quantum = (size_t)1 << (top > 3 ? top - 3 : 0);  // 8 classes per octave: <= 12.5 % slack
+  return (bytes + quantum - 1) / quantum * quantum;
+}
+
+struct DevPool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;                     // block -> class size
+  std::unordered_map<size_t, std::vector<void*>> free_blocks;  // class size -> cached blocks
+  size_t cached_bytes = 0;
+  struct Kit { hipStream_t stream; unsigned long long* flag_host; };
+  std::vector<Kit> kits;
+};
+
+DevPool& dev_pool(int device) {
+  static DevPool pools[kMaxPoolDevices];
+  return pools[device >= 0 && device < kMaxPoolDevices ? device : 0];
+}
+
+size_t pool_cap_bytes() {
+  static const size_t cap = [] {
+    const char* env = getenv("INTERPN_HIP_POOL_MB");
+    const long long mb = env ? atoll(env) : 1024;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+  }();
+  return cap;
+}
+
+// The current device must be `device`.
+hipError_t pool_alloc(int device, void** out, size_t bytes) {
+  DevPool& pool = dev_pool(device);
+  const size_t cls = pool_size_class(bytes);
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto it = pool.free_blocks.find(cls);
+    if (it != pool.free_blocks.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      pool.cached_bytes -= cls;
+      pool.live[*out] = cls;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, cls);
+  if (e != hipSuccess) {
+    // out of memory: drop everything cached and retry once
+    (void)hipGetLastError();
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lk(pool.mu);
+      for (auto& kv : pool.free_blocks) {
+        for (void* b : kv.second) drop.push_back(b);
+        kv.second.clear();
+      }
+      pool.cached_bytes = 0;
+    }
+    for (void* b : drop) (void)hipFree(b);
+    e = hipMalloc(out, cls);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(pool.mu);
+  pool.live[*out] = cls;
+  return hipSuccess;
+}
+
+// Only for blocks no in-flight work still touches.
+void pool_free(int device, void* p) {
+  if (!p) return;
+  DevPool& pool = dev_pool(device);
+  size_t cls = 0;
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto it = pool.live.find(p);
+    if (it != pool.live.end()) {
+      cls = it->second;
+      pool.live.erase(it);
+      if (pool.cached_bytes + cls <= pool_cap_bytes()) {
+        pool.free_blocks[cls].push_back(p);
+        pool.cached_bytes += cls;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
+hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** flag_host) {
+  DevPool& pool = dev_pool(device);
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (!pool.kits.empty()) {
+      *stream = pool.kits.back().stream;
+      *flag_host = pool.kits.back().flag_host;
+      pool.kits.pop_back();
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipHostMalloc((void**)flag_host, sizeof(unsigned long long), hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  e = hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { (void)hipHostFree(*flag_host); *flag_host = nullptr; }
+  return e;
+}
+
+void pool_return_kit(int device, hipStream_t stream, unsigned long long* flag_host) {
+  DevPool& pool = dev_pool(device);
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (pool.kits.size() < 16 && pool_cap_bytes() > 0) {
+      pool.kits.push_back({stream, flag_host});
+      return;
+    }
+  }
+  (void)hipStreamDestroy(stream);
+  (void)hipHostFree(flag_host);
+}
+
+int device_num_cus(int device) {
+  static std::atomic<int> cached[kMaxPoolDevices];
+  if (device >= 0 && device < kMaxPoolDevices && cached[device].load() > 0) return cached[device].load();
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = 256;
+  }
+  if (device >= 0 && device < kMaxPoolDevices) cached[device].store(n);
+  return n;
+}
+
 }  // namespace
+
 
 struct interpn_hip_interp {
   GridDesc desc;
@@ -80,12 +224,16 @@ struct interpn_hip_interp {
   void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
   void* bricks_owned = nullptr; // bricked copy of vals (3-D multilinear f64)
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
-  // Host-evaluation workspace (lazily allocated, reused across calls)
-  size_t ws_points = 0;
-  void* ws_obs = nullptr;   // ndims * ws_points elements
-  void* ws_out = nullptr;   // ws_points elements
-  unsigned long long* ws_flag_host = nullptr;  // pinned
-  hipStream_t ws_stream = nullptr;
+  // Host-evaluation workspace (lazily allocated, reused across calls): two pipeline lanes so
+  // that the upload of one chunk overlaps the download of the previous one.
+  struct HostLane {
+    size_t points = 0;
+    void* obs = nullptr;                       // ndims * points elements (device)
+    void* out = nullptr;                       // points elements (device)
+    unsigned long long* flag_dev = nullptr;    // first failing index of the chunk in flight
+    unsigned long long* flag_host = nullptr;   // pinned
+    hipStream_t stream = nullptr;
+  } lane[2];
 };
 
 namespace {
@@ -217,7 +365,7 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   g.brick_step[1] = cand[best][1];
   cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], g.brick_nb, &bytes);
   g.brick_nb[2] = 1;
-  hipError_t e = hipMalloc(&h->bricks_owned, bytes);
+  hipError_t e = pool_alloc(h->device, &h->bricks_owned, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
   HIP_TRY(build_cubic_tiles(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -237,7 +385,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     size_t free2 = 0, total2 = 0;
     if (hipMemGetInfo(&free2, &total2) != hipSuccess) free2 = (size_t)8 << 30;
     if (bytes2 > free2 / 4 || bytes2 / (g.dtype == kF64 ? 8 : 4) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
-    hipError_t e2 = hipMalloc(&h->bricks_owned, bytes2);
+    hipError_t e2 = pool_alloc(h->device, &h->bricks_owned, bytes2);
     if (e2 != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
     HIP_TRY(build_bricks2(g, h->bricks_owned, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
@@ -284,7 +432,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) return INTERPN_HIP_OK;
   g.brick_step[0] = si;
   g.brick_step[1] = sj;
-  hipError_t e = hipMalloc(&h->bricks_owned, bytes);
+  hipError_t e = pool_alloc(h->device, &h->bricks_owned, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
   HIP_TRY(build_bricks(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -294,9 +442,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
 
 int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t elem, int vals_mem) {
   GridDesc& g = h->desc;
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-  g.cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g.cfg.num_cus = device_num_cus(h->device);
   if (const char* env = getenv("INTERPN_HIP_BLOCKS_PER_CU")) {
     int v = atoi(env);
     if (v >= 1 && v <= 65536) g.cfg.blocks_per_cu = v;
@@ -309,12 +455,13 @@ int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t 
   if (vals_mem == INTERPN_HIP_MEM_DEVICE) {
     g.vals = vals;
   } else {
-    HIP_TRY(hipMalloc(&h->vals_owned, nvals * elem));
+    HIP_TRY(pool_alloc(h->device, &h->vals_owned, nvals * elem));
     HIP_TRY(hipMemcpy(h->vals_owned, vals, nvals * elem, hipMemcpyHostToDevice));
     g.vals = h->vals_owned;
   }
-  HIP_TRY(hipMalloc((void**)&h->first_bad, sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(h->first_bad, 0xFF, sizeof(unsigned long long)));
+  HIP_TRY(pool_alloc(h->device, (void**)&h->first_bad, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(unsigned long long), nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   int st = maybe_build_bricks(h);
   if (st) return st;
   return INTERPN_HIP_OK;
@@ -419,8 +566,8 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     }
   }
   g.axis_image_bytes = (unsigned)bytes;
-  hipError_t e = hipMalloc(&h->grids_owned, bytes);
-  if (e == hipSuccess) e = hipMemset(h->grids_owned, 0, bytes);
+  hipError_t e = pool_alloc(h->device, &h->grids_owned, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(h->grids_owned, 0, bytes, nullptr);
   if (e != hipSuccess) {
     interpn_hip_destroy(h);
     return hip_fail(e);
@@ -499,18 +646,21 @@ hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size
 // (8 dims x 8 B x 4 Mi = 256 MiB worst case) while each kernel launch still fills the chip.
 constexpr size_t kHostChunkPoints = (size_t)4 << 20;
 
-int ensure_workspace(interpn_hip_interp* h, size_t points) {
-  if (points > kHostChunkPoints) points = kHostChunkPoints;
-  if (h->ws_points >= points && h->ws_obs) return INTERPN_HIP_OK;
+int ensure_lane(interpn_hip_interp* h, int which, size_t points) {
+  interpn_hip_interp::HostLane& l = h->lane[which];
+  if (l.points >= points && l.obs) return INTERPN_HIP_OK;
   const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
-  if (h->ws_obs) { (void)hipFree(h->ws_obs); h->ws_obs = nullptr; }
-  if (h->ws_out) { (void)hipFree(h->ws_out); h->ws_out = nullptr; }
-  h->ws_points = 0;
-  HIP_TRY(hipMalloc(&h->ws_obs, (size_t)h->desc.ndims * points * elem));
-  HIP_TRY(hipMalloc(&h->ws_out, points * elem));
-  if (!h->ws_flag_host) HIP_TRY(hipHostMalloc((void**)&h->ws_flag_host, sizeof(unsigned long long), hipHostMallocDefault));
-  if (!h->ws_stream) HIP_TRY(hipStreamCreateWithFlags(&h->ws_stream, hipStreamNonBlocking));
-  h->ws_points = points;
+  if (l.obs) { HIP_TRY(hipStreamSynchronize(l.stream)); pool_free(h->device, l.obs); l.obs = nullptr; }
+  if (l.out) { pool_free(h->device, l.out); l.out = nullptr; }
+  l.points = 0;
+  if (!l.stream) HIP_TRY(pool_take_kit(h->device, &l.stream, &l.flag_host));
+  HIP_TRY(pool_alloc(h->device, &l.obs, (size_t)h->desc.ndims * points * elem));
+  HIP_TRY(pool_alloc(h->device, &l.out, points * elem));
+  if (!l.flag_dev) {
+    HIP_TRY(pool_alloc(h->device, (void**)&l.flag_dev, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));
+  }
+  l.points = points;
   return INTERPN_HIP_OK;
 }
 
@@ -527,9 +677,9 @@ int check_bounds_host(const T* lo, const T* hi, size_t ndims, const T* const* ob
   size_t maxlen = 0;
   for (size_t d = 0; d < ndims; ++d) maxlen = obs_lens[d] > maxlen ? obs_lens[d] : maxlen;
   const size_t chunk = maxlen < kHostChunkPoints ? (maxlen ? maxlen : 1) : kHostChunkPoints;
-  hipError_t e = hipMalloc((void**)&flags, sizeof(unsigned) * (ndims ? ndims : 1));
-  if (e == hipSuccess) e = hipMemset(flags, 0, sizeof(unsigned) * (ndims ? ndims : 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&buf, chunk * sizeof(T));
+  hipError_t e = pool_alloc(dev, (void**)&flags, sizeof(unsigned) * (ndims ? ndims : 1));
+  if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(unsigned) * (ndims ? ndims : 1), nullptr);
+  if (e == hipSuccess) e = pool_alloc(dev, (void**)&buf, chunk * sizeof(T));
   for (size_t d = 0; d < ndims && e == hipSuccess; ++d) {
     if (obs_lens[d] && !obs[d]) { e = hipErrorInvalidValue; break; }
     for (size_t begin = 0; begin < obs_lens[d] && e == hipSuccess; begin += chunk) {
@@ -541,8 +691,9 @@ int check_bounds_host(const T* lo, const T* hi, size_t ndims, const T* const* ob
   }
   std::vector<unsigned> host(ndims ? ndims : 1, 0);
   if (e == hipSuccess) e = hipMemcpy(host.data(), flags, sizeof(unsigned) * (ndims ? ndims : 1), hipMemcpyDeviceToHost);
-  if (buf) (void)hipFree(buf);
-  if (flags) (void)hipFree(flags);
+  (void)hipStreamSynchronize(nullptr);
+  pool_free(dev, buf);
+  pool_free(dev, flags);
   if (e != hipSuccess) return hip_fail(e);
   for (size_t d = 0; d < ndims; ++d) out[d] = host[d] ? 1 : 0;
   return INTERPN_HIP_OK;
@@ -617,14 +768,19 @@ int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
 void interpn_hip_destroy(interpn_hip_interp* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
-  if (h->ws_stream) (void)hipStreamDestroy(h->ws_stream);
-  if (h->ws_flag_host) (void)hipHostFree(h->ws_flag_host);
-  if (h->ws_obs) (void)hipFree(h->ws_obs);
-  if (h->ws_out) (void)hipFree(h->ws_out);
-  if (h->first_bad) (void)hipFree(h->first_bad);
-  if (h->grids_owned) (void)hipFree(h->grids_owned);
-  if (h->bricks_owned) (void)hipFree(h->bricks_owned);
-  if (h->vals_owned) (void)hipFree(h->vals_owned);
+  // hipFree would wait for the device; blocks go back to the pool only once nothing in flight
+  // (e.g. an eval_device launch on a caller's stream) can still touch them.
+  (void)hipDeviceSynchronize();
+  for (auto& l : h->lane) {
+    if (l.stream) pool_return_kit(h->device, l.stream, l.flag_host);
+    pool_free(h->device, l.flag_dev);
+    pool_free(h->device, l.obs);
+    pool_free(h->device, l.out);
+  }
+  pool_free(h->device, h->first_bad);
+  pool_free(h->device, h->grids_owned);
+  pool_free(h->device, h->bricks_owned);
+  pool_free(h->device, h->vals_owned);
   delete h;
 }
 
@@ -658,40 +814,121 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   return INTERPN_HIP_ERR_UNREPRESENTABLE;
 }
 
-// Chunked host evaluation; `*bad_index` (optional) receives the local index of the first failing
-// point when the status is INTERPN_HIP_ERR_UNREPRESENTABLE.
+// Chunked host evaluation.  Chunk c is handled by lane c % 2: upload, kernel, status word,
+// download.  With more than one chunk the second lane runs on a helper thread, so that lane A's
+// download overlaps lane B's next upload (the two directions use different DMA engines).  The
+// reference's loop stops at the first failing point — out[0..i) written, out[i..] untouched
+// (multilinear/regular.rs:277-280) — so a lane writes chunk c only once every chunk in front of
+// it is known to be clean.  `*bad_index` (optional) receives the index of the first failing point
+// when the status is INTERPN_HIP_ERR_UNREPRESENTABLE.
+struct HostPipeline {
+  interpn_hip_interp* h;
+  const void* const* obs;
+  void* out;
+  size_t nout, chunk, nchunks;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t checked[2] = {0, 0};      // chunks whose status word has been read, per lane
+  size_t fail_chunk = ~(size_t)0;  // lowest failing chunk so far
+  size_t fail_index = 0;           // global index of its first failing point
+  int error = INTERPN_HIP_OK;      // first HIP failure of any lane
+
+  int run_lane(int which) {
+    DeviceGuard guard(h->device);
+    if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+    const interpn_hip_interp::HostLane& l = h->lane[which];
+    const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
+    const int nd = h->desc.ndims;
+    const void* dev_obs[8];
+    for (size_t c = (size_t)which; c < nchunks; c += 2) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (fail_chunk < c || error) break;
+      }
+      const size_t begin = c * chunk;
+      const size_t count = (nout - begin) < chunk ? (nout - begin) : chunk;
+      for (int d = 0; d < nd; ++d) {
+        char* dst = (char*)l.obs + (size_t)d * l.points * elem;
+        HIP_TRY(hipMemcpyAsync(dst, (const char*)obs[d] + begin * elem, count * elem, hipMemcpyHostToDevice, l.stream));
+        dev_obs[d] = dst;
+      }
+      HIP_TRY(launch_any(h->desc, dev_obs, l.out, count, l.flag_dev, l.stream));
+      HIP_TRY(hipMemcpyAsync(l.flag_host, l.flag_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream));
+      HIP_TRY(hipStreamSynchronize(l.stream));
+      const unsigned long long bad = *l.flag_host;
+      if (bad != kNoBadIndexHost) HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));
+      size_t good = count;
+      bool stop = false;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (bad != kNoBadIndexHost && c < fail_chunk) {
+          fail_chunk = c;
+          fail_index = begin + (size_t)bad;
+        }
+        checked[which] = c / 2 + 1;
+        cv.notify_all();
+        // every chunk in front of c must have reported before c may touch `out`
+        const size_t need = (c + 1) / 2;  // chunks of the other lane in front of c
+        cv.wait(lk, [&] { return checked[1 - which] >= need || error != INTERPN_HIP_OK; });
+        if (error) break;
+        if (fail_chunk < c) break;
+        if (fail_chunk == c) {
+          good = (size_t)bad;
+          stop = true;
+        }
+      }
+      if (good) HIP_TRY(hipMemcpyAsync((char*)out + begin * elem, l.out, good * elem, hipMemcpyDeviceToHost, l.stream));
+      HIP_TRY(hipStreamSynchronize(l.stream));
+      if (stop) break;
+    }
+    return INTERPN_HIP_OK;
+  }
+
+  // A lane that fails (HIP error) must release the other one.
+  void lane_main(int which) {
+    const int st = run_lane(which);
+    std::lock_guard<std::mutex> lk(mu);
+    if (st != INTERPN_HIP_OK && error == INTERPN_HIP_OK) error = st;
+    checked[which] = ~(size_t)0;
+    cv.notify_all();
+  }
+};
+
+// Points per pipeline chunk: one chunk when the batch is small, else 2 Mi-point chunks.
+constexpr size_t kPipelineChunkPoints = (size_t)2 << 20;
+
 static int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t nout,
                           size_t* bad_index) {
+  (void)nobs;
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
-  int st = ensure_workspace(h, nout);
+  HostPipeline p;
+  p.h = h;
+  p.obs = obs;
+  p.out = out;
+  p.nout = nout;
+  p.chunk = nout <= kPipelineChunkPoints ? nout : kPipelineChunkPoints;
+  if (const char* env = getenv("INTERPN_HIP_HOST_CHUNK")) {  // testing: force small chunks
+    const long long v = atoll(env);
+    if (v >= 1) p.chunk = (size_t)v < nout ? (size_t)v : nout;
+  }
+  p.nchunks = (nout + p.chunk - 1) / p.chunk;
+  int st = ensure_lane(h, 0, p.chunk);
   if (st) return st;
-  const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
-  const int nd = h->desc.ndims;
-  hipStream_t s = h->ws_stream;
-  const void* dev_obs[8];
-  for (size_t begin = 0; begin < nout; begin += h->ws_points) {
-    const size_t count = (nout - begin) < h->ws_points ? (nout - begin) : h->ws_points;
-    for (int d = 0; d < nd; ++d) {
-      char* dst = (char*)h->ws_obs + (size_t)d * h->ws_points * elem;
-      HIP_TRY(hipMemcpyAsync(dst, (const char*)obs[d] + begin * elem, count * elem, hipMemcpyHostToDevice, s));
-      dev_obs[d] = dst;
-    }
-    HIP_TRY(launch_any(h->desc, dev_obs, h->ws_out, count, h->first_bad, s));
-    HIP_TRY(hipMemcpyAsync(h->ws_flag_host, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const unsigned long long bad = *h->ws_flag_host;
-    // The reference's loop stops at the first failing point: out[0..i) written, out[i..] untouched
-    // (multilinear/regular.rs:277-280).
-    const size_t good = bad == kNoBadIndexHost ? count : (size_t)bad;
-    if (good) HIP_TRY(hipMemcpyAsync((char*)out + begin * elem, h->ws_out, good * elem, hipMemcpyDeviceToHost, s));
-    if (bad != kNoBadIndexHost) {
-      HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(unsigned long long), s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (bad_index) *bad_index = begin + (size_t)bad;
-      return INTERPN_HIP_ERR_UNREPRESENTABLE;
-    }
-    HIP_TRY(hipStreamSynchronize(s));
+  if (p.nchunks > 1) {
+    st = ensure_lane(h, 1, p.chunk);
+    if (st) return st;
+    std::thread helper([&p] { p.lane_main(1); });
+    p.lane_main(0);
+    helper.join();
+  } else {
+    p.checked[1] = ~(size_t)0;
+    p.lane_main(0);
+  }
+  if (p.error) return p.error;
+  if (p.fail_chunk != ~(size_t)0) {
+    if (bad_index) *bad_index = p.fail_index;
+    return INTERPN_HIP_ERR_UNREPRESENTABLE;
   }
   return INTERPN_HIP_OK;
 }

@@ -255,6 +255,38 @@ def test_eval_host_multi_chunk(oracle):
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
+@pytest.mark.parametrize("chunk", [1000, 777, 4999, 5000])
+@pytest.mark.parametrize("k", [0, 999, 1000, 4321, 9999])
+def test_host_pipeline_abort_semantics(oracle, monkeypatch, chunk, k):
+    """The two-lane host pipeline (upload of chunk c+1 overlapping the download of chunk c) keeps
+    the reference's contract at every chunk seam: out[0..k) written, out[k..] untouched, also when
+    later chunks (of either lane) fail as well."""
+    from interpn_amd import raw
+
+    monkeypatch.setenv("INTERPN_HIP_HOST_CHUNK", str(chunk))
+    case = synthetic_case("linear", "regular", 2, [8, 9], 10_000, 5, np.float64, specials=False)
+    case.obs[1][k] = np.nan
+    for later in (k + 1, k + chunk, k + 2 * chunk + 3, 9_998):
+        if k < later < 10_000:
+            case.obs[0][later] = np.inf
+    want = np.full(10_000, -123.0)
+    with pytest.raises(AssertionError) as eo:
+        oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, case.obs, want)
+    assert eo.value.first_bad == k
+    got = np.full(10_000, -123.0)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+        raw.interpn_linear_regular_f64(case.dims, case.starts, case.steps, case.vals, case.obs, got)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("chunk", [1, 333, 4096])
+def test_host_pipeline_many_chunks(oracle, monkeypatch, chunk):
+    monkeypatch.setenv("INTERPN_HIP_HOST_CHUNK", str(chunk))
+    nobs = 50 if chunk == 1 else 20_011
+    case = synthetic_case("cubic", "rectilinear", 3, [6, 7, 5], nobs, 13, np.float64, specials=False)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
 @pytest.mark.parametrize("nhandles", [1, 2, 3, 5])
 @pytest.mark.parametrize("method,kind", [("linear", "regular"), ("linear", "rectilinear"), ("cubic", "regular")])
 def test_eval_host_sharded(oracle, method, kind, nhandles):
