@@ -37,9 +37,13 @@
  *     the grid, bounded by a quarter of the free device memory).  Environment knobs, read at handle
  *     creation / launch, for tuning and testing only:
  *       INTERPN_HIP_BRICKS=off|11|12|22 (linear) |44|24|22|14|11 (cubic)   force / disable a layout
- *       INTERPN_HIP_BLOCKS_PER_CU=n     workgroups per CU the launch grid is sized for (default 8)
+ *       INTERPN_HIP_BLOCKS_PER_CU=n     workgroups per CU a persistent launch grid is sized for (default 8)
+ *       INTERPN_HIP_ITERS_PER_BLOCK=n   256-lane rows per workgroup of the one-pass brick kernels
  *       INTERPN_HIP_PPL=1               one point per lane in the 3-D multilinear kernel
  *       INTERPN_HIP_FORCE_GENERIC=1     route every evaluation through the runtime-N kernel
+ *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (default 2 Mi)
+ *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
+ *                                       (default 1024; 0 = release everything at destroy)
  *   - Thread safety: all functions are re-entrant; concurrent evaluation on one handle is
  *     allowed (the grid is read-only), but the sticky first-bad-index word of a handle is
  *     shared by its in-flight device evaluations.
