@@ -1,5 +1,7 @@
 // Runtime-N kernels: the recursive arms of the reference's `interpn` dispatch
 // (multilinear N = 7,8; multicubic N = 5..8) and grids too large for 32-bit indexing.
+#include <cstdlib>
+
 #include "interpn_kernels.h"
 
 namespace interpn {
@@ -37,7 +39,32 @@ static hipError_t launch_mk(const GridDesc& g, const T* const* obs, T* out, size
     }
   }
   const unsigned blocks = grid_blocks(npts, 1, g.cfg);
-  hipLaunchKernelGGL((k_generic<T, METHOD, KIND, FMA>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  // Compile-time-N form for the dimension counts the reference's recursive arms serve;
+  // INTERPN_HIP_GENERIC_RUNTIME=1 keeps the runtime-N form (testing).
+  const char* env = getenv("INTERPN_HIP_GENERIC_RUNTIME");
+  const bool runtime_n = env && env[0] == '1';
+  // Row-vector form (FP trees side by side) where its FP x larger register footprint still fits
+  // the 256 architectural VGPRs; beyond that the compiler spills into AGPRs, which measured
+  // slower (cubic rectilinear N >= 6 in f64) and, for f64 cubic regular N = 8, gave wrong
+  // results on ROCm 7.2 — those shapes keep the one-tree form.  INTERPN_HIP_GENERIC_VEC=0|1
+  // overrides (testing).
+  bool vec = true;
+  if (METHOD == kCubic) {
+    const bool f32 = sizeof(T) == 4;
+    vec = KIND == kRegular ? (g.ndims <= 7 || f32) : (g.ndims == 5 || (f32 && g.ndims == 6));
+  }
+  if (const char* venv = getenv("INTERPN_HIP_GENERIC_VEC")) vec = venv[0] != '0';
+#define GO_N(NN)                                                                                                   \
+  do {                                                                                                             \
+    if (vec) hipLaunchKernelGGL((k_generic_n<T, METHOD, KIND, FMA, NN, true>), dim3(blocks), dim3(kBlock), 0, stream, a);  \
+    else hipLaunchKernelGGL((k_generic_n<T, METHOD, KIND, FMA, NN, false>), dim3(blocks), dim3(kBlock), 0, stream, a);     \
+  } while (0)
+  if (!runtime_n && g.ndims == 8) GO_N(8);
+  else if (!runtime_n && g.ndims == 7) GO_N(7);
+  else if (!runtime_n && METHOD == kCubic && g.ndims == 6) GO_N(6);
+  else if (!runtime_n && METHOD == kCubic && g.ndims == 5) GO_N(5);
+  else hipLaunchKernelGGL((k_generic<T, METHOD, KIND, FMA>), dim3(blocks), dim3(kBlock), 0, stream, a);
+#undef GO_N
   return hipGetLastError();
 }
 

@@ -61,14 +61,34 @@ def test_cubic_random(oracle, kind, n, linearize, dtype):
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("form", ["static", "runtime"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
-@pytest.mark.parametrize("method,n", [("linear", 7), ("linear", 8), ("cubic", 5), ("cubic", 6)])
-def test_recursive_arms(oracle, method, kind, n):
-    """N = 7,8 (linear) and 5,6 (cubic) take the reference's recursive arm, with its own FMA
-    sites (regular_recursive.rs:310-313; rectilinear_recursive.rs:467,527)."""
+@pytest.mark.parametrize("method,n", [("linear", 7), ("linear", 8), ("cubic", 5), ("cubic", 6), ("cubic", 7)])
+def test_recursive_arms(oracle, monkeypatch, method, kind, n, linearize, form, dtype):
+    """N = 7,8 (linear) and 5..8 (cubic) take the reference's recursive arm, with its own FMA
+    sites (regular_recursive.rs:310-313; rectilinear_recursive.rs:467,527).  Served by the
+    compile-time-N vertex loop (k_generic_n); the runtime-N kernel must agree bit for bit."""
+    if method == "linear" and linearize:
+        pytest.skip("linearize_extrapolation is a cubic argument")
+    if form == "runtime":
+        monkeypatch.setenv("INTERPN_HIP_GENERIC_RUNTIME", "1")
     m = 2 if method == "linear" else 4
     axis = [m + (d % 2) for d in range(n)]
-    case = synthetic_case(method, kind, n, axis, 3001, 300 + n, np.float64, linearize=True, extrap=0.3)
+    nobs = 3001
+    case = synthetic_case(method, kind, n, axis, nobs, 300 + n, dtype, linearize=linearize, extrap=0.3)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_recursive_arm_cubic_8d(oracle, kind, linearize, dtype):
+    """The largest shape the reference dispatches (multicubic N = 8: 65 536 grid reads per point);
+    30 % of the coordinates extrapolate, so every saturation case meets every level."""
+    case = synthetic_case("cubic", kind, 8, [4] * 8, 601, 77, dtype, linearize=linearize, extrap=0.3,
+                          specials=False)
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
