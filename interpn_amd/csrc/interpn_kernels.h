@@ -6,16 +6,18 @@
 //   k_linear_rectilinear<T,N,FMA,U>  N = 1..6   multilinear::rectilinear  (flattened arm)
 //   k_cubic_regular<T,N,FMA>         N = 1..4   multicubic::regular       (flattened arm)
 //   k_cubic_rectilinear<T,N,FMA>     N = 1..4   multicubic::rectilinear   (flattened arm)
-//   k_generic<T,METHOD,KIND,FMA>     runtime N <= 8, 64-bit indexing: the recursive arms
-//                                    (linear N = 7,8; cubic N = 5..8) and grids >= 4 GiB.
+//   k_generic_n<T,METHOD,KIND,FMA,N,VEC>  the recursive arms (linear N = 7,8; cubic N = 5..8)
+//   k_generic<T,METHOD,KIND,FMA>     runtime N <= 8, 64-bit indexing: grids of 2^32 elements and
+//                                    more, and the reference form the static-N kernel is tested against.
 // The kernels that carry the benchmarked shapes live next to it and read a re-laid copy of the
 // grid: k_linear_brick.hip (multilinear N = 3..6), k_linear2_brick.hip (N = 2), cubic_brick.h
 // (multicubic N = 2..4), k_nearest.hip.  The C-order kernels here remain the path for N = 1,
 // for grids whose re-laid copy does not fit, and when INTERPN_HIP_BRICKS=off.
 //
-// Launch shape: 256-thread workgroups (4 waves, one per SIMD), a grid of a few workgroups
-// per CU that strides over the observation points; U points per lane and iteration keep
-// several independent gathers in flight per wave.
+// Launch shape: 256-thread workgroups (4 waves, one per SIMD).  The C-order kernels run a grid of
+// a few workgroups per CU that strides over the observation points (U points per lane and
+// iteration keep several independent gathers in flight per wave); the brick kernels cover the
+// batch in one pass of small workgroups (interpn_host.h::brick_iters).
 #pragma once
 
 #include "interpn_device.h"
