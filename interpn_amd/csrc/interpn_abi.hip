@@ -97,6 +97,7 @@ struct DevPool {
   size_t cached_bytes = 0;
   struct Kit { hipStream_t stream; unsigned long long* flag_host; };
   std::vector<Kit> kits;
+  std::vector<unsigned long long*> pinned_words;
 };
 
 DevPool& dev_pool(int device) {
@@ -202,6 +203,32 @@ void pool_return_kit(int device, hipStream_t stream, unsigned long long* flag_ho
   (void)hipHostFree(flag_host);
 }
 
+hipError_t pool_take_pinned_word(int device, unsigned long long** word) {
+  DevPool& pool = dev_pool(device);
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (!pool.pinned_words.empty()) {
+      *word = pool.pinned_words.back();
+      pool.pinned_words.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipHostMalloc((void**)word, sizeof(unsigned long long), hipHostMallocDefault);
+}
+
+void pool_return_pinned_word(int device, unsigned long long* word) {
+  if (!word) return;
+  DevPool& pool = dev_pool(device);
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (pool.pinned_words.size() < 64 && pool_cap_bytes() > 0) {
+      pool.pinned_words.push_back(word);
+      return;
+    }
+  }
+  (void)hipHostFree(word);
+}
+
 int device_num_cus(int device) {
   static std::atomic<int> cached[kMaxPoolDevices];
   if (device >= 0 && device < kMaxPoolDevices && cached[device].load() > 0) return cached[device].load();
@@ -224,6 +251,8 @@ struct interpn_hip_interp {
   void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
   void* bricks_owned = nullptr; // bricked copy of vals (3-D multilinear f64)
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
+  unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
+  std::mutex finish_mu;
   // Host-evaluation workspace (lazily allocated, reused across calls): two pipeline lanes so
   // that the upload of one chunk overlaps the download of the previous one.
   struct HostLane {
@@ -778,6 +807,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
     pool_free(h->device, l.out);
   }
   pool_free(h->device, h->first_bad);
+  pool_return_pinned_word(h->device, h->finish_word);
   pool_free(h->device, h->grids_owned);
   pool_free(h->device, h->bricks_owned);
   pool_free(h->device, h->vals_owned);
@@ -804,9 +834,12 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  unsigned long long word = kNoBadIndexHost;
-  HIP_TRY(hipMemcpyAsync(&word, h->first_bad, sizeof(word), hipMemcpyDeviceToHost, s));
+  // The status word lands in pinned memory: a plain DMA behind the kernel, no staging copy.
+  std::lock_guard<std::mutex> lk(h->finish_mu);
+  if (!h->finish_word) HIP_TRY(pool_take_pinned_word(h->device, &h->finish_word));
+  HIP_TRY(hipMemcpyAsync(h->finish_word, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  const unsigned long long word = *h->finish_word;
   if (word == kNoBadIndexHost) return INTERPN_HIP_OK;
   HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(word), s));
   HIP_TRY(hipStreamSynchronize(s));
