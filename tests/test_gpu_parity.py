@@ -582,3 +582,14 @@ def test_device_tensors_full_size_properties(oracle):
     it2.finish()
     exact = 0.5 * obs[0] - 1.25 * obs[1] + 2.0 * obs[2] + 0.75
     assert float((out2 - exact).abs().max()) < 1e-12
+
+
+def test_differential_fuzz_short(oracle):
+    """A fixed-seed slice of tools/fuzz_parity.py (random method / kind / N / axis sizes / dtype /
+    layout and scheduling knobs / special coordinates): every case bit-identical to the oracle.
+    The long form (7 minutes, 76 890 cases, 0 differences) is run by hand."""
+    from tools.fuzz_parity import run
+
+    cases, failures = run(budget=12.0, seed=20261003, max_cases=1500)
+    assert cases > 100
+    assert failures == 0

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Differential fuzz: random (method, kind, N, axis sizes, dtype, linearize, layout knobs, batch
+size, special coordinates) through the C ABI against the CPU oracle, bit for bit.
+    python tools/fuzz_parity.py [seconds=120] [seed=0]
+Prints one line per failure and a summary; exit code 1 if anything differed."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle
+from tests.helpers import run_hip_raw, run_oracle, synthetic_case
+
+KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
+         "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK")
+LAYOUTS_LIN = [None, "off", "11", "12", "22"]
+LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
+
+
+def run(budget: float, seed: int, max_cases: int = 0):
+    """Returns (cases, failures)."""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n_cases = n_fail = 0
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    try:
+        while time.time() < t_end and (max_cases == 0 or n_cases < max_cases):
+            method = rng.choice(["linear", "cubic", "nearest"], p=[0.45, 0.4, 0.15])
+            kind = rng.choice(["regular", "rectilinear"])
+            fp = 4 if method == "cubic" else 2
+            nmax = 6 if method == "nearest" else 8
+            N = int(rng.integers(1, nmax + 1))
+            # keep the grid and the oracle's work bounded
+            cap = 2_000_000
+            axis = []
+            for d in range(N):
+                hi = max(fp, int(round(cap ** (1.0 / N))))
+                axis.append(int(rng.integers(fp, min(hi, 70) + 1)))
+            while np.prod(axis) > cap:
+                axis[int(np.argmax(axis))] = max(fp, axis[int(np.argmax(axis))] // 2)
+            work_per_pt = fp ** N
+            nobs = int(min(200_000, max(1, 3_000_000 // work_per_pt)) * rng.uniform(0.05, 1.0)) + int(rng.integers(0, 5))
+            dtype = np.float64 if rng.random() < 0.6 else np.float32
+            linearize = bool(rng.integers(0, 2))
+            extrap = float(rng.choice([0.0, 0.05, 0.3, 2.0]))
+            env = {}
+            if method == "linear":
+                lay = LAYOUTS_LIN[int(rng.integers(0, len(LAYOUTS_LIN)))]
+            elif method == "cubic":
+                lay = LAYOUTS_CUB[int(rng.integers(0, len(LAYOUTS_CUB)))]
+            else:
+                lay = None
+            if lay: env["INTERPN_HIP_BRICKS"] = lay
+            if rng.random() < 0.15: env["INTERPN_HIP_PPL"] = "1"
+            if rng.random() < 0.1: env["INTERPN_HIP_FORCE_GENERIC"] = "1"
+            if rng.random() < 0.1: env["INTERPN_HIP_GENERIC_RUNTIME"] = "1"
+            if rng.random() < 0.2: env["INTERPN_HIP_HOST_CHUNK"] = str(int(rng.integers(1, max(2, nobs))))
+            if rng.random() < 0.2: env["INTERPN_HIP_ITERS_PER_BLOCK"] = str(int(rng.choice([1, 2, 3, 8, 64])))
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            case = synthetic_case(method, kind, N, axis, nobs, int(rng.integers(0, 2**31)), dtype, linearize=linearize,
+                                  extrap=extrap, specials=bool(rng.integers(0, 2)))
+            if kind == "rectilinear" and rng.random() < 0.3:
+                # inject NaN / inf / huge coordinates: rectilinear never errors, results must still match
+                for _ in range(3):
+                    case.obs[int(rng.integers(0, N))][int(rng.integers(0, nobs))] = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30])
+            try:
+                want = run_oracle(pyoracle, case, True)
+                got = run_hip_raw(case)
+                same = np.array_equal(got, want, equal_nan=True)
+            except Exception as e:  # noqa: BLE001
+                same = False
+                got = want = None
+                print("EXC", repr(e))
+            n_cases += 1
+            if not same:
+                n_fail += 1
+                nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))) if got is not None else -1
+                print(f"FAIL method={method} kind={kind} N={N} axis={axis} nobs={nobs} dtype={np.dtype(dtype).name} "
+                      f"linearize={linearize} extrap={extrap} env={env} nbad={nbad}", flush=True)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    return n_cases, n_fail
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    n_cases, n_fail = run(budget, seed)
+    print(f"fuzz: {n_cases} cases, {n_fail} failures, seed {seed}, {budget:.0f} s")
+    sys.exit(1 if n_fail else 0)
