@@ -6,9 +6,10 @@ from __future__ import annotations
 import numpy as np
 
 
-def run_oracle(oracle, case, fma=True, dtype=None):
+def run_oracle(oracle, case, fma=True, dtype=None, out=None):
     dtype = dtype or case.vals.dtype
-    out = np.zeros(case.obs[0].size, dtype=dtype)
+    if out is None:
+        out = np.zeros(case.obs[0].size, dtype=dtype)
     if case.method == "nearest" and case.kind == "regular":
         oracle.nearest_regular(case.dims, case.starts, case.steps, case.vals, case.obs, out, fma=fma)
     elif case.method == "nearest":
@@ -24,14 +25,15 @@ def run_oracle(oracle, case, fma=True, dtype=None):
     return out
 
 
-def run_hip_raw(case, dtype=None):
+def run_hip_raw(case, dtype=None, out=None):
     """Through the reference-named raw functions -> C ABI one-shot entry points."""
     from interpn_amd import raw
 
     dtype = np.dtype(dtype or case.vals.dtype)
     sfx = "f64" if dtype == np.float64 else "f32"
     cv = lambda a: np.ascontiguousarray(a, dtype=dtype)
-    out = np.zeros(case.obs[0].size, dtype=dtype)
+    if out is None:
+        out = np.zeros(case.obs[0].size, dtype=dtype)
     obs = [cv(o) for o in case.obs]
     if case.method == "nearest" and case.kind == "regular":
         getattr(raw, f"interpn_nearest_regular_{sfx}")(case.dims, cv(case.starts), cv(case.steps), cv(case.vals), obs, out)

@@ -64,20 +64,34 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 # inject NaN / inf / huge coordinates: rectilinear never errors, results must still match
                 for _ in range(3):
                     case.obs[int(rng.integers(0, N))][int(rng.integers(0, nobs))] = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30])
+            inject = kind == "regular" and rng.random() < 0.25
+            if inject:
+                # regular grids abort at the first unrepresentable coordinate: same error, same
+                # prefix written, rest of `out` untouched (host entry points)
+                for _ in range(int(rng.integers(1, 4))):
+                    case.obs[int(rng.integers(0, N))][int(rng.integers(0, nobs))] = rng.choice([np.nan, np.inf, -np.inf])
+            want = np.full(nobs, -777.0, dtype=dtype)
+            got = np.full(nobs, -777.0, dtype=dtype)
+            err_o = err_g = None
             try:
-                want = run_oracle(pyoracle, case, True)
-                got = run_hip_raw(case)
-                same = np.array_equal(got, want, equal_nan=True)
+                run_oracle(pyoracle, case, True, out=want)
+            except AssertionError as e:
+                err_o = str(e)
+            try:
+                run_hip_raw(case, out=got)
+            except AssertionError as e:
+                err_g = str(e)
             except Exception as e:  # noqa: BLE001
-                same = False
-                got = want = None
-                print("EXC", repr(e))
+                err_g = "EXC " + repr(e)
+            same = err_o == err_g and np.array_equal(got, want, equal_nan=True)
+            if inject and err_o is None:
+                same = False  # the injection must have been seen
             n_cases += 1
             if not same:
                 n_fail += 1
-                nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want))))) if got is not None else -1
+                nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want)))))
                 print(f"FAIL method={method} kind={kind} N={N} axis={axis} nobs={nobs} dtype={np.dtype(dtype).name} "
-                      f"linearize={linearize} extrap={extrap} env={env} nbad={nbad}", flush=True)
+                      f"linearize={linearize} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
     finally:
         for k, v in saved.items():
             os.environ.pop(k, None)
