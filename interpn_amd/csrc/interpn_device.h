@@ -130,6 +130,23 @@ __device__ __forceinline__ int partition_point_lt(GridPtr g, int n, T x) {
   return base + ((g[base] < x) ? 1 : 0);
 }
 
+// The same probe sequence on an axis of at most 64 coordinates held one per lane (`greg` =
+// g[lane]); probes are cross-lane reads (ds_bpermute): no LDS memory, hence none of the bank
+// conflicts random 8-byte gathers on a tiny axis image suffer (they cost the rectilinear kernel
+// ~0.3 ms per 1e8 points).  Must be called with the whole wave active.
+template <typename T>
+__device__ __forceinline__ int partition_point_lt_lanes(T greg, int n, T x) {
+  int size = n;
+  int base = 0;
+  while (size > 1) {  // trip count depends on n only
+    const int half = size >> 1;
+    const int mid = base + half;
+    base = (__shfl(greg, mid) < x) ? mid : base;
+    size -= half;
+  }
+  return base + ((__shfl(greg, base) < x) ? 1 : 0);
+}
+
 // Rectilinear axis as the kernels see it: coordinates plus (for strictly increasing, finite
 // axes) a bucket table that brackets the bisection.  tab[b] = number of coordinates whose own
 // bucket index is < b, so for a query x in bucket b the answer lies in [tab[b], tab[b+1]].

@@ -52,8 +52,8 @@ struct GridDesc {
 // 256-lane rows) instead of a persistent grid-stride loop: the dispatcher then balances the XCDs
 // dynamically (measured on 1e8 points, 64^3: 1.36 -> 1.29 ms).  Rectilinear kernels stage their
 // axes per workgroup and want a few rows each to amortise that.
-inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane) {
-  unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (g.kind == kRegular ? 1u : 8u);
+inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane, bool per_block_setup) {
+  unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (per_block_setup ? 8u : 1u);
   // keep the grid below 2^30 workgroups
   const size_t rows = (npts + (size_t)256 * points_per_lane - 1) / ((size_t)256 * points_per_lane);
   while ((rows + iters - 1) / iters > (1u << 30)) iters *= 2;

@@ -122,7 +122,9 @@ struct LeadReduce<T, 0, FMA> {
 // results move as 2*sizeof(T)-byte vectors (16 B in f64): the streams then cost the L2 fewer
 // channel-cycles per line (measured -4 % at 64^3, -7 % at 32^3; tools/tune_layout ... w).  Needs all
 // obs/out pointers aligned to 2*sizeof(T); the launcher falls back to PPL = 1 otherwise.
-template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL>
+// AXR (rectilinear, every axis <= 64 coordinates): the axes live in registers, one coordinate
+// per lane, and are searched with cross-lane reads instead of LDS gathers.
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, bool AXR = false>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
   typedef typename LeafVec<T, 2>::type P;
   constexpr int L = N - 3;
@@ -131,8 +133,18 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
   unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
-  if (RECT && a.ax.use_lds) stage_axes<T, N>(a.ax, lds_axes);
-  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
+  T greg[N];
+  if constexpr (RECT && AXR) {
+    const int wl = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const T* g = reinterpret_cast<const T*>(a.ax.image + a.ax.g_off[d]);
+      greg[d] = g[wl < a.ax.n[d] ? wl : a.ax.n[d] - 1];
+    }
+  } else if (RECT && a.ax.use_lds) {
+    stage_axes<T, N>(a.ax, lds_axes);
+  }
+  const unsigned char* axis_base = (RECT && !AXR && a.ax.use_lds) ? lds_axes : a.ax.image;
   const unsigned lane = threadIdx.x;
   const unsigned q = lane & 3;
   const unsigned quad = lane >> 2;
@@ -165,6 +177,49 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
 #pragma unroll
       for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? stream_load(a.obs[d] + i0) : (RECT ? (T)0 : a.start[d]);
     }
+    // AXR: the PPL x N binary searches advance in lockstep (six fixed halving steps cover 64
+    // coordinates), so every step issues PPL*N independent cross-lane reads instead of one.
+    int cell_r[PPL][N];
+    T x0_r[PPL][N], x1_r[PPL][N];
+    if constexpr (RECT && AXR) {
+      int size[N];
+#pragma unroll
+      for (int d = 0; d < N; ++d) size[d] = a.ax.n[d];
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) cell_r[h][d] = 0;
+#pragma unroll
+      for (int step = 0; step < 6; ++step) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const int half = size[d] >> 1;  // 0 once size is 1: the probe then re-reads g[base] and keeps base
+#pragma unroll
+          for (int h = 0; h < PPL; ++h) {
+            const int mid = cell_r[h][d] + half;
+            cell_r[h][d] = (half > 0 && __shfl(greg[d], mid) < xin[h][d]) ? mid : cell_r[h][d];
+          }
+          size[d] -= half;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const int n = a.ax.n[d];
+          int l = cell_r[h][d] + ((__shfl(greg[d], cell_r[h][d]) < xin[h][d]) ? 1 : 0) - 1;  // multilinear/rectilinear.rs:363
+          l = l > 0 ? l : 0;
+          l = l < n - 2 ? l : n - 2;  // rectilinear.rs:365-367
+          cell_r[h][d] = l;
+        }
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          x0_r[h][d] = __shfl(greg[d], cell_r[h][d]);
+          x1_r[h][d] = __shfl(greg[d], cell_r[h][d] + 1);
+        }
+    }
     T resv[PPL];
 #pragma unroll
     for (int h = 0; h < PPL; ++h) {
@@ -175,9 +230,16 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
       for (int d = 0; d < N; ++d) {
         const T x = xin[h][d];
         if (RECT) {
-          const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
           T x0, x1;
-          const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
+          int l;
+          if constexpr (AXR) {
+            l = cell_r[h][d];
+            x0 = x0_r[h][d];
+            x1 = x1_r[h][d];
+          } else {
+            const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
+            l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
+          }
           const T step = x1 - x0;
           t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
           loc[d] = l;
@@ -294,26 +356,43 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int N, bool RECT, bool FMA, int PPL>
+template <typename T, int N, bool RECT, bool FMA, int PPL, bool AXR>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
-  if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
-  else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
-  else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
+  else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }
 
+// Axes small enough to sit one coordinate per lane (3-D only: the instantiation count is kept
+// bounded); INTERPN_HIP_AXIS_REGS=0 keeps them in LDS (testing).
+template <int N>
+static bool axes_fit_lanes(const GridDesc& g) {
+  if (N != 3 || g.kind != kRectilinear) return false;
+  for (int d = 0; d < N; ++d)
+    if (g.n[d] > 64) return false;
+  const char* env = getenv("INTERPN_HIP_AXIS_REGS");
+  return !(env && env[0] == '0');
+}
+
 template <typename T, int N, int PPL>
-static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t npts, hipStream_t stream) {
-  a.iters = brick_iters(g, npts, PPL);
+static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t axis_lds, size_t npts, hipStream_t stream) {
+  const bool axr = axes_fit_lanes<N>(g);
+  a.iters = brick_iters(g, npts, PPL, /*per_block_setup=*/g.kind == kRectilinear && !axr);
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;
   const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);
   if (g.kind == kRegular)
-    return g.fma ? launch_steps<T, N, false, true, PPL>(g, a, lds, blocks, stream)
-                 : launch_steps<T, N, false, false, PPL>(g, a, lds, blocks, stream);
-  return g.fma ? launch_steps<T, N, true, true, PPL>(g, a, lds, blocks, stream)
-               : launch_steps<T, N, true, false, PPL>(g, a, lds, blocks, stream);
+    return g.fma ? launch_steps<T, N, false, true, PPL, false>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, false, false, PPL, false>(g, a, lds, blocks, stream);
+  if constexpr (N == 3) {
+    if (axr)
+      return g.fma ? launch_steps<T, N, true, true, PPL, true>(g, a, lds, blocks, stream)
+                   : launch_steps<T, N, true, false, PPL, true>(g, a, lds, blocks, stream);
+  }
+  return g.fma ? launch_steps<T, N, true, true, PPL, false>(g, a, lds + axis_lds, blocks, stream)
+               : launch_steps<T, N, true, false, PPL, false>(g, a, lds + axis_lds, blocks, stream);
 }
 
 template <typename T, int N>
@@ -343,16 +422,17 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.use_lds = 0;
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
-  if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
+  size_t axis_lds = 0;
+  if (g.kind == kRectilinear) axis_lds = fill_axis_args<T, N>(g, a.ax);
   // Two points per lane (vector coordinate/result accesses) for the 3-D shape when every stream is
   // aligned to 2*sizeof(T); INTERPN_HIP_PPL=1 forces the scalar form (tuning / testing).
   if constexpr (N == 3) {
     bool aligned = (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0;
     for (int d = 0; d < N; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
     const char* env = getenv("INTERPN_HIP_PPL");
-    if (aligned && !(env && env[0] == '1')) return launch_kind<T, N, 2>(g, a, lds, npts, stream);
+    if (aligned && !(env && env[0] == '1')) return launch_kind<T, N, 2>(g, a, lds, axis_lds, npts, stream);
   }
-  return launch_kind<T, N, 1>(g, a, lds, npts, stream);
+  return launch_kind<T, N, 1>(g, a, lds, axis_lds, npts, stream);
 }
 
 template <typename T>

@@ -118,6 +118,25 @@ def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("axis_regs", ["0", "1"])
+@pytest.mark.parametrize("ppl", ["1", "2"])
+@pytest.mark.parametrize("axis", [[2, 2, 2], [64, 64, 64], [63, 2, 33], [5, 64, 7], [65, 8, 8]], ids=str)
+def test_rectilinear_axes_in_registers(oracle, monkeypatch, dtype, axis_regs, ppl, axis):
+    """3-D rectilinear axes of at most 64 coordinates are searched across lanes (one coordinate
+    per lane, ds_bpermute probes) instead of in LDS; same probe sequence, same bits — including
+    NaN / +-inf coordinates, 2-point axes and the 65-point case that must fall back to LDS."""
+    monkeypatch.setenv("INTERPN_HIP_AXIS_REGS", axis_regs)
+    monkeypatch.setenv("INTERPN_HIP_PPL", ppl)
+    case = synthetic_case("linear", "rectilinear", 3, axis, 30_011, 4000 + sum(axis), dtype, extrap=0.3,
+                          specials=min(axis) >= 8)
+    case.obs[0][17] = np.nan
+    case.obs[1][18] = np.inf
+    case.obs[2][19] = -np.inf
+    case.obs[0][20] = 1e300 if dtype == np.float64 else 1e30
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 @pytest.mark.parametrize("layout", ["off", "on"])
 @pytest.mark.parametrize("axis", [[2, 2], [2, 9], [3, 8], [9, 2], [16, 17], [33, 15], [7, 100], [257, 129]], ids=str)
