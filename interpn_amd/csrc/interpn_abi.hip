@@ -589,6 +589,16 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     bytes += (n * sizeof(T) + 15) & ~(size_t)15;
     g.axis_tab_off[i] = (unsigned)bytes;
     bytes += (((size_t)M + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
+    g.axis_ltab_off[i] = 0;
+    g.axis_lscale[i] = 0.0;
+    if (M && n <= 64) {
+      const double ls = (double)(T)(255.0 / span);
+      if (ls > 0 && std::isfinite(ls)) {
+        g.axis_lscale[i] = ls;
+        g.axis_ltab_off[i] = (unsigned)bytes;
+        bytes += 65 * sizeof(unsigned) + 12;  // 64 packed words + the scan length, 16-byte multiple
+      }
+    }
     if (bytes > 0xFFFFFF00ull) {
       interpn_hip_destroy(h);
       return INTERPN_HIP_ERR_UNSUPPORTED;
@@ -609,6 +619,9 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       e = build_buckets<T>(reinterpret_cast<const T*>(gdev), g.n[i], g.axis_buckets[i], (T)g.axis_g0[i],
                            (T)g.axis_scale[i], reinterpret_cast<unsigned*>((char*)h->grids_owned + g.axis_tab_off[i]),
                            nullptr);
+    if (e == hipSuccess && g.axis_ltab_off[i])
+      e = build_lane_table<T>(reinterpret_cast<const T*>(gdev), g.n[i], (T)g.axis_g0[i], (T)g.axis_lscale[i],
+                              reinterpret_cast<unsigned*>((char*)h->grids_owned + g.axis_ltab_off[i]), nullptr);
     if (e != hipSuccess) {
       interpn_hip_destroy(h);
       return hip_fail(e);

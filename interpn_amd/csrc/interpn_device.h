@@ -165,6 +165,8 @@ struct Axis {
   T scale;
 };
 
+constexpr int kLaneBuckets = 255;  // buckets of a lane table (256 byte entries = 64 lanes x 4)
+
 template <typename T>
 __device__ __forceinline__ int bucket_of(T x, T g0, T scale, int M) {
   const T u = (x - g0) * scale;

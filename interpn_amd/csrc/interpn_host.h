@@ -40,6 +40,11 @@ struct GridDesc {
   int axis_buckets[8] = {0};       // M per axis, 0 = no table
   double axis_g0[8] = {0};
   double axis_scale[8] = {0};
+  // Lane table of an axis with at most 64 coordinates (sorted, finite): 255 buckets, the count of
+  // coordinates in front of each bucket packed four bytes per word (64 words: one per lane),
+  // followed by one word holding the largest bucket population.  0 = none.
+  unsigned axis_ltab_off[8] = {0};
+  double axis_lscale[8] = {0};
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   const void* bricks = nullptr;
@@ -109,6 +114,8 @@ hipError_t launch_cubic_brick(const GridDesc& g, const T* const* obs, T* out, si
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>
 hipError_t build_buckets(const T* g, int n, int M, T g0, T scale, unsigned* tab, hipStream_t stream);
+template <typename T>
+hipError_t build_lane_table(const T* g, int n, T g0, T scale, unsigned* words65, hipStream_t stream);
 
 // check_bounds: OR into flag[0] whether any of x[0..n) violates [lo, hi] by atol or more
 // (src/multilinear/regular.rs:168-171).

@@ -54,6 +54,8 @@ struct AxisArgs {
   T g0[N];
   T scale[N];
   int use_lds;
+  unsigned ltab_off[N];  // lane tables (axes <= 64 coordinates), 0 = none
+  T lscale[N];
 };
 
 template <typename T, int N>

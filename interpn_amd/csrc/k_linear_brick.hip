@@ -122,9 +122,13 @@ struct LeadReduce<T, 0, FMA> {
 // results move as 2*sizeof(T)-byte vectors (16 B in f64): the streams then cost the L2 fewer
 // channel-cycles per line (measured -4 % at 64^3, -7 % at 32^3; tools/tune_layout ... w).  Needs all
 // obs/out pointers aligned to 2*sizeof(T); the launcher falls back to PPL = 1 otherwise.
-// AXR (rectilinear, every axis <= 64 coordinates): the axes live in registers, one coordinate
-// per lane, and are searched with cross-lane reads instead of LDS gathers.
-template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, bool AXR = false>
+// AXR != 0 (rectilinear, every axis <= 64 coordinates): the axes live in registers, one
+// coordinate per lane, and are searched with cross-lane reads instead of LDS gathers.
+//   AXR == 1: the reference's binary-search probe sequence, six lockstep steps (any axis);
+//   AXR == 2: a 255-bucket lane table (sorted finite axes) brackets the answer to the bucket's
+//             few coordinates: 1 + 2*scan probes instead of 14 (the LDS pipe is what the
+//             rectilinear kernel waits for, profiles/r01_sq_counters_regular_vs_rectilinear.txt).
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
   typedef typename LeafVec<T, 2>::type P;
   constexpr int L = N - 3;
@@ -134,17 +138,26 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
   unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
   T greg[N];
-  if constexpr (RECT && AXR) {
+  unsigned ltab[N];
+  unsigned scan = 0;
+  if constexpr (RECT && AXR != 0) {
     const int wl = (int)(threadIdx.x & 63u);
 #pragma unroll
     for (int d = 0; d < N; ++d) {
       const T* g = reinterpret_cast<const T*>(a.ax.image + a.ax.g_off[d]);
       greg[d] = g[wl < a.ax.n[d] ? wl : a.ax.n[d] - 1];
+      if constexpr (AXR == 2) {
+        const unsigned* words = reinterpret_cast<const unsigned*>(a.ax.image + a.ax.ltab_off[d]);
+        ltab[d] = words[wl];
+        const unsigned pop = words[64];  // uniform
+        scan = pop > scan ? pop : scan;
+      }
     }
+    scan = __builtin_amdgcn_readfirstlane(scan);
   } else if (RECT && a.ax.use_lds) {
     stage_axes<T, N>(a.ax, lds_axes);
   }
-  const unsigned char* axis_base = (RECT && !AXR && a.ax.use_lds) ? lds_axes : a.ax.image;
+  const unsigned char* axis_base = (RECT && AXR == 0 && a.ax.use_lds) ? lds_axes : a.ax.image;
   const unsigned lane = threadIdx.x;
   const unsigned q = lane & 3;
   const unsigned quad = lane >> 2;
@@ -181,35 +194,67 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
     // coordinates), so every step issues PPL*N independent cross-lane reads instead of one.
     int cell_r[PPL][N];
     T x0_r[PPL][N], x1_r[PPL][N];
-    if constexpr (RECT && AXR) {
-      int size[N];
+    if constexpr (RECT && AXR != 0) {
+      // cell_r <- partition_point(g < x) (multilinear/rectilinear.rs:363) ...
+      if constexpr (AXR == 1) {
+        int size[N];
 #pragma unroll
-      for (int d = 0; d < N; ++d) size[d] = a.ax.n[d];
+        for (int d = 0; d < N; ++d) size[d] = a.ax.n[d];
 #pragma unroll
-      for (int h = 0; h < PPL; ++h)
+        for (int h = 0; h < PPL; ++h)
 #pragma unroll
-        for (int d = 0; d < N; ++d) cell_r[h][d] = 0;
+          for (int d = 0; d < N; ++d) cell_r[h][d] = 0;
 #pragma unroll
-      for (int step = 0; step < 6; ++step) {
+        for (int step = 0; step < 6; ++step) {
 #pragma unroll
-        for (int d = 0; d < N; ++d) {
-          const int half = size[d] >> 1;  // 0 once size is 1: the probe then re-reads g[base] and keeps base
+          for (int d = 0; d < N; ++d) {
+            const int half = size[d] >> 1;  // 0 once size is 1: the probe then re-reads g[base] and keeps base
 #pragma unroll
-          for (int h = 0; h < PPL; ++h) {
-            const int mid = cell_r[h][d] + half;
-            cell_r[h][d] = (half > 0 && __shfl(greg[d], mid) < xin[h][d]) ? mid : cell_r[h][d];
+            for (int h = 0; h < PPL; ++h) {
+              const int mid = cell_r[h][d] + half;
+              cell_r[h][d] = (half > 0 && __shfl(greg[d], mid) < xin[h][d]) ? mid : cell_r[h][d];
+            }
+            size[d] -= half;
           }
-          size[d] -= half;
+        }
+#pragma unroll
+        for (int h = 0; h < PPL; ++h)
+#pragma unroll
+          for (int d = 0; d < N; ++d)
+            cell_r[h][d] += (__shfl(greg[d], cell_r[h][d]) < xin[h][d]) ? 1 : 0;
+      } else {
+        // Coordinates in earlier buckets are < x and those in later buckets are >= x (bucket_of is
+        // monotone and the table was built with it), so starting at the bucket's first coordinate
+        // and stepping while g[idx] < x — at most `scan` times — lands on the count of g < x.
+#pragma unroll
+        for (int h = 0; h < PPL; ++h)
+#pragma unroll
+          for (int d = 0; d < N; ++d) {
+            const int b = bucket_of<T>(xin[h][d], a.ax.g0[d], a.ax.lscale[d], kLaneBuckets);
+            const unsigned w = __shfl(ltab[d], b >> 2);
+            cell_r[h][d] = (int)((w >> ((b & 3) * 8)) & 0xFFu);
+          }
+        for (unsigned s = 0; s < scan; ++s) {  // uniform trip count
+#pragma unroll
+          for (int h = 0; h < PPL; ++h)
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+              const int n = a.ax.n[d];
+              const int idx = cell_r[h][d];
+              const T gi = __shfl(greg[d], idx < n ? idx : n - 1);
+              cell_r[h][d] = idx + ((idx < n && gi < xin[h][d]) ? 1 : 0);
+            }
         }
       }
+      // ... then the cell: clamp(partition_point - 1, 0, n-2) (rectilinear.rs:365-367)
 #pragma unroll
       for (int h = 0; h < PPL; ++h)
 #pragma unroll
         for (int d = 0; d < N; ++d) {
           const int n = a.ax.n[d];
-          int l = cell_r[h][d] + ((__shfl(greg[d], cell_r[h][d]) < xin[h][d]) ? 1 : 0) - 1;  // multilinear/rectilinear.rs:363
+          int l = cell_r[h][d] - 1;
           l = l > 0 ? l : 0;
-          l = l < n - 2 ? l : n - 2;  // rectilinear.rs:365-367
+          l = l < n - 2 ? l : n - 2;
           cell_r[h][d] = l;
         }
 #pragma unroll
@@ -232,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         if (RECT) {
           T x0, x1;
           int l;
-          if constexpr (AXR) {
+          if constexpr (AXR != 0) {
             l = cell_r[h][d];
             x0 = x0_r[h][d];
             x1 = x1_r[h][d];
@@ -356,7 +401,7 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int N, bool RECT, bool FMA, int PPL, bool AXR>
+template <typename T, int N, bool RECT, bool FMA, int PPL, int AXR>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
   if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
@@ -367,32 +412,44 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
 
 // Axes small enough to sit one coordinate per lane (3-D only: the instantiation count is kept
 // bounded); INTERPN_HIP_AXIS_REGS=0 keeps them in LDS (testing).
+// 0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane tables.
+// INTERPN_HIP_AXIS_REGS=0|1|2 overrides (testing; 2 falls back to 1 when a table is missing).
 template <int N>
-static bool axes_fit_lanes(const GridDesc& g) {
-  if (N != 3 || g.kind != kRectilinear) return false;
-  for (int d = 0; d < N; ++d)
-    if (g.n[d] > 64) return false;
-  const char* env = getenv("INTERPN_HIP_AXIS_REGS");
-  return !(env && env[0] == '0');
+static int axes_in_lanes(const GridDesc& g) {
+  if (N != 3 || g.kind != kRectilinear) return 0;
+  bool tables = true;
+  for (int d = 0; d < N; ++d) {
+    if (g.n[d] > 64) return 0;
+    tables = tables && g.axis_ltab_off[d] != 0;
+  }
+  int mode = tables ? 2 : 1;
+  if (const char* env = getenv("INTERPN_HIP_AXIS_REGS")) {
+    if (env[0] == '0') mode = 0;
+    else if (env[0] == '1') mode = 1;
+  }
+  return mode;
 }
 
 template <typename T, int N, int PPL>
 static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t axis_lds, size_t npts, hipStream_t stream) {
-  const bool axr = axes_fit_lanes<N>(g);
-  a.iters = brick_iters(g, npts, PPL, /*per_block_setup=*/g.kind == kRectilinear && !axr);
+  const int axr = axes_in_lanes<N>(g);
+  a.iters = brick_iters(g, npts, PPL, /*per_block_setup=*/g.kind == kRectilinear && axr == 0);
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;
   const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);
   if (g.kind == kRegular)
-    return g.fma ? launch_steps<T, N, false, true, PPL, false>(g, a, lds, blocks, stream)
-                 : launch_steps<T, N, false, false, PPL, false>(g, a, lds, blocks, stream);
+    return g.fma ? launch_steps<T, N, false, true, PPL, 0>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, false, false, PPL, 0>(g, a, lds, blocks, stream);
   if constexpr (N == 3) {
-    if (axr)
-      return g.fma ? launch_steps<T, N, true, true, PPL, true>(g, a, lds, blocks, stream)
-                   : launch_steps<T, N, true, false, PPL, true>(g, a, lds, blocks, stream);
+    if (axr == 2)
+      return g.fma ? launch_steps<T, N, true, true, PPL, 2>(g, a, lds, blocks, stream)
+                   : launch_steps<T, N, true, false, PPL, 2>(g, a, lds, blocks, stream);
+    if (axr == 1)
+      return g.fma ? launch_steps<T, N, true, true, PPL, 1>(g, a, lds, blocks, stream)
+                   : launch_steps<T, N, true, false, PPL, 1>(g, a, lds, blocks, stream);
   }
-  return g.fma ? launch_steps<T, N, true, true, PPL, false>(g, a, lds + axis_lds, blocks, stream)
-               : launch_steps<T, N, true, false, PPL, false>(g, a, lds + axis_lds, blocks, stream);
+  return g.fma ? launch_steps<T, N, true, true, PPL, 0>(g, a, lds + axis_lds, blocks, stream)
+               : launch_steps<T, N, true, false, PPL, 0>(g, a, lds + axis_lds, blocks, stream);
 }
 
 template <typename T, int N>

@@ -15,6 +15,8 @@ inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax) {
     ax.M[d] = g.axis_buckets[d];
     ax.g0[d] = (T)g.axis_g0[d];
     ax.scale[d] = (T)g.axis_scale[d];
+    ax.ltab_off[d] = g.axis_ltab_off[d];
+    ax.lscale[d] = (T)g.axis_lscale[d];
   }
   ax.use_lds = g.axis_image_bytes <= kMaxGridLdsBytes;
   return ax.use_lds ? g.axis_image_bytes : 0;

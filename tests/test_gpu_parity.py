@@ -118,13 +118,14 @@ def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("axis_regs", ["0", "1"])
+@pytest.mark.parametrize("axis_regs", ["0", "1", "2"])
 @pytest.mark.parametrize("ppl", ["1", "2"])
 @pytest.mark.parametrize("axis", [[2, 2, 2], [64, 64, 64], [63, 2, 33], [5, 64, 7], [65, 8, 8]], ids=str)
 def test_rectilinear_axes_in_registers(oracle, monkeypatch, dtype, axis_regs, ppl, axis):
     """3-D rectilinear axes of at most 64 coordinates are searched across lanes (one coordinate
-    per lane, ds_bpermute probes) instead of in LDS; same probe sequence, same bits — including
-    NaN / +-inf coordinates, 2-point axes and the 65-point case that must fall back to LDS."""
+    per lane, ds_bpermute probes) instead of in LDS — mode 1 with the reference's probe sequence,
+    mode 2 through a 255-bucket lane table; same bits as the LDS form (mode 0), including NaN /
+    +-inf coordinates, 2-point axes and the 65-point case that must fall back to LDS."""
     monkeypatch.setenv("INTERPN_HIP_AXIS_REGS", axis_regs)
     monkeypatch.setenv("INTERPN_HIP_PPL", ppl)
     case = synthetic_case("linear", "rectilinear", 3, axis, 30_011, 4000 + sum(axis), dtype, extrap=0.3,
@@ -134,6 +135,32 @@ def test_rectilinear_axes_in_registers(oracle, monkeypatch, dtype, axis_regs, pp
     case.obs[2][19] = -np.inf
     case.obs[0][20] = 1e300 if dtype == np.float64 else 1e30
     assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("axis_regs", ["0", "1", "2"])
+def test_rectilinear_clustered_and_unsorted_axes(oracle, monkeypatch, dtype, axis_regs):
+    """Lane-table corner cases: many coordinates inside one bucket (the scan length grows to the
+    bucket population), coordinates a few ulps apart, and an unsorted axis (legal input: the
+    reference only checks g[1] > g[0]) which has no table and takes the probe-sequence search."""
+    from tests.kat import Case
+
+    monkeypatch.setenv("INTERPN_HIP_AXIS_REGS", axis_regs)
+    rng = np.random.default_rng(99)
+    one = dtype(1.0)
+    g0 = np.concatenate([[-1.0], 0.25 + np.arange(20) * 1e-4, [0.9, 1.0]]).astype(dtype)      # 20 nodes in one bucket
+    g1 = np.concatenate([[-1.0, -0.5], [np.nextafter(one, dtype(2)) * dtype(0.125) * k for k in range(1, 4)],
+                         [2.0]]).astype(dtype)
+    g1 = np.sort(np.unique(g1))
+    g2 = np.array([0.0, 1.0, 0.5, 3.0, 2.0, 2.5, 4.0], dtype=dtype)                          # unsorted
+    for grids in ([g0, g1, np.linspace(-1, 1, 64).astype(dtype)], [g0, g2, g1]):
+        nobs = 20_000
+        vals = rng.uniform(-1, 1, int(np.prod([g.size for g in grids]))).astype(dtype)
+        obs = [rng.uniform(float(g.min()) - 0.2, float(g.max()) + 0.2, nobs).astype(dtype) for g in grids]
+        obs[0][:g0.size] = g0          # exact nodes of the clustered axis
+        obs[0][100:120] = g0[1:21] + dtype(5e-5)
+        case = Case("clustered", "linear", "rectilinear", grids, vals, obs, np.zeros(nobs, dtype=dtype), 0.0)
+        assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])

@@ -55,7 +55,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
             if rng.random() < 0.1: env["INTERPN_HIP_GENERIC_RUNTIME"] = "1"
             if rng.random() < 0.2: env["INTERPN_HIP_HOST_CHUNK"] = str(int(rng.integers(1, max(2, nobs))))
             if rng.random() < 0.2: env["INTERPN_HIP_ITERS_PER_BLOCK"] = str(int(rng.choice([1, 2, 3, 8, 64])))
-            if rng.random() < 0.3: env["INTERPN_HIP_AXIS_REGS"] = "0"
+            if rng.random() < 0.4: env["INTERPN_HIP_AXIS_REGS"] = str(int(rng.integers(0, 2)))
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(env)
