@@ -41,6 +41,9 @@
  *       INTERPN_HIP_ITERS_PER_BLOCK=n   256-lane rows per workgroup of the one-pass brick kernels
  *       INTERPN_HIP_PPL=1               one point per lane in the 3-D multilinear kernel
  *       INTERPN_HIP_FORCE_GENERIC=1     route every evaluation through the runtime-N kernel
+ *       INTERPN_HIP_GENERIC_RUNTIME=1, INTERPN_HIP_GENERIC_VEC=0|1   forms of the recursive-arm kernel
+ *       INTERPN_HIP_AXIS_REGS=0|1       3-D rectilinear axes <= 64 coordinates: 0 = search in LDS,
+ *                                       1 = across lanes without the lane table (default: with it)
  *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (default 2 Mi)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
  *                                       (default 1024; 0 = release everything at destroy)
