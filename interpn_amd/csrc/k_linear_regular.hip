@@ -1,4 +1,6 @@
 // multilinear::regular launchers (reference: src/multilinear/regular.rs:51-117 dispatch on ndims).
+#include <cstdlib>
+
 #include "interpn_kernels.h"
 
 #ifndef INTERPN_U_LINEAR
@@ -26,7 +28,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
     acc *= (unsigned)g.n[d];
   }
   constexpr int U = INTERPN_U_LINEAR;
-  const unsigned blocks = grid_blocks(npts, U, g.cfg);
+  const unsigned blocks = getenv("INTERPN_HIP_PERSISTENT") ? grid_blocks(npts, U, g.cfg) : one_pass_blocks(npts, U);
   hipLaunchKernelGGL((k_linear_regular<T, N, FMA, U>), dim3(blocks), dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }
