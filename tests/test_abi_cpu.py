@@ -167,3 +167,20 @@ def test_python_classes_validate_like_the_reference():
     assert rt.dims == it.dims and np.array_equal(rt.vals, it.vals) and rt.linearize_extrapolation is True
     with pytest.raises(TypeError):
         it.dims = [1]
+
+
+def test_header_is_valid_c99_and_c_consumer_compiles(tmp_path):
+    """The boundary is a C ABI: `include/interpn_hip.h` must compile as plain C99 (no C++isms, no
+    HIP/torch types) and the pure-C consumer in examples/ must compile and link against the
+    library (running it needs a GPU: tests/test_gpu_parity.py::test_c_consumer_runs)."""
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    src = os.path.join(ROOT, "examples", "c_abi_demo.c")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", src])
+    probe = tmp_path / "only_header.c"
+    probe.write_text('#include "interpn_hip.h"\nint main(void) { return INTERPN_HIP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-I", inc, "-c", str(probe), "-o", str(tmp_path / "p.o")])
+    libdir = os.path.join(ROOT, "interpn_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", inc, src, "-L", libdir, "-linterpn_hip", f"-Wl,-rpath,{libdir}",
+                           "-lm", "-o", str(tmp_path / "demo")])

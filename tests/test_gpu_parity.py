@@ -639,3 +639,21 @@ def test_differential_fuzz_short(oracle):
     cases, failures = run(budget=12.0, seed=20261003, max_cases=1500)
     assert cases > 100
     assert failures == 0
+
+
+def test_c_consumer_runs(tmp_path):
+    """examples/c_abi_demo.c — a pure-C program linked against libinterpn_hip.so (no Python, no
+    torch in the process): one-shot and handle calls, abort semantics, the reference's error
+    strings, a cubic rectilinear call."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "interpn_amd")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-L", libdir, "-linterpn_hip",
+                           f"-Wl,-rpath,{libdir}", "-lm", "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ALL PASSED" in res.stdout and "FAIL " not in res.stdout
