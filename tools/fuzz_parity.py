@@ -18,10 +18,14 @@ LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
 def run(budget: float, seed: int, max_cases: int = 0):
     """Returns (cases, failures)."""
+    from interpn_amd import _lib
+
+    lib = _lib.load()
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     n_cases = n_fail = 0
     saved = {k: os.environ.get(k) for k in KNOBS}
+    prev_fma = lib.interpn_hip_set_fma(1)
     try:
         while time.time() < t_end and (max_cases == 0 or n_cases < max_cases):
             method = rng.choice(["linear", "cubic", "nearest"], p=[0.45, 0.4, 0.15])
@@ -65,6 +69,8 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 # inject NaN / inf / huge coordinates: rectilinear never errors, results must still match
                 for _ in range(3):
                     case.obs[int(rng.integers(0, N))][int(rng.integers(0, nobs))] = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30])
+            fma = bool(rng.random() < 0.7)  # the reference's `fma` cargo feature, both flavours
+            lib.interpn_hip_set_fma(1 if fma else 0)
             inject = kind == "regular" and rng.random() < 0.25
             if inject:
                 # regular grids abort at the first unrepresentable coordinate: same error, same
@@ -75,7 +81,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
             got = np.full(nobs, -777.0, dtype=dtype)
             err_o = err_g = None
             try:
-                run_oracle(pyoracle, case, True, out=want)
+                run_oracle(pyoracle, case, fma, out=want)
             except AssertionError as e:
                 err_o = str(e)
             try:
@@ -92,8 +98,9 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 n_fail += 1
                 nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want)))))
                 print(f"FAIL method={method} kind={kind} N={N} axis={axis} nobs={nobs} dtype={np.dtype(dtype).name} "
-                      f"linearize={linearize} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
+                      f"linearize={linearize} fma={fma} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
     finally:
+        lib.interpn_hip_set_fma(prev_fma)
         for k, v in saved.items():
             os.environ.pop(k, None)
             if v is not None:
