@@ -16,6 +16,41 @@ LAYOUTS_LIN = [None, "off", "11", "12", "22"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
 
+def run_device(case, rng, dtype):
+    """The persistent-handle device entry point on torch tensors whose first element sits at a
+    random element offset (exercises the aligned-vector and the scalar stream paths)."""
+    import torch
+
+    import interpn_amd
+
+    if case.kind == "regular":
+        it = interpn_amd.Interpolator.regular(case.method, case.dims, case.starts, case.steps, case.vals,
+                                              linearize_extrapolation=case.linearize)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(case.method, case.grids, case.vals,
+                                                  linearize_extrapolation=case.linearize)
+    try:
+        nobs = case.obs[0].size
+        obs_t = []
+        for o in case.obs:
+            off = int(rng.integers(0, 4))
+            t = torch.empty(nobs + off, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+            t[off:].copy_(torch.from_numpy(np.ascontiguousarray(o)))
+            obs_t.append(t[off:])
+        off = int(rng.integers(0, 4))
+        out_full = torch.full((nobs + off,), -777.0, dtype=obs_t[0].dtype, device="cuda")
+        out_t = out_full[off:]
+        it.eval_tensors(obs_t, out_t)
+        err, first_bad = None, None
+        try:
+            it.finish()
+        except AssertionError as e:
+            err, first_bad = str(e), getattr(e, "first_bad_index", None)
+        return out_t.cpu().numpy(), err, first_bad
+    finally:
+        it.close()
+
+
 def run(budget: float, seed: int, max_cases: int = 0):
     """Returns (cases, failures)."""
     from interpn_amd import _lib
@@ -84,13 +119,22 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 run_oracle(pyoracle, case, fma, out=want)
             except AssertionError as e:
                 err_o = str(e)
+            device_path = rng.random() < 0.3
             try:
-                run_hip_raw(case, out=got)
+                if device_path:
+                    got, err_g, first_bad = run_device(case, rng, dtype)
+                else:
+                    run_hip_raw(case, out=got)
             except AssertionError as e:
                 err_g = str(e)
             except Exception as e:  # noqa: BLE001
                 err_g = "EXC " + repr(e)
-            same = err_o == err_g and np.array_equal(got, want, equal_nan=True)
+            if device_path and err_g is not None and err_o == err_g:
+                # device entry point: out[first_bad..] is unspecified; the index and the prefix are not
+                k = int(np.flatnonzero(want == dtype(-777.0))[0]) if np.any(want == dtype(-777.0)) else nobs
+                same = first_bad == k and np.array_equal(got[:k], want[:k], equal_nan=True)
+            else:
+                same = err_o == err_g and np.array_equal(got, want, equal_nan=True)
             if inject and err_o is None:
                 same = False  # the injection must have been seen
             n_cases += 1
@@ -98,7 +142,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 n_fail += 1
                 nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want)))))
                 print(f"FAIL method={method} kind={kind} N={N} axis={axis} nobs={nobs} dtype={np.dtype(dtype).name} "
-                      f"linearize={linearize} fma={fma} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
+                      f"linearize={linearize} fma={fma} device_path={device_path} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
     finally:
         lib.interpn_hip_set_fma(prev_fma)
         for k, v in saved.items():
