@@ -59,9 +59,9 @@ struct GridDesc {
 // axes per workgroup and want a few rows each to amortise that.
 inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane, bool per_block_setup) {
   unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (per_block_setup ? 8u : 1u);
-  // keep the grid below 2^30 workgroups
+  // keep the grid below 2^23 workgroups (the dispatch packet counts work-items in 32 bits)
   const size_t rows = (npts + (size_t)256 * points_per_lane - 1) / ((size_t)256 * points_per_lane);
-  while ((rows + iters - 1) / iters > (1u << 30)) iters *= 2;
+  while ((rows + iters - 1) / iters > (1u << 23)) iters *= 2;
   return iters;
 }
 

@@ -589,7 +589,9 @@ inline unsigned one_pass_blocks(size_t npts, int points_per_thread) {
   size_t per_block = (size_t)kBlock * points_per_thread;
   size_t want = (npts + per_block - 1) / per_block;
   if (want < 1) want = 1;
-  return (unsigned)(want < ((size_t)1 << 30) ? want : ((size_t)1 << 30));
+  // at most 2^23 workgroups: the dispatch packet counts work-items in 32 bits; the grid-stride
+  // loop of the kernel covers anything beyond
+  return (unsigned)(want < ((size_t)1 << 23) ? want : ((size_t)1 << 23));
 }
 
 }  // namespace interpn
