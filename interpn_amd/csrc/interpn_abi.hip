@@ -361,10 +361,20 @@ int resolve_device(int device, int* out) {
 // Candidates are ranked by a two-level cost model: lines per point x (L2 hit ? 1/2.7e11 : 1/6.2e10 s),
 // with the hit fraction ~ min(1, 3 MiB / table bytes) — the measured L2 and Infinity-Cache line
 // rates.  INTERPN_HIP_BRICKS=off|44|24|22|14|11 overrides.
+// A grid of at most 16 KiB stays resident in every CU's 32 KiB vector L1, where the plain C-order
+// gather beats the cooperative brick gather and its LDS exchange (measured, 1e8 points: 2-D linear
+// 45^2 0.53 vs 0.70 ms, 3-D linear 12^3 0.74 vs 0.86 ms, 2-D cubic 45^2 1.16 vs 1.53 ms; from
+// 32 KiB on the bricks win: 16^3 0.93 vs 1.38 ms).  An explicit INTERPN_HIP_BRICKS layout still
+// applies (tests).
+static bool grid_is_l1_resident(const GridDesc& g) {
+  return g.nvals * (g.dtype == kF64 ? 8u : 4u) <= 16u * 1024u;
+}
+
 int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   GridDesc& g = h->desc;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
+  if (!(env && strlen(env) == 2) && grid_is_l1_resident(g)) return INTERPN_HIP_OK;
   static const int cand[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 4}, {1, 1}};
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
@@ -408,6 +418,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (g.method == kLinear && g.ndims == 2) {
     const char* env2 = getenv("INTERPN_HIP_BRICKS");
     if (env2 && !strcmp(env2, "off")) return INTERPN_HIP_OK;
+    if (!(env2 && !strcmp(env2, "on")) && grid_is_l1_resident(g)) return INTERPN_HIP_OK;
     size_t bytes2;
     brick2_geometry(g, g.brick_nb, &bytes2);
     g.brick_nb[2] = 1;
@@ -429,6 +440,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     si = env[0] - '0';
     sj = env[1] - '0';
   } else {
+    if (grid_is_l1_resident(g)) return INTERPN_HIP_OK;
     // Measured on MI355X (tools/sweep_layouts.py, 3-D f64, 24^3 .. 384^3, non-temporal streams):
     // the fully overlapped layout (one line per cell) wins while its table is L2-sized (<= 6 MiB)
     // and again once even the (2,2) table is far beyond the 4 MiB L2 (Infinity-Cache- or
