@@ -393,7 +393,7 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
     double planes = 1;
     for (int d = 2; d < g.ndims; ++d) planes *= 4;
     const double lines = planes * e_i * e_j;
-    double hit = (3.0 * 1048576.0) / (double)bytes;
+    double hit = (3.5 * 1048576.0) / (double)bytes;  // share of the 4 MiB L2 the table keeps beside the non-temporal streams
     if (hit > 1) hit = 1;
     const double cost = lines * (hit / 2.7e11 + (1 - hit) / 6.2e10);
     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
