@@ -654,6 +654,38 @@ def test_c_consumer_runs(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
                            os.path.join(root, "examples", "c_abi_demo.c"), "-L", libdir, "-linterpn_hip",
                            f"-Wl,-rpath,{libdir}", "-lm", "-o", exe])
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert res.returncode == 0, res.stdout + res.stderr
-    assert "ALL PASSED" in res.stdout and "FAIL " not in res.stdout
+    for pool_mb in (None, "0"):  # default pool of freed device blocks, and pool disabled
+        env = dict(os.environ)
+        if pool_mb is not None:
+            env["INTERPN_HIP_POOL_MB"] = pool_mb
+        res = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "ALL PASSED" in res.stdout and "FAIL " not in res.stdout
+
+
+def test_one_shot_calls_do_not_leak_device_memory(oracle):
+    """The one-shot entry points rebuild the interpolator per call (as the reference does) and
+    recycle device blocks through a per-device pool capped at INTERPN_HIP_POOL_MB (1 GiB): a long
+    run of calls with changing grid and batch sizes must not grow the device footprint past it."""
+    import torch
+
+    from interpn_amd import raw
+
+    rng = np.random.default_rng(11)
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info()
+    for k in range(400):
+        n = int(rng.integers(2, 40))
+        nobs = int(rng.integers(1, 50_000))
+        g = np.linspace(-1.0, 1.0, n)
+        vals = rng.uniform(-1, 1, n ** 3)
+        obs = [rng.uniform(-1.1, 1.1, nobs) for _ in range(3)]
+        out = np.zeros(nobs)
+        raw.interpn_linear_regular_f64([n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0]), vals, obs, out)
+        if k % 100 == 0:
+            want = np.zeros(nobs)
+            oracle.linear_regular([n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0]), vals, obs, want)
+            assert np.array_equal(out, want)
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info()
+    assert free0 - free1 < (1 << 30) + (256 << 20), f"device footprint grew by {(free0 - free1) >> 20} MiB"
