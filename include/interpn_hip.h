@@ -47,9 +47,10 @@
  *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (default 2 Mi)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
  *                                       (default 1024; 0 = release everything at destroy)
- *   - Thread safety: all functions are re-entrant; concurrent evaluation on one handle is
- *     allowed (the grid is read-only), but the sticky first-bad-index word of a handle is
- *     shared by its in-flight device evaluations.
+ *   - Thread safety: all functions are re-entrant.  Device-pointer evaluations on one handle may
+ *     run concurrently (the grid is read-only; the sticky first-bad-index word of the handle is
+ *     shared by them); host-pointer evaluations on one handle share its staging buffers and are
+ *     serialised internally — use one handle per thread to overlap them.
  */
 #ifndef INTERPN_HIP_H
 #define INTERPN_HIP_H

@@ -253,6 +253,7 @@ struct interpn_hip_interp {
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
   unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
   std::mutex finish_mu;
+  std::mutex host_mu;  // host-pointer evaluations on one handle share its two lanes: serialised
   // Host-evaluation workspace (lazily allocated, reused across calls): two pipeline lanes so
   // that the upload of one chunk overlaps the download of the previous one.
   struct HostLane {
@@ -958,6 +959,7 @@ constexpr size_t kPipelineChunkPoints = (size_t)2 << 20;
 static int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t nout,
                           size_t* bad_index) {
   (void)nobs;
+  std::lock_guard<std::mutex> host_lock(h->host_mu);
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
   HostPipeline p;

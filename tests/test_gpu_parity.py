@@ -689,3 +689,54 @@ def test_one_shot_calls_do_not_leak_device_memory(oracle):
     torch.cuda.synchronize()
     free1, _total = torch.cuda.mem_get_info()
     assert free0 - free1 < (1 << 30) + (256 << 20), f"device footprint grew by {(free0 - free1) >> 20} MiB"
+
+
+def test_concurrent_host_calls_from_threads(oracle):
+    """The ABI is re-entrant (threading): one-shot calls and evaluations on a
+    shared resident handle from eight host threads at once, every result bit-identical."""
+    import threading
+
+    import interpn_amd
+    from interpn_amd import raw
+
+    rng = np.random.default_rng(5)
+    n = 17
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0])
+    vals = rng.uniform(-1, 1, n ** 3)
+    shared = interpn_amd.MultilinearRegular.new(dims, starts, steps, vals)
+    errors = []
+
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for k in range(25):
+                nobs = int(r.integers(1, 30_000))
+                obs = [r.uniform(-1.2, 1.2, nobs) for _ in range(3)]
+                want = np.zeros(nobs)
+                oracle.linear_regular(dims, starts, steps, vals, obs, want)
+                got = np.zeros(nobs)
+                if k % 2:
+                    raw.interpn_linear_regular_f64(dims, starts, steps, vals, obs, got)
+                else:
+                    cub = np.zeros(nobs)
+                    raw.interpn_cubic_regular_f64(dims, starts, steps, vals, True, obs, cub)
+                    wantc = np.zeros(nobs)
+                    oracle.cubic_regular(dims, starts, steps, vals, True, obs, wantc)
+                    if not np.array_equal(cub, wantc):
+                        errors.append(f"cubic one-shot differs (seed {seed}, call {k})")
+                    raw.interpn_linear_regular_f64(dims, starts, steps, vals, obs, got)
+                if not np.array_equal(got, want):
+                    errors.append(f"linear one-shot differs (seed {seed}, call {k})")
+                if not np.array_equal(shared.eval(obs), want):  # one handle, many threads
+                    errors.append(f"shared-handle eval differs (seed {seed}, call {k})")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(100 + i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    del shared
+    assert not errors, errors[:3]
