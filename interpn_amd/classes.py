@@ -13,12 +13,15 @@ the observation points never leave the device.
 from __future__ import annotations
 
 import json
+import threading
 from functools import reduce
 
 import numpy as np
 
 from . import raw
 from .handle import Interpolator
+
+_HANDLE_LOCK = threading.Lock()
 
 
 def _as_flat(a, dtype):
@@ -48,7 +51,9 @@ class _Base:
     # -- device residency -------------------------------------------------------------------
     def _interp(self) -> Interpolator:
         if self._handle is None:
-            object.__setattr__(self, "_handle", self._make_handle())
+            with _HANDLE_LOCK:  # first eval from several threads: upload the grid once
+                if self._handle is None:
+                    object.__setattr__(self, "_handle", self._make_handle())
         return self._handle
 
     def to_device(self, device: int = -1) -> "_Base":
