@@ -220,6 +220,15 @@ void interpn_hip_destroy(interpn_hip_interp* h);
  * out[d] = 1 if any observation violates the bounds of dimension d by atol or more.
  * Host pointers; streamed through the current device.
  * ---------------------------------------------------------------------------------------- */
+/* The same check on DEVICE-resident coordinates, limits taken from the handle's grid (the
+ * pre-pass of the reference's Python `interpn(..., check_bounds=True)`, src/interpn/__init__.py:
+ * 115-132, without moving the points over PCIe).  `obs`: host array of `nobs` device pointers
+ * to `npoints` elements of the handle's type; `out`: host, `nout` = ndims bytes.  Synchronous
+ * on `stream`. */
+int interpn_hip_check_bounds_device(interpn_hip_interp* h, const void* const* obs, size_t nobs,
+                                    size_t npoints, double atol, uint8_t* out, size_t nout,
+                                    void* stream);
+
 #define INTERPN_HIP_DECLARE_BOUNDS(T, SUFFIX)                                                            \
   int interpn_hip_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,      \
                                                 size_t nstarts, const T* steps, size_t nsteps,          \

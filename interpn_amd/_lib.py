@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libinterpn_hip.so")
 
 # interpn_hip_status (include/interpn_hip.h)
 OK = 0
+ERR_DIM_MISMATCH = 1
 ERR_UNREPRESENTABLE = 7
 ERR_REFERENCE_PANIC = 9
 ERR_TOO_MANY_DIMS_6 = 10
@@ -111,6 +112,8 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_eval_host_sharded.argtypes = [POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_size_t),
                                                   c_size_t, c_void_p, c_size_t, POINTER(c_uint64)]
     lib.interpn_hip_eval_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p]
+    lib.interpn_hip_check_bounds_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_size_t, ctypes.c_double,
+                                                    POINTER(ctypes.c_uint8), c_size_t, c_void_p]
     lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
     lib.interpn_hip_set_blocks_per_cu.argtypes = [c_void_p, c_int]
     lib.interpn_hip_destroy.argtypes = [c_void_p]

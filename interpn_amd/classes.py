@@ -156,6 +156,8 @@ class _RegularBase(_Base):
                                     getattr(self, "linearize_extrapolation", False), device, dtype)
 
     def check_bounds(self, obs, atol: float):
+        if obs and _is_tensor(obs[0]):
+            return self._interp().check_bounds_tensors(obs, atol)
         ndims = self.ndims()
         out = np.array([False] * ndims)
         dtype = self.vals.dtype
@@ -201,6 +203,8 @@ class _RectilinearBase(_Base):
                                         getattr(self, "linearize_extrapolation", False), device, self.vals.dtype)
 
     def check_bounds(self, obs, atol: float):
+        if obs and _is_tensor(obs[0]):
+            return self._interp().check_bounds_tensors(obs, atol)
         ndims = self.ndims()
         out = np.array([False] * ndims)
         dtype = self.vals.dtype

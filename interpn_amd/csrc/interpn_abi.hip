@@ -539,6 +539,12 @@ int create_regular(int method, const size_t* dims, size_t ndims, const T* starts
     g.n[i] = (int)dims[i];
     g.start[i] = (double)starts[i];
     g.step[i] = (double)steps[i];
+    {
+      const T prod = steps[i] * (T)(dims[i] - 1);
+      const T last = starts[i] + prod;  // regular.rs:164, not fused
+      g.bound_lo[i] = (double)(T)__builtin_fmin((double)starts[i], (double)last);
+      g.bound_hi[i] = (double)(T)__builtin_fmax((double)starts[i], (double)last);
+    }
     g.grid_total += dims[i];
   }
   st = finish_create(h, vals, nvals, sizeof(T), vals_mem);
@@ -579,6 +585,8 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
   for (size_t i = 0; i < ngrids; ++i) {
     g.n[i] = (int)grid_lens[i];
     total += grid_lens[i];
+    g.bound_lo[i] = (double)grids[i][0];                  // rectilinear.rs:121-123
+    g.bound_hi[i] = (double)grids[i][grid_lens[i] - 1];
   }
   g.grid_total = total;
   // Axis image: per axis the coordinates (16-byte aligned) followed by the bucket table
@@ -1157,6 +1165,39 @@ DEFINE_ONESHOT(float, f32)
   }
 DEFINE_NEAREST(double, f64)
 DEFINE_NEAREST(float, f32)
+
+// check_bounds on device-resident coordinates, limits from the handle's grid.
+int interpn_hip_check_bounds_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, size_t npoints,
+                                    double atol, uint8_t* out, size_t nout, void* stream) {
+  if (!h || (!obs && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  const size_t ndims = (size_t)h->desc.ndims;
+  if (!(nobs == ndims && nout == ndims)) return INTERPN_HIP_ERR_DIM_MISMATCH;  // regular.rs:153-156
+  if (!out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  for (size_t d = 0; d < nobs; ++d)
+    if (!obs[d] && npoints) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned* flags = nullptr;
+  HIP_TRY(pool_alloc(h->device, (void**)&flags, sizeof(unsigned) * 8));
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(unsigned) * 8, s);
+  for (size_t d = 0; d < ndims && e == hipSuccess; ++d) {
+    if (h->desc.dtype == kF64)
+      e = launch_check_bounds<double>(static_cast<const double*>(obs[d]), npoints, h->desc.bound_lo[d],
+                                      h->desc.bound_hi[d], atol, flags + d, s);
+    else
+      e = launch_check_bounds<float>(static_cast<const float*>(obs[d]), npoints, (float)h->desc.bound_lo[d],
+                                     (float)h->desc.bound_hi[d], (float)atol, flags + d, s);
+  }
+  unsigned host[8] = {0};
+  if (e == hipSuccess) e = hipMemcpyAsync(host, flags, sizeof(host), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  else (void)hipStreamSynchronize(s);
+  pool_free(h->device, flags);
+  if (e != hipSuccess) return hip_fail(e);
+  for (size_t d = 0; d < ndims; ++d) out[d] = host[d] ? 1 : 0;
+  return INTERPN_HIP_OK;
+}
 
 #define DEFINE_BOUNDS(T, SUFFIX)                                                                              \
   int interpn_hip_check_bounds_regular_##SUFFIX(const size_t* dims, size_t ndims, const T* starts,           \

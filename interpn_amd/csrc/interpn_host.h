@@ -50,6 +50,10 @@ struct GridDesc {
   const void* bricks = nullptr;
   int brick_step[2] = {2, 2};
   unsigned brick_nb[3] = {0, 0, 0};
+  // check_bounds limits per dimension, in the element type's arithmetic
+  // (multilinear/regular.rs:160-166: starts + steps*(dims-1), min/max; rectilinear.rs:121-123).
+  double bound_lo[8] = {0};
+  double bound_hi[8] = {0};
   LaunchConfig cfg;
 };
 

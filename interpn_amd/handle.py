@@ -134,6 +134,32 @@ class Interpolator:
         self.eval_device_ptrs([t.data_ptr() for t in obs], out.data_ptr(), n, s)
         return out
 
+    def check_bounds_tensors(self, obs, atol: float, stream=None) -> np.ndarray:
+        """`check_bounds` on torch CUDA tensors against this interpolator's grid: one flag per
+        dimension, True where any coordinate lies outside the grid by `atol` or more
+        (src/multilinear/regular.rs:145-182).  The points stay on the device."""
+        import torch
+
+        want = torch.float64 if self.dtype == np.float64 else torch.float32
+        obs = list(obs)
+        for i, t in enumerate(obs):
+            if not (t.is_cuda and t.is_contiguous() and t.dim() == 1 and t.dtype == want):
+                raise TypeError(f"obs[{i}]: expected a contiguous 1-D {want} CUDA tensor")
+        n = obs[0].numel() if obs else 0
+        for t in obs:
+            if t.numel() != n:
+                raise AssertionError(_lib.strerror(_lib.ERR_DIM_MISMATCH))
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device()).cuda_stream
+        vp = (c_void_p * max(len(obs), 1))()
+        for i, t in enumerate(obs):
+            vp[i] = c_void_p(t.data_ptr())
+        flags = (ctypes.c_uint8 * max(len(obs), 1))()
+        st = _lib.load().interpn_hip_check_bounds_device(self._h, vp, len(obs), n, float(atol), flags, len(obs),
+                                                         c_void_p(int(stream)))
+        _lib.raise_for_status(st)
+        return np.array([bool(flags[i]) for i in range(len(obs))])
+
     def finish(self, stream=None) -> None:
         """Wait for the stream; raise AssertionError("Unrepresentable coordinate value") if any
         device evaluation since the last finish hit a NaN/inf/out-of-range coordinate."""

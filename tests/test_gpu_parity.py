@@ -588,6 +588,39 @@ def test_check_bounds_matches_oracle(oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_check_bounds_on_device_tensors(oracle, dtype):
+    """`check_bounds` with the points already on the device (interpn_hip_check_bounds_device):
+    limits come from the resident grid; same flags as the oracle on the same coordinates, for
+    regular and rectilinear grids, including a violation smaller / larger than atol."""
+    import torch
+
+    import interpn_amd
+
+    rng = np.random.default_rng(3)
+    dims = [10, 20, 30]
+    starts, steps = np.array([0.0, -1.0, 2.0], dtype=dtype), np.array([0.1, 0.2, 0.3], dtype=dtype)
+    grids = [(starts[d] + steps[d] * np.arange(dims[d], dtype=dtype)).astype(dtype) for d in range(3)]
+    vals = rng.uniform(-1, 1, int(np.prod(dims))).astype(dtype)
+    reg = interpn_amd.MultilinearRegular.new(dims, starts, steps, vals)
+    rect = interpn_amd.MulticubicRectilinear.new(grids, vals)
+    atol = 1e-4
+    for violate in (None, (1, 5e-3), (2, -5e-3), (0, 1e-6)):
+        obs = [rng.uniform(float(g[0]), float(g[-1]), 200_003).astype(dtype) for g in grids]
+        if violate is not None:
+            d, eps = violate
+            obs[d][12_345] = (grids[d][-1] + dtype(eps)) if eps > 0 else (grids[d][0] + dtype(eps))
+        obs_t = [torch.from_numpy(o).cuda() for o in obs]
+        want = np.zeros(3, dtype=bool)
+        oracle.check_bounds_regular(dims, starts, steps, obs, dtype(atol), want)
+        assert np.array_equal(reg.check_bounds(obs_t, atol), want)
+        assert np.array_equal(reg.check_bounds(obs, atol), want)  # host form, same answer
+        oracle.check_bounds_rectilinear(grids, obs, dtype(atol), want)
+        assert np.array_equal(rect.check_bounds(obs_t, atol), want)
+        if violate is not None and abs(violate[1]) > atol:
+            assert want[violate[0]]
+
+
 def test_device_tensors_full_size_properties(oracle):
     """BASELINE config 2 at full size (3-D multilinear-regular, 64^3 grid, 1e8 obs) on device
     tensors: (a) a sampled subset is bit-identical to the oracle; (b) evaluating a sub-range
