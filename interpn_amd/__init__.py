@@ -54,6 +54,9 @@ def interpn(
     treated as regular iff every axis has exactly equal spacing (`_check_regular`, :197-203)
     or `assume_regular` is set, and the call dispatches to the matching raw function (:135-192).
     """
+    if len(obs) and _is_cuda_tensor(obs[0]):
+        return _interpn_on_device(obs, grids, vals, method, out, linearize_extrapolation, assume_regular,
+                                  check_bounds, bounds_atol)
     # src/interpn/__init__.py:86-88 (the reference's `out or ...` raises on multi-element arrays;
     # `is None` is what it means)
     out = out if out is not None else np.zeros_like(obs[0])
@@ -104,6 +107,52 @@ def interpn(
         raise ValueError(f"Unsupported interpolation configuration: {dtype}, {is_regular}, {method}")
 
     return out.reshape(outshape)
+
+
+def _is_cuda_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _interpn_on_device(obs, grids, vals, method, out, linearize_extrapolation, assume_regular, check_bounds,
+                       bounds_atol):
+    """`interpn()` for observation points that already live on the GPU (torch CUDA tensors): same
+    rules as the host form (ravelled inputs, dtype from `vals`, exact-spacing regularity test,
+    optional bounds check), the points and the result never cross PCIe.  Returns a tensor."""
+    import torch
+
+    if method not in ("linear", "cubic", "nearest"):
+        raise ValueError(f"Unsupported interpolation configuration: {method}")
+    shape = (out if out is not None else obs[0]).shape
+    obs_t = [x.reshape(-1).contiguous() for x in obs]
+    grids = [np.ascontiguousarray(np.asarray(x).ravel()) for x in grids]
+    vals = vals if _is_cuda_tensor(vals) else np.ascontiguousarray(np.asarray(vals).ravel())
+    dtype = np.dtype(np.float64 if str(vals.dtype).endswith("64") else np.float32)
+    assert str(vals.dtype).endswith(("float64", "float32")), "`interpn` defined only for float32 and float64 data"
+    grids = [g.astype(dtype, copy=False) for g in grids]
+    if _is_cuda_tensor(vals):
+        vals = vals.reshape(-1).contiguous()
+    if assume_regular or _check_regular(grids):
+        starts = np.array([g[0] for g in grids], dtype=dtype)
+        steps = np.array([g[1] - g[0] for g in grids], dtype=dtype)
+        it = Interpolator.regular(method, [len(g) for g in grids], starts, steps, vals,
+                                  linearize_extrapolation=linearize_extrapolation, dtype=dtype)
+    else:
+        it = Interpolator.rectilinear(method, grids, vals, linearize_extrapolation=linearize_extrapolation,
+                                      dtype=dtype)
+    try:
+        if check_bounds and it.check_bounds_tensors(obs_t, bounds_atol).any():
+            raise ValueError("Observation points violate interpolator bounds")
+        if out is not None:
+            if not out.is_contiguous():
+                raise ValueError("out: expected a contiguous CUDA tensor")
+            out_t = out.reshape(-1)
+        else:
+            out_t = torch.empty_like(obs_t[0])
+        it.eval_tensors(obs_t, out_t)
+        it.finish()
+    finally:
+        it.close()
+    return out_t.reshape(shape)
 
 
 def _check_regular(grids) -> bool:

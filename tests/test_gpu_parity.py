@@ -773,3 +773,31 @@ def test_concurrent_host_calls_from_threads(oracle):
         t.join()
     del shared
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic", "nearest"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_interpn_helper_on_device_tensors(oracle, method, kind):
+    """`interpn()` with the observation points as torch CUDA tensors: same dispatch rules as the
+    host form, same bits, the result comes back as a CUDA tensor of the observation shape; the
+    optional bounds check runs on the device too."""
+    import torch
+
+    import interpn_amd
+
+    rng = np.random.default_rng(8)
+    grids = [np.linspace(-1.0, 1.0, 9), np.linspace(0.0, 3.0, 7)]
+    if kind == "rectilinear":
+        grids[1] = np.array([0.0, 0.4, 1.0, 1.1, 2.0, 2.7, 3.0])
+    vals = rng.uniform(-1, 1, (9, 7))
+    xs = rng.uniform(-1.0, 1.0, (50, 40))
+    ys = rng.uniform(0.0, 3.0, (50, 40))
+    host = interpn_amd.interpn([xs, ys], grids, vals, method=method)
+    dev = interpn_amd.interpn([torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()], grids, vals, method=method,
+                              check_bounds=True)
+    assert dev.is_cuda and tuple(dev.shape) == xs.shape
+    assert np.array_equal(dev.cpu().numpy(), host)
+    ys_bad = torch.from_numpy(ys).cuda()
+    ys_bad[3, 3] = 3.5
+    with pytest.raises(ValueError, match="violate interpolator bounds"):
+        interpn_amd.interpn([torch.from_numpy(xs).cuda(), ys_bad], grids, vals, method=method, check_bounds=True)
