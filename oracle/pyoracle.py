@@ -43,8 +43,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        override = os.environ.get("INTERPN_ORACLE_LIB")  # e.g. an ASan/UBSan build of the same source
+        if override:
+            _lib = ctypes.CDLL(override)
+        else:
+            build()
+            _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_strerror.restype = ctypes.c_char_p
         _lib.oracle_strerror.argtypes = [c_int]
     return _lib
