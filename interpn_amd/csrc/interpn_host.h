@@ -73,6 +73,8 @@ constexpr unsigned long long kNoBadIndexHost = ~0ull;  // value of the device fi
 
 // LDS budget for rectilinear axes: keeps 8 workgroups per CU resident (160 KiB / 8).
 constexpr size_t kMaxGridLdsBytes = 20 * 1024;
+// ... or most of the 64 KiB a workgroup gets without opt-in, for 1-D / 2-D kernels with no other LDS use.
+constexpr size_t kMaxGridLdsBytesWide = 60 * 1024;
 
 template <typename T>
 hipError_t launch_linear_regular(const GridDesc& g, const T* const* obs, T* out, size_t npts,

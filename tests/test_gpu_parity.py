@@ -801,3 +801,19 @@ def test_interpn_helper_on_device_tensors(oracle, method, kind):
     ys_bad[3, 3] = 3.5
     with pytest.raises(ValueError, match="violate interpolator bounds"):
         interpn_amd.interpn([torch.from_numpy(xs).cuda(), ys_bad], grids, vals, method=method, check_bounds=True)
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic", "nearest"])
+@pytest.mark.parametrize("axis", [[3000], [6000], [1500, 900], [2800, 2500]], ids=str)
+def test_rectilinear_long_axes(oracle, monkeypatch, method, axis):
+    """1-D / 2-D rectilinear axes of a few thousand coordinates: the axis image (coordinates +
+    bucket tables, 12 bytes per coordinate) is searched in LDS up to 60 KiB in the kernels that
+    have no other LDS use, and through L1/L2 beyond; bricks on and off."""
+    for bricks in (None, "off"):
+        if bricks:
+            monkeypatch.setenv("INTERPN_HIP_BRICKS", bricks)
+        else:
+            monkeypatch.delenv("INTERPN_HIP_BRICKS", raising=False)
+        case = synthetic_case(method, "rectilinear", len(axis), axis, 60_007, 5000 + sum(axis), np.float64,
+                              linearize=True, extrap=0.1)
+        assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
