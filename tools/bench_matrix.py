@@ -10,6 +10,8 @@ import interpn_amd
 from oracle import pyoracle
 
 dev = torch.device("cuda:0")
+DT = np.float32 if os.environ.get("BENCH_MATRIX_DTYPE", "f64") == "f32" else np.float64
+TDT = torch.float32 if DT == np.float32 else torch.float64
 AX = {1: 4096, 2: 512, 3: 64, 4: 24, 5: 12, 6: 8, 7: 6, 8: 5}
 rows = []
 for method in ("linear", "cubic", "nearest"):
@@ -20,15 +22,15 @@ for method in ("linear", "cubic", "nearest"):
             n = AX[N]
             P = 4_000_000 if (method != "cubic" or N <= 4) else 200_000
             rng = np.random.default_rng(N)
-            grids = [np.linspace(-1.0, 1.0, n) for _ in range(N)]
+            grids = [np.linspace(-1.0, 1.0, n).astype(DT) for _ in range(N)]
             if kind == "rectilinear":
-                grids = [g + np.concatenate([[0], (rng.random(n - 2) - 0.5) * 0.4 * (g[1] - g[0]), [0]]) for g in grids]
-            vals = rng.uniform(-1, 1, n ** N)
-            obs_h = [rng.uniform(-1.02, 1.02, P) for _ in range(N)]
+                grids = [(g + np.concatenate([[0], (rng.random(n - 2) - 0.5) * 0.4 * (g[1] - g[0]), [0]])).astype(DT) for g in grids]
+            vals = rng.uniform(-1, 1, n ** N).astype(DT)
+            obs_h = [rng.uniform(-1.02, 1.02, P).astype(DT) for _ in range(N)]
             obs = [torch.from_numpy(o).to(dev) for o in obs_h]
-            out = torch.empty(P, dtype=torch.float64, device=dev)
+            out = torch.empty(P, dtype=TDT, device=dev)
             dims = [n] * N
-            starts = np.full(N, -1.0); steps = np.full(N, grids[0][1] - grids[0][0])
+            starts = np.full(N, -1.0, dtype=DT); steps = np.full(N, grids[0][1] - grids[0][0], dtype=DT)
             if kind == "regular":
                 it = interpn_amd.Interpolator.regular(method, dims, starts, steps, vals, linearize_extrapolation=True)
             else:
@@ -42,7 +44,7 @@ for method in ("linear", "cubic", "nearest"):
             it.close()
             # CPU oracle on a sample
             S = min(P, 200_000 if method != "cubic" or N <= 4 else 20_000)
-            sub = [o[:S] for o in obs_h]; o_cpu = np.zeros(S)
+            sub = [o[:S] for o in obs_h]; o_cpu = np.zeros(S, dtype=DT)
             t0 = time.perf_counter()
             if method == "linear":
                 (pyoracle.linear_regular(dims, starts, steps, vals, sub, o_cpu) if kind == "regular" else pyoracle.linear_rectilinear(grids, vals, sub, o_cpu))
