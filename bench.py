@@ -274,7 +274,7 @@ def main():
                                  "the L2, Infinity-Cache hits included; the excess over the algorithmic 3.2 GB is brick "
                                  "lines of the 5.4 MiB table re-fetched from the 256 MiB Infinity Cache, not HBM re-reads "
                                  "(profiles/README.md)"),
-                "kernel": "interpn::k_linear_brick<double,3,false,true,1,2,2> (bricked grid copy, quad-cooperative gather, 2 points/lane)",
+                "kernel": "interpn::k_linear_brick<double,3,false,true,1,2,2,0> (bricked grid copy, quad-cooperative gather, 2 points/lane)",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_point": BYTES_PER_POINT,
                 "measured_copy_GBps": round(copy_gbps, 1),
