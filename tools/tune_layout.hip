@@ -39,6 +39,15 @@ __device__ __forceinline__ unsigned brick_addr(const Args& a, int i, int j, int 
   return ((unsigned)(bi * a.nbj + bj) * a.nbk + bk) * 16u + (unsigned)((oi * 2 + oj) * 4 + ok);
 }
 
+// 4(j) x 4(k) tiles of one plane i, stepped 3 along j and k (a (j,j+1) x (k,k+1) patch never leaves a
+// tile): 1.78x the grid, always exactly 2 lines per cell (planes i and i+1).  SI = 0 selects it.
+template <>
+__device__ __forceinline__ unsigned brick_addr<0, 0, 0>(const Args& a, int i, int j, int k, int di, int dj, int dk) {
+  const int tj = j / 3, oj = j - tj * 3 + dj;
+  const int tk = k / 3, ok = k - tk * 3 + dk;
+  return ((unsigned)((i + di) * a.nbj + tj) * a.nbk + tk) * 16u + (unsigned)(oj * 4 + ok);
+}
+
 // LAYOUT 0 = row-major; 1 = bricked with steps SI,SJ,SK.  NOSTREAM: synthesise obs, skip store.
 template <int LAYOUT, int SI, int SJ, int SK, int LD, bool NOSTREAM>
 __global__ void __launch_bounds__(256) k_lay(const Args a) {
@@ -309,6 +318,17 @@ static std::vector<double> make_bricks(const std::vector<double>& v, int n, int 
   return b;
 }
 
+static std::vector<double> make_tiles(const std::vector<double>& v, int n, unsigned& ntj, unsigned& ntk) {
+  ntj = (n - 2) / 3 + 1; ntk = (n - 2) / 3 + 1;
+  std::vector<double> b((size_t)n * ntj * ntk * 16, 0.0);
+  for (int i = 0; i < n; ++i) for (unsigned tj = 0; tj < ntj; ++tj) for (unsigned tk = 0; tk < ntk; ++tk)
+    for (int oj = 0; oj < 4; ++oj) for (int ok = 0; ok < 4; ++ok) {
+      int j = tj * 3 + oj, k = tk * 3 + ok;
+      if (j < n && k < n) b[(((size_t)i * ntj + tj) * ntk + tk) * 16 + oj * 4 + ok] = v[((size_t)i * n + j) * n + k];
+    }
+  return b;
+}
+
 static double time_it(const char* name, std::function<void()> fn, size_t P, int reps = 7) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   fn(); CK(hipDeviceSynchronize());
@@ -396,6 +416,40 @@ int main(int argc, char** argv) {
       time_it(name, [&] { hipLaunchKernelGGL((k_coop_cell<true>), dim3(BLK), dim3(256), 0, 0, c); }, P);
       CK(hipFree(dc));
     }
+    return 0;
+  }
+  if (argc > 3 && argv[3][0] == 't') {  // tile layout (2 lines, 1.78x) against bricks (1,2,3) and (2,2,3)
+    a.out = dout;
+    unsigned nbi, nbj, nbk, ntj, ntk;
+    std::vector<double> t = make_tiles(hv, n, ntj, ntk);
+    double* dt; CK(hipMalloc(&dt, t.size() * 8)); CK(hipMemcpy(dt, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    Args ct = a; ct.vals = dt; ct.nbj = ntj; ct.nbk = ntk; ct.out = dout;
+    std::vector<double> b12 = make_bricks(hv, n, 1, 2, 3, nbi, nbj, nbk);
+    double* d12; CK(hipMalloc(&d12, b12.size() * 8)); CK(hipMemcpy(d12, b12.data(), b12.size() * 8, hipMemcpyHostToDevice));
+    Args c12 = a; c12.vals = d12; c12.nbj = nbj; c12.nbk = nbk; c12.out = dout;
+    std::vector<double> b22 = make_bricks(hv, n, 2, 2, 3, nbi, nbj, nbk);
+    double* d22; CK(hipMalloc(&d22, b22.size() * 8)); CK(hipMemcpy(d22, b22.data(), b22.size() * 8, hipMemcpyHostToDevice));
+    Args c22 = a; c22.vals = d22; c22.nbj = nbj; c22.nbk = nbk; c22.out = dout;
+    printf("tables: tiles %.2f MiB, bricks(1,2,3) %.2f MiB, bricks(2,2,3) %.2f MiB\n", t.size() * 8 / 1048576.0, b12.size() * 8 / 1048576.0, b22.size() * 8 / 1048576.0);
+    // reference result for a correctness check of the tile kernel
+    hipLaunchKernelGGL((k_coop<1, 2, 3, false, false, 2>), dim3(BLK), dim3(256), 0, 0, c12); CK(hipDeviceSynchronize());
+    std::vector<double> r1(1 << 20), r2(1 << 20);
+    CK(hipMemcpy(r1.data(), dout, r1.size() * 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL((k_coop<0, 0, 0, false, false, 2>), dim3(BLK), dim3(256), 0, 0, ct); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r2.data(), dout, r2.size() * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t q = 0; q < r1.size(); ++q) bad += r1[q] != r2[q];
+    printf("tile kernel vs bricks(1,2,3): %zu mismatches in the first 2^20 results\n", bad);
+    for (int blk : {2048, 8192, 65536}) {
+      char name[128];
+      snprintf(name, sizeof name, "bricks(1,2,3) nt full      %6d blk", blk);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<1, 2, 3, false, false, 2>), dim3(blk), dim3(256), 0, 0, c12); }, P);
+      snprintf(name, sizeof name, "bricks(2,2,3) nt full      %6d blk", blk);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<2, 2, 3, false, false, 2>), dim3(blk), dim3(256), 0, 0, c22); }, P);
+      snprintf(name, sizeof name, "tiles 4x4(j,k) nt full     %6d blk", blk);
+      time_it(name, [&] { hipLaunchKernelGGL((k_coop<0, 0, 0, false, false, 2>), dim3(blk), dim3(256), 0, 0, ct); }, P);
+    }
+    time_it("bricks(1,2,3) gather-only     2048 blk", [&] { hipLaunchKernelGGL((k_coop<1, 2, 3, true>), dim3(2048), dim3(256), 0, 0, c12); }, P);
+    time_it("tiles 4x4(j,k) gather-only    2048 blk", [&] { hipLaunchKernelGGL((k_coop<0, 0, 0, true>), dim3(2048), dim3(256), 0, 0, ct); }, P);
     return 0;
   }
   if (argc > 3 && argv[3][0] == 's') {  // streaming-rate calibration
