@@ -71,9 +71,11 @@ def run(budget: float, seed: int, max_cases: int = 0):
             # keep the grid and the oracle's work bounded
             cap = 2_000_000
             axis = []
+            # long axes for N <= 2 (LDS-staged up to 60 KiB of axis image, L1/L2 search beyond)
+            axis_cap = 70 if N > 2 or rng.random() < 0.5 else (8000 if N == 1 else 3000)
             for d in range(N):
                 hi = max(fp, int(round(cap ** (1.0 / N))))
-                axis.append(int(rng.integers(fp, min(hi, 70) + 1)))
+                axis.append(int(rng.integers(fp, min(hi, axis_cap) + 1)))
             while np.prod(axis) > cap:
                 axis[int(np.argmax(axis))] = max(fp, axis[int(np.argmax(axis))] // 2)
             work_per_pt = fp ** N
