@@ -34,19 +34,27 @@
  *     (plain `cargo test`).  Results are bit-identical to the Rust code of the same flavour.
  *   - Memory: besides the C-ordered `vals`, a handle may keep a second, re-laid copy of the grid
  *     (cache-line bricks for multilinear N = 2..6, 4 x 4 tiles for multicubic N = 2..4; up to 16x
- *     the grid, bounded by a quarter of the free device memory).  Environment knobs, read at handle
- *     creation / launch, for tuning and testing only:
- *       INTERPN_HIP_BRICKS=off|11|12|22 (linear) |44|24|22|14|11 (cubic)   force / disable a layout
+ *     the grid, bounded by a quarter of the free device memory).  Tuning / testing knobs.  The
+ *     environment is read ONCE PER HANDLE, when it is created (never on the launch path); the
+ *     per-handle options can be changed afterwards with interpn_hip_set_option(h, "<name>", v),
+ *     <name> = the variable's suffix in lower case:
+ *       INTERPN_HIP_BRICKS=off|11|12|22 (linear) |44|24|22|14|11 (cubic)   force / disable a layout (creation only)
  *       INTERPN_HIP_BLOCKS_PER_CU=n     workgroups per CU a persistent launch grid is sized for (default 8)
- *       INTERPN_HIP_ITERS_PER_BLOCK=n   256-lane rows per workgroup of the one-pass brick kernels
- *       INTERPN_HIP_PPL=1               one point per lane in the 3-D multilinear kernel
+ *       INTERPN_HIP_ITERS_PER_BLOCK=n   256-lane rows per workgroup of the one-pass brick kernels (0 = default)
+ *       INTERPN_HIP_PPL=1               one point per lane in the multilinear brick kernels (0 = auto)
  *       INTERPN_HIP_FORCE_GENERIC=1     route every evaluation through the runtime-N kernel
- *       INTERPN_HIP_GENERIC_RUNTIME=1, INTERPN_HIP_GENERIC_VEC=0|1   forms of the recursive-arm kernel
- *       INTERPN_HIP_AXIS_REGS=0|1       3-D rectilinear axes <= 64 coordinates: 0 = search in LDS,
- *                                       1 = across lanes without the lane table (default: with it)
- *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (default 2 Mi)
+ *       INTERPN_HIP_GENERIC_RUNTIME=1   recursive arms: runtime-N form
+ *       INTERPN_HIP_GENERIC_VEC=0|1     recursive arms: one-tree / row-vector form (-1 = auto; the
+ *                                       row-vector form exists only where it compiles without
+ *                                       AGPR or scratch spills, see k_generic.hip)
+ *       INTERPN_HIP_AXIS_REGS=0|1|2     rectilinear axes <= 64 coordinates: 0 = search in LDS,
+ *                                       1 = across lanes without the lane table, 2 = with it (-1 = auto)
+ *       INTERPN_HIP_AXIS_LDS_KB=n       LDS budget of the rectilinear axis image (-1 = default)
+ *       INTERPN_HIP_PERSISTENT=1        C-order regular / nearest kernels: persistent grid
+ *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (0 = default 2 Mi)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
- *                                       (default 1024; 0 = release everything at destroy)
+ *                                       (process-wide, read once; default 1024; 0 = release
+ *                                       everything at destroy)
  *   - Thread safety: all functions are re-entrant.  Device-pointer evaluations on one handle may
  *     run concurrently (the grid is read-only; the sticky first-bad-index word of the handle is
  *     shared by them); host-pointer evaluations on one handle share its staging buffers and are
@@ -212,6 +220,29 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
 /* Tuning knob: workgroups per CU the launch grid is sized for (default 8). */
 int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu);
 
+/* Per-handle tuning / testing options by name (the list is in the header comment above:
+ * "blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic", "generic_runtime",
+ * "generic_vec", "persistent", "axis_lds_kb", "host_chunk").  Their defaults are latched from the
+ * INTERPN_HIP_* environment variables when the handle is created.  INTERPN_HIP_ERR_INVALID_ARGUMENT
+ * for an unknown name or a value out of range.  Not synchronised against evaluations running
+ * concurrently on the same handle. */
+int interpn_hip_set_option(interpn_hip_interp* h, const char* name, long long value);
+int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long long* value);
+
+/* Name of the kernel instantiation the most recent evaluation through this handle launched, in
+ * rocprofv3's spelling without return type and argument list, e.g.
+ * "interpn::k_linear_brick<double, 3, false, true, 1, 2, 2, 0>"; "" before the first launch.
+ * (bench.py reports this instead of a hard-coded string.) */
+int interpn_hip_kernel_name(const interpn_hip_interp* h, char* buf, size_t buflen);
+
+/* Bytes of the re-laid grid copy the handle keeps (0 = the kernels read the C-ordered `vals`);
+ * *step_i / *step_j (optional) receive the layout's brick / tile steps. */
+size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* step_j);
+
+/* Waits only for work enqueued through THIS handle (an event behind its last launch on every
+ * caller stream, plus its own staging streams) before its device memory is recycled; other
+ * streams of the device keep running.  Launches captured into a graph cannot be tracked: the
+ * caller must not replay such a graph after destroying the handle. */
 void interpn_hip_destroy(interpn_hip_interp* h);
 
 /* ------------------------------------------------------------------------------------------

@@ -131,14 +131,18 @@ def _interpn_on_device(obs, grids, vals, method, out, linearize_extrapolation, a
     grids = [g.astype(dtype, copy=False) for g in grids]
     if _is_cuda_tensor(vals):
         vals = vals.reshape(-1).contiguous()
+    # The interpolator lives where the points are (not on whatever device happens to be current).
+    device = obs_t[0].device.index if obs_t[0].device.index is not None else torch.cuda.current_device()
+    if _is_cuda_tensor(vals) and vals.device.index not in (None, device):
+        raise ValueError(f"vals is on {vals.device} but the observation points are on cuda:{device}")
     if assume_regular or _check_regular(grids):
         starts = np.array([g[0] for g in grids], dtype=dtype)
         steps = np.array([g[1] - g[0] for g in grids], dtype=dtype)
         it = Interpolator.regular(method, [len(g) for g in grids], starts, steps, vals,
-                                  linearize_extrapolation=linearize_extrapolation, dtype=dtype)
+                                  linearize_extrapolation=linearize_extrapolation, device=device, dtype=dtype)
     else:
         it = Interpolator.rectilinear(method, grids, vals, linearize_extrapolation=linearize_extrapolation,
-                                      dtype=dtype)
+                                      device=device, dtype=dtype)
     try:
         if check_bounds and it.check_bounds_tensors(obs_t, bounds_atol).any():
             raise ValueError("Observation points violate interpolator bounds")

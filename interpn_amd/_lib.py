@@ -116,6 +116,11 @@ def load() -> ctypes.CDLL:
                                                     POINTER(ctypes.c_uint8), c_size_t, c_void_p]
     lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
     lib.interpn_hip_set_blocks_per_cu.argtypes = [c_void_p, c_int]
+    lib.interpn_hip_set_option.argtypes = [c_void_p, c_char_p, ctypes.c_longlong]
+    lib.interpn_hip_get_option.argtypes = [c_void_p, c_char_p, POINTER(ctypes.c_longlong)]
+    lib.interpn_hip_kernel_name.argtypes = [c_void_p, ctypes.c_char_p, c_size_t]
+    lib.interpn_hip_table_bytes.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.interpn_hip_table_bytes.restype = c_size_t
     lib.interpn_hip_destroy.argtypes = [c_void_p]
     lib.interpn_hip_destroy.restype = None
     _lib = lib

@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -100,9 +101,13 @@ struct DevPool {
   std::vector<unsigned long long*> pinned_words;
 };
 
+// Devices beyond the table are not pooled at all (plain hipMalloc / hipFree): two devices must never
+// share cached blocks.
+bool pooled_device(int device) { return device >= 0 && device < kMaxPoolDevices; }
+
 DevPool& dev_pool(int device) {
   static DevPool pools[kMaxPoolDevices];
-  return pools[device >= 0 && device < kMaxPoolDevices ? device : 0];
+  return pools[pooled_device(device) ? device : 0];
 }
 
 size_t pool_cap_bytes() {
@@ -116,6 +121,7 @@ size_t pool_cap_bytes() {
 
 // The current device must be `device`.
 hipError_t pool_alloc(int device, void** out, size_t bytes) {
+  if (!pooled_device(device)) return hipMalloc(out, bytes < 256 ? 256 : bytes);
   DevPool& pool = dev_pool(device);
   const size_t cls = pool_size_class(bytes);
   {
@@ -154,6 +160,7 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
 // Only for blocks no in-flight work still touches.
 void pool_free(int device, void* p) {
   if (!p) return;
+  if (!pooled_device(device)) { (void)hipFree(p); return; }
   DevPool& pool = dev_pool(device);
   size_t cls = 0;
   {
@@ -174,7 +181,7 @@ void pool_free(int device, void* p) {
 
 hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** flag_host) {
   DevPool& pool = dev_pool(device);
-  {
+  if (pooled_device(device)) {
     std::lock_guard<std::mutex> lk(pool.mu);
     if (!pool.kits.empty()) {
       *stream = pool.kits.back().stream;
@@ -192,7 +199,7 @@ hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** f
 
 void pool_return_kit(int device, hipStream_t stream, unsigned long long* flag_host) {
   DevPool& pool = dev_pool(device);
-  {
+  if (pooled_device(device)) {
     std::lock_guard<std::mutex> lk(pool.mu);
     if (pool.kits.size() < 16 && pool_cap_bytes() > 0) {
       pool.kits.push_back({stream, flag_host});
@@ -205,7 +212,7 @@ void pool_return_kit(int device, hipStream_t stream, unsigned long long* flag_ho
 
 hipError_t pool_take_pinned_word(int device, unsigned long long** word) {
   DevPool& pool = dev_pool(device);
-  {
+  if (pooled_device(device)) {
     std::lock_guard<std::mutex> lk(pool.mu);
     if (!pool.pinned_words.empty()) {
       *word = pool.pinned_words.back();
@@ -219,7 +226,7 @@ hipError_t pool_take_pinned_word(int device, unsigned long long** word) {
 void pool_return_pinned_word(int device, unsigned long long* word) {
   if (!word) return;
   DevPool& pool = dev_pool(device);
-  {
+  if (pooled_device(device)) {
     std::lock_guard<std::mutex> lk(pool.mu);
     if (pool.pinned_words.size() < 64 && pool_cap_bytes() > 0) {
       pool.pinned_words.push_back(word);
@@ -254,6 +261,15 @@ struct interpn_hip_interp {
   unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
   std::mutex finish_mu;
   std::mutex host_mu;  // host-pointer evaluations on one handle share its two lanes: serialised
+  // Caller streams that device-pointer work was enqueued on, each with an event recorded behind
+  // the most recent such launch: interpn_hip_destroy waits for exactly these (and its own lane
+  // streams) instead of stalling the whole device.  `sync_device_at_destroy` is set for launches
+  // that could not be marked (a stream under capture, more than kMaxMarks streams, event failure).
+  static constexpr size_t kMaxMarks = 16;
+  struct StreamMark { hipStream_t stream; hipEvent_t event; };
+  std::mutex marks_mu;
+  std::vector<StreamMark> marks;
+  bool sync_device_at_destroy = false;
   // Host-evaluation workspace (lazily allocated, reused across calls): two pipeline lanes so
   // that the upload of one chunk overlaps the download of the previous one.
   struct HostLane {
@@ -482,17 +498,67 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   return INTERPN_HIP_OK;
 }
 
+// Options by name (interpn_hip_set_option / interpn_hip_get_option, and the INTERPN_HIP_<NAME>
+// environment variables latched at creation).  Returns false for an unknown name or a value out
+// of range; `set == false` reads.
+bool option_access(LaunchConfig& c, const char* name, long long* value, bool set) {
+  struct Opt { const char* name; int* field; long long lo, hi; };
+  const Opt opts[] = {
+      {"blocks_per_cu", &c.blocks_per_cu, 1, 65536},
+      {"iters_per_block", &c.iters_per_block, 0, 65536},
+      {"ppl", &c.ppl, 0, 2},
+      {"axis_regs", &c.axis_regs, -1, 2},
+      {"force_generic", &c.force_generic, 0, 1},
+      {"generic_runtime", &c.generic_runtime, 0, 1},
+      {"generic_vec", &c.generic_vec, -1, 1},
+      {"persistent", &c.persistent, 0, 1},
+      {"axis_lds_kb", &c.axis_lds_kb, -1, 60},
+  };
+  if (!name || !value) return false;
+  if (!strcmp(name, "host_chunk")) {
+    if (set) {
+      if (*value < 0) return false;
+      c.host_chunk = *value;
+    } else {
+      *value = c.host_chunk;
+    }
+    return true;
+  }
+  for (const Opt& o : opts) {
+    if (strcmp(name, o.name)) continue;
+    if (set) {
+      if (*value < o.lo || *value > o.hi) return false;
+      *o.field = (int)*value;
+    } else {
+      *value = *o.field;
+    }
+    return true;
+  }
+  return false;
+}
+
+// The environment is read here, once per handle, and nowhere on the launch path.
+void latch_env(LaunchConfig& c) {
+  static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
+                                      "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk"};
+  for (const char* nm : names) {
+    char var[64] = "INTERPN_HIP_";
+    size_t k = strlen(var);
+    for (const char* q = nm; *q && k + 1 < sizeof(var); ++q) var[k++] = (char)toupper((unsigned char)*q);
+    var[k] = 0;
+    const char* env = getenv(var);
+    if (!env || !*env) continue;
+    char* end = nullptr;
+    long long v = strtoll(env, &end, 10);
+    if (end == env) continue;
+    (void)option_access(c, nm, &v, true);  // out-of-range values are ignored, as before
+  }
+}
+
 int finish_create(interpn_hip_interp* h, const void* vals, size_t nvals, size_t elem, int vals_mem) {
   GridDesc& g = h->desc;
   g.cfg.num_cus = device_num_cus(h->device);
-  if (const char* env = getenv("INTERPN_HIP_BLOCKS_PER_CU")) {
-    int v = atoi(env);
-    if (v >= 1 && v <= 65536) g.cfg.blocks_per_cu = v;
-  }
-  if (const char* env = getenv("INTERPN_HIP_ITERS_PER_BLOCK")) {
-    int v = atoi(env);
-    if (v >= 1 && v <= 65536) g.cfg.iters_per_block = v;
-  }
+  latch_env(g.cfg);
   g.nvals = nvals;
   if (vals_mem == INTERPN_HIP_MEM_DEVICE) {
     g.vals = vals;
@@ -668,8 +734,7 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
                   hipStream_t stream) {
   if (npts == 0) return hipSuccess;
   if (g.method == kNearest) return launch_nearest<T>(g, obs, out, npts, first_bad, stream);
-  const bool force_generic = getenv("INTERPN_HIP_FORCE_GENERIC") != nullptr;  // testing aid
-  if (force_generic || !fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
+  if (g.cfg.force_generic || !fast_path(g)) return launch_generic<T>(g, obs, out, npts, first_bad, stream);
   if (g.method == kLinear)
     return g.kind == kRegular ? launch_linear_regular<T>(g, obs, out, npts, first_bad, stream)
                               : launch_linear_rectilinear<T>(g, obs, out, npts, first_bad, stream);
@@ -679,21 +744,21 @@ hipError_t launch(const GridDesc& g, const T* const* obs, T* out, size_t npts, u
 
 hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size_t npts,
                       unsigned long long* first_bad, hipStream_t stream) {
-  if (g.bricks && npts && g.method == kCubic && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+  if (g.bricks && npts && g.method == kCubic && !g.cfg.force_generic) {
     if (g.dtype == kF64)
       return launch_cubic_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
                                         npts, first_bad, stream);
     return launch_cubic_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
                                      first_bad, stream);
   }
-  if (g.bricks && npts && g.ndims == 2 && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+  if (g.bricks && npts && g.ndims == 2 && !g.cfg.force_generic) {
     if (g.dtype == kF64)
       return launch_linear2_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
                                           npts, first_bad, stream);
     return launch_linear2_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
                                        first_bad, stream);
   }
-  if (g.bricks && npts && !getenv("INTERPN_HIP_FORCE_GENERIC")) {
+  if (g.bricks && npts && !g.cfg.force_generic) {
     if (g.dtype == kF64)
       return launch_linear_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
                                          npts, first_bad, stream);
@@ -762,6 +827,43 @@ int check_bounds_host(const T* lo, const T* hi, size_t ndims, const T* const* ob
   return INTERPN_HIP_OK;
 }
 
+// Remember that device-pointer work was enqueued on `stream` (see interpn_hip_interp::marks).
+// No allocation, copy or synchronisation on the common path (the event of a known stream is
+// re-recorded); a stream under capture is never touched, so eval_device stays graph-capturable.
+void mark_stream(interpn_hip_interp* h, hipStream_t stream) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(h->marks_mu);
+    h->sync_device_at_destroy = true;
+    return;
+  }
+  std::lock_guard<std::mutex> lk(h->marks_mu);
+  if (cs != hipStreamCaptureStatusNone) {
+    h->sync_device_at_destroy = true;  // the graph may replay this launch at any later time
+    return;
+  }
+  for (auto& m : h->marks)
+    if (m.stream == stream) {
+      if (hipEventRecord(m.event, stream) != hipSuccess) { (void)hipGetLastError(); h->sync_device_at_destroy = true; }
+      return;
+    }
+  hipEvent_t ev = nullptr;
+  if (h->marks.size() >= interpn_hip_interp::kMaxMarks ||
+      hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    h->sync_device_at_destroy = true;
+    return;
+  }
+  if (hipEventRecord(ev, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipEventDestroy(ev);
+    h->sync_device_at_destroy = true;
+    return;
+  }
+  h->marks.push_back({stream, ev});
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -828,12 +930,71 @@ int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
   return INTERPN_HIP_OK;
 }
 
+int interpn_hip_set_option(interpn_hip_interp* h, const char* name, long long value) {
+  if (!h || !name) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  return option_access(h->desc.cfg, name, &value, true) ? INTERPN_HIP_OK : INTERPN_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long long* value) {
+  if (!h || !name || !value) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  LaunchConfig c = h->desc.cfg;
+  return option_access(c, name, value, false) ? INTERPN_HIP_OK : INTERPN_HIP_ERR_INVALID_ARGUMENT;
+}
+
+// "interpn::k_linear_brick<double, 3, false, true, 1, 2, 2, 0>" — rocprofv3's spelling of the
+// instantiation, without the return type and the argument list.
+int interpn_hip_kernel_name(const interpn_hip_interp* h, char* buf, size_t buflen) {
+  if (!h || !buf || buflen == 0) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  const KernelTag t = h->desc.tag;
+  if (!t.name) {
+    buf[0] = 0;
+    return INTERPN_HIP_OK;
+  }
+  std::string out = std::string("interpn::") + t.name + "<" + (h->desc.dtype == kF64 ? "double" : "float");
+  for (int k = 0; k < t.nargs; ++k) {
+    out += ", ";
+    if (t.bool_mask & (1u << k)) out += t.args[k] ? "true" : "false";
+    else out += std::to_string(t.args[k]);
+  }
+  out += ">";
+  snprintf(buf, buflen, "%s", out.c_str());
+  return INTERPN_HIP_OK;
+}
+
+// Bytes of the re-laid grid copy the handle keeps (0 = kernels read the C-ordered `vals`), and
+// its layout steps; for reports.
+size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* step_j) {
+  if (!h || !h->desc.bricks) return 0;
+  const GridDesc& g = h->desc;
+  if (step_i) *step_i = g.brick_step[0];
+  if (step_j) *step_j = g.brick_step[1];
+  size_t bytes = 0;
+  unsigned nb[3];
+  if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+  else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
+  else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+  return bytes;
+}
+
 void interpn_hip_destroy(interpn_hip_interp* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
-  // hipFree would wait for the device; blocks go back to the pool only once nothing in flight
-  // (e.g. an eval_device launch on a caller's stream) can still touch them.
-  (void)hipDeviceSynchronize();
+  // Blocks go back to the pool only once nothing in flight can still touch them.  Wait for the
+  // work THIS handle enqueued — the event behind the last launch on every caller stream it was
+  // given, and its own lane streams — not for the whole device: unrelated streams (a training
+  // step on the same GPU) keep running.  Launches that could not be marked fall back to
+  // hipDeviceSynchronize.
+  {
+    std::lock_guard<std::mutex> lk(h->marks_mu);
+    for (auto& m : h->marks) {
+      if (hipEventSynchronize(m.event) != hipSuccess) { (void)hipGetLastError(); h->sync_device_at_destroy = true; }
+      (void)hipEventDestroy(m.event);
+    }
+    h->marks.clear();
+  }
+  for (auto& l : h->lane)
+    if (l.stream && hipStreamSynchronize(l.stream) != hipSuccess) { (void)hipGetLastError(); h->sync_device_at_destroy = true; }
+  if (h->sync_device_at_destroy) (void)hipDeviceSynchronize();
   for (auto& l : h->lane) {
     if (l.stream) pool_return_kit(h->device, l.stream, l.flag_host);
     pool_free(h->device, l.flag_dev);
@@ -860,6 +1021,7 @@ int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
   HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
+  mark_stream(h, static_cast<hipStream_t>(stream));
   return INTERPN_HIP_OK;
 }
 
@@ -976,10 +1138,8 @@ static int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t 
   p.out = out;
   p.nout = nout;
   p.chunk = nout <= kPipelineChunkPoints ? nout : kPipelineChunkPoints;
-  if (const char* env = getenv("INTERPN_HIP_HOST_CHUNK")) {  // testing: force small chunks
-    const long long v = atoll(env);
-    if (v >= 1) p.chunk = (size_t)v < nout ? (size_t)v : nout;
-  }
+  if (h->desc.cfg.host_chunk >= 1)  // testing: force small chunks
+    p.chunk = (size_t)h->desc.cfg.host_chunk < nout ? (size_t)h->desc.cfg.host_chunk : nout;
   p.nchunks = (nout + p.chunk - 1) / p.chunk;
   int st = ensure_lane(h, 0, p.chunk);
   if (st) return st;

@@ -5,16 +5,46 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <initializer_list>
+
 namespace interpn {
 
 enum Method : int { kLinear = 0, kCubic = 1, kNearest = 2 };
 enum Kind : int { kRegular = 0, kRectilinear = 1 };
 enum DType : int { kF64 = 0, kF32 = 1 };
 
+// Per-handle launch options.  Defaults are latched from the environment ONCE, when the handle is
+// created (interpn_abi.hip::latch_env); interpn_hip_set_option changes them afterwards.  Nothing on
+// the launch path reads the environment.
 struct LaunchConfig {
   int num_cus = 256;       // MI355X: 8 XCDs x 32 CUs
   int blocks_per_cu = 8;   // 256-thread workgroups resident per CU that a persistent grid is sized for
   int iters_per_block = 0; // brick kernels: 256-wide iterations per workgroup (0 = the kernel's default)
+  int ppl = 0;             // multilinear brick kernels: points per lane (0 = auto, 1 = scalar streams)
+  int axis_regs = -1;      // rectilinear brick kernels: -1 auto, 0 axes in LDS, 1 lanes + probe sequence, 2 lanes + lane table
+  int force_generic = 0;   // route every evaluation through the runtime-N kernel (testing)
+  int generic_runtime = 0; // recursive arms: keep the runtime-N form (testing)
+  int generic_vec = -1;    // recursive arms: -1 auto, 0 one-tree form, 1 row-vector form where it is compiled
+  int persistent = 0;      // C-order regular / nearest kernels: persistent grid instead of one pass
+  int axis_lds_kb = -1;    // LDS budget for the rectilinear axis image in KiB (-1 = the kernel's default)
+  long long host_chunk = 0;  // points per chunk of the host-pointer pipeline (0 = default)
+};
+
+// What the most recent launch through a handle ran: the kernel template and its arguments in
+// template order after the element type (reported by interpn_hip_kernel_name in the spelling
+// rocprofv3 prints).  Written by the launchers without locking: concurrent evaluations on one
+// handle run the same kernel, so a torn write cannot mix two different answers in practice.
+struct KernelTag {
+  const char* name = nullptr;  // static string, e.g. "k_linear_brick"
+  int nargs = 0;
+  int args[8] = {0};
+  unsigned bool_mask = 0;      // bit k set: args[k] is a bool template parameter
+  void set(const char* nm, std::initializer_list<int> a, unsigned bools) {
+    name = nm;
+    nargs = 0;
+    for (int v : a) args[nargs++] = v;
+    bool_mask = bools;
+  }
 };
 
 struct GridDesc {
@@ -55,6 +85,7 @@ struct GridDesc {
   double bound_lo[8] = {0};
   double bound_hi[8] = {0};
   LaunchConfig cfg;
+  mutable KernelTag tag;
 };
 
 // Brick kernels cover the batch with ONE pass of small workgroups (each owning `iters` consecutive

@@ -31,7 +31,7 @@ hipError_t build_cubic_tiles(const GridDesc& g, void* tiles, hipStream_t stream)
 template <typename T, int N, bool RECT, bool FMA>
 static hipError_t launch_steps(const GridDesc& g, const CubicBrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
-#define GO(SI, SJ) hipLaunchKernelGGL((k_cubic_brick<T, N, RECT, FMA, SI, SJ>), dim3(blocks), dim3(kBlock), lds, stream, a)
+#define GO(SI, SJ) do { g.tag.set("k_cubic_brick", {N, RECT, FMA, SI, SJ}, 0b00110u); hipLaunchKernelGGL((k_cubic_brick<T, N, RECT, FMA, SI, SJ>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
   if (si == 4 && sj == 4) GO(4, 4);
   else if (si == 2 && sj == 4) GO(2, 4);
   else if (si == 2 && sj == 2) GO(2, 2);

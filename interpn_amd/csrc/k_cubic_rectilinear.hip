@@ -8,6 +8,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   RectArgs<T, N> a;
   const size_t lds = fill_rect_args<T, N>(g, obs, out, npts, a);
   const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  g.tag.set("k_cubic_rectilinear", {N, FMA}, 0b10u);
   hipLaunchKernelGGL((k_cubic_rectilinear<T, N, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }

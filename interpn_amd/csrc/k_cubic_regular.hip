@@ -22,6 +22,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
     acc *= (unsigned)g.n[d];
   }
   const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  g.tag.set("k_cubic_regular", {N, FMA}, 0b10u);
   hipLaunchKernelGGL((k_cubic_regular<T, N, FMA>), dim3(blocks), dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }

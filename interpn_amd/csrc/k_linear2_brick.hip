@@ -168,7 +168,7 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax, /*big_lds=*/true);
   const unsigned blocks = g.kind == kRegular ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
-#define GO(RECT, FMA) hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a)
+#define GO(RECT, FMA) do { g.tag.set("k_linear2_brick", {RECT, FMA}, 0b11u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
   else { if (g.fma) GO(true, true); else GO(true, false); }
 #undef GO

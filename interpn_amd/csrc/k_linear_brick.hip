@@ -404,6 +404,7 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
 template <typename T, int N, bool RECT, bool FMA, int PPL, int AXR>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
+  g.tag.set("k_linear_brick", {N, RECT, FMA, si == 1 ? 1 : 2, (si == 1 && sj == 1) ? 1 : 2, PPL, AXR}, 0b0000110u);
   if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
   else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
   else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
@@ -411,9 +412,9 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
 }
 
 // Axes small enough to sit one coordinate per lane (3-D only: the instantiation count is kept
-// bounded); INTERPN_HIP_AXIS_REGS=0 keeps them in LDS (testing).
-// 0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane tables.
-// INTERPN_HIP_AXIS_REGS=0|1|2 overrides (testing; 2 falls back to 1 when a table is missing).
+// bounded).  0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane
+// tables.  The handle's `axis_regs` option (latched from INTERPN_HIP_AXIS_REGS at creation)
+// overrides: 0 | 1 | 2, where 2 falls back to 1 when a table is missing.
 template <int N>
 static int axes_in_lanes(const GridDesc& g) {
   if (N != 3 || g.kind != kRectilinear) return 0;
@@ -423,10 +424,8 @@ static int axes_in_lanes(const GridDesc& g) {
     tables = tables && g.axis_ltab_off[d] != 0;
   }
   int mode = tables ? 2 : 1;
-  if (const char* env = getenv("INTERPN_HIP_AXIS_REGS")) {
-    if (env[0] == '0') mode = 0;
-    else if (env[0] == '1') mode = 1;
-  }
+  if (g.cfg.axis_regs == 0) mode = 0;
+  else if (g.cfg.axis_regs == 1) mode = 1;
   return mode;
 }
 
@@ -482,12 +481,11 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   size_t axis_lds = 0;
   if (g.kind == kRectilinear) axis_lds = fill_axis_args<T, N>(g, a.ax);
   // Two points per lane (vector coordinate/result accesses) for the 3-D shape when every stream is
-  // aligned to 2*sizeof(T); INTERPN_HIP_PPL=1 forces the scalar form (tuning / testing).
+  // aligned to 2*sizeof(T); the handle's `ppl` option = 1 forces the scalar form (tuning / testing).
   if constexpr (N == 3) {
     bool aligned = (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0;
     for (int d = 0; d < N; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
-    const char* env = getenv("INTERPN_HIP_PPL");
-    if (aligned && !(env && env[0] == '1')) return launch_kind<T, N, 2>(g, a, lds, axis_lds, npts, stream);
+    if (aligned && g.cfg.ppl != 1) return launch_kind<T, N, 2>(g, a, lds, axis_lds, npts, stream);
   }
   return launch_kind<T, N, 1>(g, a, lds, axis_lds, npts, stream);
 }

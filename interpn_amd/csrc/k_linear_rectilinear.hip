@@ -13,6 +13,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   const size_t lds = fill_rect_args<T, N>(g, obs, out, npts, a);
   constexpr int U = INTERPN_U_LINEAR;
   const unsigned blocks = grid_blocks(npts, U, g.cfg);
+  g.tag.set("k_linear_rectilinear", {N, FMA, U}, 0b010u);
   hipLaunchKernelGGL((k_linear_rectilinear<T, N, FMA, U>), dim3(blocks), dim3(kBlock), lds, stream, a);
   return hipGetLastError();
 }

@@ -28,7 +28,8 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
     acc *= (unsigned)g.n[d];
   }
   constexpr int U = INTERPN_U_LINEAR;
-  const unsigned blocks = getenv("INTERPN_HIP_PERSISTENT") ? grid_blocks(npts, U, g.cfg) : one_pass_blocks(npts, U);
+  const unsigned blocks = g.cfg.persistent ? grid_blocks(npts, U, g.cfg) : one_pass_blocks(npts, U);
+  g.tag.set("k_linear_regular", {N, FMA, U}, 0b010u);
   hipLaunchKernelGGL((k_linear_regular<T, N, FMA, U>), dim3(blocks), dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }

@@ -87,8 +87,8 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);
-  const unsigned blocks = (g.kind == kRegular && !getenv("INTERPN_HIP_PERSISTENT")) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
-#define GO(RECT, FMA) hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a)
+  const unsigned blocks = (g.kind == kRegular && !g.cfg.persistent) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
+#define GO(RECT, FMA) do { g.tag.set("k_nearest", {N, RECT, FMA}, 0b110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
   else GO(true, true);  // no FMA site in the rectilinear path
 #undef GO

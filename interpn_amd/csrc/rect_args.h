@@ -25,10 +25,7 @@ inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds
     ax.lscale[d] = (T)g.axis_lscale[d];
   }
   size_t cap = (big_lds && N <= 2) ? kMaxGridLdsBytesWide : kMaxGridLdsBytes;
-  if (const char* env = getenv("INTERPN_HIP_AXIS_LDS_KB")) {  // tuning: LDS budget for the axis image
-    const long v = atol(env);
-    if (v >= 0 && v <= 60) cap = (size_t)v * 1024;
-  }
+  if (g.cfg.axis_lds_kb >= 0 && g.cfg.axis_lds_kb <= 60) cap = (size_t)g.cfg.axis_lds_kb * 1024;  // tuning knob
   ax.use_lds = g.axis_image_bytes <= cap;
   return ax.use_lds ? g.axis_image_bytes : 0;
 }

@@ -24,6 +24,7 @@ class Interpolator:
         self.dtype = np.dtype(dtype)
         self._ndims = ndims
         self._keepalive = keepalive  # e.g. a torch tensor whose storage the handle borrows
+        self._last_stream = None     # stream of the most recent eval_tensors (finish() waits on it)
 
     # -- construction ---------------------------------------------------------------------
     @staticmethod
@@ -87,6 +88,38 @@ class Interpolator:
     def set_blocks_per_cu(self, n: int) -> None:
         _lib.raise_for_status(_lib.load().interpn_hip_set_blocks_per_cu(self._h, int(n)))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle tuning / testing option (`interpn_hip_set_option`; names in include/interpn_hip.h)."""
+        _lib.raise_for_status(_lib.load().interpn_hip_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_longlong(0)
+        _lib.raise_for_status(_lib.load().interpn_hip_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def kernel_name(self) -> str:
+        """Instantiation the most recent evaluation launched, in rocprofv3's spelling ("" before any)."""
+        buf = ctypes.create_string_buffer(256)
+        _lib.raise_for_status(_lib.load().interpn_hip_kernel_name(self._h, buf, len(buf)))
+        return buf.value.decode()
+
+    def table_layout(self):
+        """(bytes, step_i, step_j) of the re-laid grid copy the kernels read; (0, 0, 0) = C order."""
+        si, sj = ctypes.c_int(0), ctypes.c_int(0)
+        nbytes = _lib.load().interpn_hip_table_bytes(self._h, ctypes.byref(si), ctypes.byref(sj))
+        return int(nbytes), int(si.value), int(sj.value)
+
+    def _check_same_device(self, what: str, tensor) -> None:
+        """Kernels run under the handle's device with the grid resident there: a tensor on another
+        GPU would be read across devices on a stream of the wrong device."""
+        idx = tensor.device.index
+        if idx is None:
+            import torch
+
+            idx = torch.cuda.current_device()
+        if idx != self.device():
+            raise ValueError(f"{what} is on cuda:{idx} but this interpolator lives on cuda:{self.device()}")
+
     def eval_host(self, obs, out: np.ndarray) -> np.ndarray:
         """`.interp(obs, out)` on host arrays (synchronous)."""
         lib = _lib.load()
@@ -120,18 +153,22 @@ class Interpolator:
         for i, t in enumerate(obs):
             if not (t.is_cuda and t.is_contiguous() and t.dim() == 1 and t.dtype == want):
                 raise TypeError(f"obs[{i}]: expected a contiguous 1-D {want} CUDA tensor")
+            self._check_same_device(f"obs[{i}]", t)
         n = obs[0].numel() if obs else 0
         for t in obs:
             if t.numel() != n:
                 raise AssertionError("Dimension mismatch")
         if out is None:
-            out = torch.empty(n, dtype=want, device=obs[0].device)
+            out = torch.empty(n, dtype=want, device=torch.device("cuda", self.device()))
         elif not (out.is_cuda and out.is_contiguous() and out.dim() == 1 and out.dtype == want):
             raise TypeError(f"out: expected a contiguous 1-D {want} CUDA tensor")
         elif out.numel() != n:
             raise AssertionError("Dimension mismatch")
-        s = stream if stream is not None else torch.cuda.current_stream(obs[0].device).cuda_stream
+        else:
+            self._check_same_device("out", out)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device()).cuda_stream
         self.eval_device_ptrs([t.data_ptr() for t in obs], out.data_ptr(), n, s)
+        self._last_stream = s
         return out
 
     def check_bounds_tensors(self, obs, atol: float, stream=None) -> np.ndarray:
@@ -145,6 +182,7 @@ class Interpolator:
         for i, t in enumerate(obs):
             if not (t.is_cuda and t.is_contiguous() and t.dim() == 1 and t.dtype == want):
                 raise TypeError(f"obs[{i}]: expected a contiguous 1-D {want} CUDA tensor")
+            self._check_same_device(f"obs[{i}]", t)
         n = obs[0].numel() if obs else 0
         for t in obs:
             if t.numel() != n:
@@ -162,8 +200,12 @@ class Interpolator:
 
     def finish(self, stream=None) -> None:
         """Wait for the stream; raise AssertionError("Unrepresentable coordinate value") if any
-        device evaluation since the last finish hit a NaN/inf/out-of-range coordinate."""
+        device evaluation since the last finish hit a NaN/inf/out-of-range coordinate.  `stream`
+        defaults to the one the most recent `eval_tensors` was enqueued on (else torch's current
+        stream of the handle's device)."""
         lib = _lib.load()
+        if stream is None and self._last_stream is not None:
+            stream = self._last_stream
         if stream is None:
             try:
                 import torch

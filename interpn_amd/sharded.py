@@ -91,18 +91,27 @@ class ShardedInterpolator:
         sentinel = np.iinfo(np.int64).max
         local = sentinel
         msg = "Unrepresentable coordinate value"
+        failure = None  # anything that is not the reference's per-point error (HIP fault, OOM, ...)
         try:
             self._interp.finish()
         except AssertionError as e:
             local = self._offset + int(getattr(e, "first_bad_index", 0))
             msg = str(e)
+        except Exception as e:  # noqa: BLE001 - every rank must still reach the collective below
+            failure = e
         if self.world > 1:
-            t = torch.tensor([local], dtype=torch.int64)
+            # One MIN all-reduce of (-failed, first bad index): a rank that failed outright still
+            # takes part, so the others never hang in the collective; -1 wins the MIN.
+            t = torch.tensor([-1 if failure is not None else 0, local], dtype=torch.int64)
             backend = dist.get_backend()
             if backend == "nccl":
                 t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            local = int(t.item())
+            any_failed, local = int(t[0].item()) < 0, int(t[1].item())
+            if failure is None and any_failed:
+                failure = RuntimeError("another rank failed during the sharded evaluation")
+        if failure is not None:
+            raise failure
         if local != sentinel:
             err = AssertionError(msg)
             err.first_bad_index = local

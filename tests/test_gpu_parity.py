@@ -82,6 +82,41 @@ def test_recursive_arms(oracle, monkeypatch, method, kind, n, linearize, form, d
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("vec", ["0", "1"], ids=["onetree", "rowvec"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("method,n", [("linear", 7), ("linear", 8), ("cubic", 5), ("cubic", 6), ("cubic", 7), ("cubic", 8)])
+def test_recursive_arm_forms(oracle, monkeypatch, method, kind, n, vec, dtype):
+    """Both forms of k_generic_n (one tree per leaf element / FP trees side by side over one row
+    load) for every shape of the recursive arms.  The row-vector form is compiled only where it
+    fits the register file (k_generic.hip::generic_vec_ok, asserted on the build by
+    tests/test_build_resources.py); asking for it elsewhere must fall back to the one-tree form,
+    never to a spilled kernel (round 1: f64 cubic regular N = 8 returned wrong results)."""
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_GENERIC_VEC", vec)
+    m = 2 if method == "linear" else 4
+    axis = [m + ((d + 1) % 2) for d in range(n)] if n < 8 or method == "linear" else [4] * 8
+    nobs = 1501 if n < 8 or method == "linear" else 301
+    case = synthetic_case(method, kind, n, axis, nobs, 900 + n, dtype, linearize=True, extrap=0.3)
+    assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+    # which instantiation ran: query it from a handle built the same way
+    cv = lambda a: np.ascontiguousarray(a, dtype=dtype)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular(method, case.dims, cv(case.starts), cv(case.steps), cv(case.vals), True)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(method, [cv(g) for g in case.grids], cv(case.vals), True)
+    out = it.eval_host([cv(o) for o in case.obs], np.zeros(nobs, dtype=dtype))
+    name = it.kernel_name()
+    it.close()
+    assert_parity(case, out, run_oracle(oracle, case, True))
+    assert name.startswith("interpn::k_generic_n<"), name
+    f64_cubic = method == "cubic" and dtype == np.float64
+    spilled = f64_cubic and ((kind == "regular" and n >= 7) or (kind == "rectilinear" and n >= 6))
+    want_vec = vec == "1" and not spilled
+    assert name.endswith(", true>") == want_vec, (name, vec)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 def test_recursive_arm_cubic_8d(oracle, kind, linearize, dtype):

@@ -11,7 +11,7 @@ from oracle import pyoracle
 from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
-         "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC")
+         "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT")
 LAYOUTS_LIN = [None, "off", "11", "12", "22"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -96,7 +96,11 @@ def run(budget: float, seed: int, max_cases: int = 0):
             if rng.random() < 0.1: env["INTERPN_HIP_GENERIC_RUNTIME"] = "1"
             if rng.random() < 0.2: env["INTERPN_HIP_HOST_CHUNK"] = str(int(rng.integers(1, max(2, nobs))))
             if rng.random() < 0.2: env["INTERPN_HIP_ITERS_PER_BLOCK"] = str(int(rng.choice([1, 2, 3, 8, 64])))
-            if rng.random() < 0.4: env["INTERPN_HIP_AXIS_REGS"] = str(int(rng.integers(0, 2)))
+            if rng.random() < 0.4: env["INTERPN_HIP_AXIS_REGS"] = str(int(rng.integers(0, 3)))
+            # both forms of the recursive-arm kernel wherever the row-vector form is compiled
+            # (k_generic.hip::generic_vec_ok; elsewhere the option falls back to the one-tree form)
+            if rng.random() < 0.5: env["INTERPN_HIP_GENERIC_VEC"] = str(int(rng.integers(0, 2)))
+            if rng.random() < 0.1: env["INTERPN_HIP_PERSISTENT"] = "1"
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(env)
