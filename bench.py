@@ -1,17 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpoints/s (f64) of 3-D multilinear-regular interpolation, 64^3 grid,
-1e8 random observation points per GPU (BASELINE.json configs[1]), plus the achieved fraction of
-the HBM roofline for the kernel and the CPU oracle timed beside it.
+"""Headline benchmark: Mpoints/s (f64) of 3-D multilinear-regular interpolation on random
+observation points, plus the achieved fraction of the HBM roofline for the kernel and the CPU
+oracle timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+* `--gpus 1` (default): BASELINE.json configs[1] — 64^3 f64 grid, 1e8 random obs on one MI355X.
+* `--gpus N` (N > 1): BASELINE.json configs[4] — 128^3 f64 grid, 1e8 obs PER RANK (8e8 at N = 8),
+  observation points sharded contiguously, the grid generated on rank 0 and replicated by ONE RCCL
+  broadcast, no collective in the timed loop (weak scaling).  When no launcher has set WORLD_SIZE
+  this process only SPAWNS the N ranks (fresh child processes, created before anything touches a
+  GPU here) and relays rank 0's line; under `python -m torch.distributed.run ... bench.py --gpus N`
+  it is one of the ranks.
+* `--workload cfg2|cfg5` overrides the choice (e.g. the cfg5 shard on one GPU).
 
 A step is one pass of the hot path over one batch: one `interpn_hip_eval_device` launch over the
-rank's 1e8 device-resident points followed by the status check (`interpn_hip_finish`).  Inputs
-are synthetic: axes linspace(-1,1,64), vals U(-1,1), obs i.i.d. uniform over
-the grid extent, unordered.  With N > 1 the observation batch is sharded (weak scaling: 1e8
-points per rank), the grid is broadcast once from rank 0 over RCCL, and there is no collective
-in the timed loop.  Rank 0 prints ONE JSON line.
+rank's device-resident points followed by the status check (`interpn_hip_finish`).  Inputs are
+synthetic: axes linspace(-1,1,n), vals U(-1,1), obs i.i.d. uniform over the
+grid extent, unordered.  EXACTLY K steps are timed between barrier + synchronize pairs; rank 0
+prints ONE JSON line.  At N = 1 the line also carries
+  roofline.sustained   the same launch repeated for >= 0.5 s (K may be as small as 20 = 26 ms),
+  roofline.ablation    stream-only / gather-only variants of the same kernel source (the L2-bound
+                       ceiling argument of DESIGN.md section 4.1, reproducible by the driver),
+  configs[]            every single-GPU BASELINE configuration (cfg2, cfg3, cfg4 with both
+                       linearize flags, the cfg5 shard): kernel time, roofline fraction, the kernel
+                       name queried from the handle, and a bitwise check of sampled points against
+                       the CPU oracle (outside every timed region),
+  cpu_baseline         the oracle (a port: the Rust reference cannot be built here) on host cores.
 """
 
 from __future__ import annotations
@@ -19,6 +34,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,44 +45,207 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-NDIMS = 3
-GRID_N = 64
-BYTES_PER_POINT = 8 * (NDIMS + 1)  # read 3 f64 coordinates + write 1 f64 result
+METRIC = "Mpoints/sec (f64) per GPU + achieved HBM GB/s vs roofline, 3D linear-regular"
+WORKLOADS = {
+    # name: (grid points per axis, BASELINE.json entry)
+    "cfg2": (64, "BASELINE configs[1]"),
+    "cfg5": (128, "BASELINE configs[4] shard"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg5"],
+                    help="auto = cfg2 on one GPU, cfg5 (128^3, 1e8 obs per rank) on several")
     ap.add_argument("--points", type=int, default=100_000_000, help="observation points per GPU")
-    ap.add_argument("--grid", type=int, default=GRID_N, help="grid points per axis")
+    ap.add_argument("--grid", type=int, default=0, help="grid points per axis (0 = the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="points for the CPU baseline (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration table (N = 1)")
+    ap.add_argument("--no-ablate", action="store_true", help="skip the stream-only / gather-only ablation (N = 1)")
+    ap.add_argument("--sustain-seconds", type=float, default=0.5)
     # Test aids for a 1-GPU box: run the multi-rank control flow with every rank on cuda:0 over
     # gloo (RCCL refuses two ranks on one device).  The driver never passes these.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0)
+    # CPU test of the spawn / rendezvous path only (tests/test_bench_spawn.py): no GPU work, every
+    # rank joins a gloo group and rank 0 prints who took part.  Not a benchmark.
+    ap.add_argument("--dry-run", action="store_true")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(dims, starts, steps, vals, obs_dev, sample_points):
+# ---------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks.  Nothing in this function (or before it) touches HIP.
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """Start `args.gpus` child processes of this script, one per GPU, as a launcher would
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0's stdout (the JSON line) is ours.
+    Returns the largest exit code.  Children are fresh processes made by fork+exec from a parent
+    that has not initialised the GPU."""
+    world = args.gpus
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "INTERPN_BENCH_SPAWNED": "1"})
+        out = None if r == 0 else subprocess.DEVNULL  # only rank 0 prints the record
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    deadline = time.time() + args.spawn_timeout
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                rc = max(rc, abs(code))
+                if code != 0:  # one rank failed: the others would wait in a collective for ever
+                    deadline = min(deadline, time.time() + 20.0)
+        if pending and time.time() > deadline:
+            for p in pending:
+                p.kill()  # exact PIDs we started
+            rc = max(rc, 124)
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+def make_axes(n, ndims, rectilinear, rng):
+    g = np.linspace(-1.0, 1.0, n)
+    step = g[1] - g[0]
+    grids = []
+    for _ in range(ndims):
+        gg = g.copy()
+        if rectilinear:  # interior nodes jittered by up to a quarter step (SURVEY.md section 8(d))
+            j = (rng.random(n) - 0.5) * 0.5 * step
+            j[0] = j[-1] = 0.0
+            gg = gg + j
+            assert np.all(np.diff(gg) > 0)
+        grids.append(gg)
+    return grids, step
+
+
+def time_launches(torch, it, obs, out, launches=0, seconds=0.0, finish_each=False):
+    """Run `launches` evaluations (or as many as fill `seconds`), each bracketed by HIP events on
+    the launch stream (torch's current stream is what the ABI is given).  Returns per-launch ms."""
+    ms = []
+    t_end = time.perf_counter() + seconds
+    pending = []
+    n = 0
+    while (launches and n < launches) or (not launches and (time.perf_counter() < t_end or n < 8)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        it.eval_tensors(obs, out)
+        b.record()
+        if finish_each:
+            it.finish()
+        pending.append((a, b))
+        n += 1
+        if len(pending) >= 64 or finish_each:
+            if not finish_each:
+                it.finish()
+            ms += [x.elapsed_time(y) for x, y in pending]
+            pending = []
+    it.finish()
+    ms += [x.elapsed_time(y) for x, y in pending]
+    return ms
+
+
+def oracle_eval(spec, sub):
+    """CPU oracle on a small sample (the checker; never the thing measured on the GPU side)."""
+    from oracle import pyoracle
+
+    want = np.zeros(sub[0].size)
+    if spec["method"] == "linear" and spec["kind"] == "regular":
+        pyoracle.linear_regular(spec["dims"], spec["starts"], spec["steps"], spec["vals"], sub, want)
+    elif spec["method"] == "linear":
+        pyoracle.linear_rectilinear(spec["grids"], spec["vals"], sub, want)
+    elif spec["kind"] == "regular":
+        pyoracle.cubic_regular(spec["dims"], spec["starts"], spec["steps"], spec["vals"], spec["linearize"], sub, want)
+    else:
+        pyoracle.cubic_rectilinear(spec["grids"], spec["vals"], spec["linearize"], sub, want)
+    return want
+
+
+def build_spec(method, kind, n, ndims, linearize, seed):
+    rng = np.random.default_rng(seed)
+    grids, step = make_axes(n, ndims, kind == "rectilinear", rng)
+    return {"method": method, "kind": kind, "n": n, "ndims": ndims, "linearize": bool(linearize),
+            "dims": [n] * ndims, "starts": np.full(ndims, -1.0), "steps": np.full(ndims, step), "grids": grids,
+            "vals": rng.uniform(-1.0, 1.0, n**ndims)}
+
+
+def make_interp(interpn_amd, spec, device, vals=None):
+    vals = spec["vals"] if vals is None else vals
+    if spec["kind"] == "regular":
+        return interpn_amd.Interpolator.regular(spec["method"], spec["dims"], spec["starts"], spec["steps"], vals,
+                                                spec["linearize"], device, np.float64)
+    return interpn_amd.Interpolator.rectilinear(spec["method"], spec["grids"], vals, spec["linearize"], device,
+                                                np.float64)
+
+
+def config_row(torch, interpn_amd, name, spec, obs, out, device, seconds, check_points=100_000):
+    """One row of the per-configuration table: kernel time over >= `seconds` of launches, roofline
+    fraction, kernel name from the handle, sampled bitwise check against the oracle."""
+    it = make_interp(interpn_amd, spec, device)
+    P = obs[0].numel()
+    for _ in range(3):
+        it.eval_tensors(obs, out)
+    it.finish()
+    ms = time_launches(torch, it, obs, out, seconds=seconds)
+    kernel_ms = float(np.mean(ms))
+    bpp = 8 * (spec["ndims"] + 1)
+    achieved = P * bpp / (kernel_ms * 1e-3) / 1e9
+    tbytes, si, sj = it.table_layout()
+    gen = torch.Generator(device=obs[0].device)
+    gen.manual_seed(99)
+    idx = torch.randint(0, P, (check_points,), device=obs[0].device, generator=gen)
+    sub = [o[idx].cpu().numpy() for o in obs]
+    same = bool(np.array_equal(out[idx].cpu().numpy(), oracle_eval(spec, sub)))
+    row = {"config": name, "points": P, "grid": spec["dims"], "kernel": it.kernel_name(),
+           "table_MiB": round(tbytes / 2**20, 2), "layout_steps": [si, sj],
+           "launches": len(ms), "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(float(np.min(ms)), 4),
+           "Mpoints_per_s": round(P / kernel_ms / 1e3, 1), "algorithmic_bytes_per_point": bpp,
+           "achieved_GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+           "oracle_check": {"points": check_points, "bitwise_equal": same}}
+    it.close()
+    return row
+
+
+def cpu_baseline(spec, obs_dev, sample_points):
     """Time the CPU oracle (a port of the reference's algorithm; the Rust reference cannot be
     built here) single-threaded on a bounded sample of the same workload."""
     from oracle import pyoracle
 
-    # calibrate on 1e6 points, then size the sample for ~12 s unless told otherwise
+    dims, starts, steps, vals = spec["dims"], spec["starts"], spec["steps"], spec["vals"]
     cal = 1_000_000
     sub = [o[:cal].cpu().numpy() for o in obs_dev]
     out = np.zeros(cal)
     t0 = time.perf_counter()
     pyoracle.linear_regular(dims, starts, steps, vals, sub, out)
     rate = cal / (time.perf_counter() - t0)
-    n = sample_points or int(min(obs_dev[0].numel(), max(cal, rate * 12.0)))
+    n = sample_points or int(min(obs_dev[0].numel(), max(cal, rate * 4.0)))  # ~4 s per pass, 3 passes
     sub = [o[:n].cpu().numpy() for o in obs_dev]
     out = np.zeros(n)
     best = float("inf")
-    for _ in range(4):  # ~10 s of single-thread CPU work at 1e8 points
+    for _ in range(3):
         t0 = time.perf_counter()
         pyoracle.linear_regular(dims, starts, steps, vals, sub, out)
         best = min(best, time.perf_counter() - t0)
@@ -74,7 +254,7 @@ def cpu_baseline(dims, starts, steps, vals, obs_dev, sample_points):
         "unit": "Mpoints/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {n} points of rank 0's batch, best of 4, single thread, "
+        "sample": f"first {n} points of rank 0's batch, best of 3 passes, single thread, "
                   f"-O3 -march=x86-64-v3 -ffp-contract=off, fma flavour",
     }
     # Not reference behaviour (the reference is single-threaded): the same port on every host
@@ -126,8 +306,105 @@ def cpu_baseline(dims, starts, steps, vals, obs_dev, sample_points):
     return rec, out, n
 
 
-def main():
-    args = parse()
+def committed_traffic(kernel, points, grid, table_bytes):
+    """HBM/fabric bytes per launch from the committed rocprofv3 --pmc passes (separate runs, as the
+    guide prescribes) — reported only if that profile was taken on the SAME kernel instantiation,
+    table layout, grid and batch as this run; otherwise null."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f)
+    except Exception:
+        return None, "no committed traffic profile"
+    same = (tj.get("points") == points and tj.get("grid") == grid and tj.get("kernel") == kernel and
+            tj.get("table_bytes") == table_bytes)
+    if not same:
+        return None, (f"committed profile is for kernel={tj.get('kernel')!r} grid={tj.get('grid')} "
+                      f"table_bytes={tj.get('table_bytes')}: does not match this run, not reported")
+    return tj.get("hbm_bytes_per_launch"), tj.get("source", "profiles/traffic_latest.json")
+
+
+def run_ablation(torch, spec, obs, out, it, seconds):
+    """Stream-only and gather-only variants of the product kernel (same source, a template flag;
+    tools/ablate_linear3d.hip), on the same table layout the handle chose.  Outputs of these
+    variants are meaningless by construction; only their durations are reported."""
+    import ctypes
+
+    path = os.path.join(ROOT, "tools", "libinterpn_ablate.so")
+    if not os.path.exists(path):
+        return {"error": "tools/libinterpn_ablate.so not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    lib = ctypes.CDLL(path)
+    lib.ablate_create.restype = ctypes.c_void_p
+    lib.ablate_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    lib.ablate_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.ablate_destroy.argtypes = [ctypes.c_void_p]
+    _, si, sj = it.table_layout()
+    if not si:
+        return {"error": "the handle reads the C-ordered grid: no brick kernel to ablate"}
+    dev = obs[0].device
+    vals_dev = torch.from_numpy(spec["vals"]).to(dev)
+    h = lib.ablate_create(ctypes.c_void_p(vals_dev.data_ptr()), spec["n"], si, sj, float(spec["steps"][0]))
+    if not h:
+        return {"error": "ablate_create failed"}
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    P = obs[0].numel()
+    res = {}
+    try:
+        for mode, key in ((0, "full_ms"), (1, "stream_only_ms"), (2, "gather_only_ms")):
+            ms = []
+            t_end = time.perf_counter() + seconds
+            k = 0
+            while time.perf_counter() < t_end or k < 8:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = lib.ablate_launch(h, mode, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(),
+                                       P, ctypes.c_void_p(stream))
+                b.record()
+                if rc != 0:
+                    return {"error": f"ablate_launch mode {mode} failed with HIP error {rc}"}
+                torch.cuda.synchronize()
+                if k >= 2:
+                    ms.append(a.elapsed_time(b))
+                k += 1
+            res[key] = round(float(np.mean(ms)), 4)
+    finally:
+        lib.ablate_destroy(h)
+    res["note"] = ("same kernel source as the product path (interpn_amd/csrc/linear_brick.h, template flag ABL): "
+                   "stream_only = coordinates read + result written, cell values synthesised (no table access); "
+                   "gather_only = table gathers + arithmetic, coordinates synthesised, nothing stored; "
+                   "full = the unmodified kernel through the harness (cross-check of kernel_ms)")
+    return res
+
+
+# ---------------------------------------------------------------------------------------------
+def dry_run(args):
+    """Spawn / rendezvous check without a GPU: what the launcher contract gives every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("INTERPN_BENCH_DRY_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        world = dist.get_world_size()
+        got = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank, int(os.environ.get("LOCAL_RANK", "-1"))], dtype=torch.int64))
+        dist.barrier()
+        ranks = [[int(x[0]), int(x[1])] for x in got]
+        dist.destroy_process_group()
+    else:
+        ranks = [[0, int(os.environ.get("LOCAL_RANK", "0"))]]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks, "steps": args.steps,
+                          "spawned": bool(os.environ.get("INTERPN_BENCH_SPAWNED"))}), flush=True)
+
+
+def worker(args):
+    if args.dry_run:
+        return dry_run(args)
     import torch
     import torch.distributed as dist
 
@@ -143,6 +420,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: interpn_amd has no CPU path")
     if args.same_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -150,20 +429,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        world = dist.get_world_size()  # what the process group actually is
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
+    workload = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg5")
+    n = args.grid or WORKLOADS[workload][0]
     P = args.points
-    n = args.grid
-    g = np.linspace(-1.0, 1.0, n)
-    dims = [n] * NDIMS
-    starts = np.full(NDIMS, -1.0)
-    steps = np.full(NDIMS, g[1] - g[0])
+    NDIMS = 3
+    bpp = 8 * (NDIMS + 1)  # read 3 f64 coordinates + write 1 f64 result
+    spec = build_spec("linear", "regular", n, NDIMS, False, seed=1)
 
     # Grid: generated on rank 0, replicated read-only on every GPU by ONE RCCL broadcast.
     vals_dev = torch.empty(n**NDIMS, dtype=torch.float64, device=dev)
     if rank == 0:
-        vals_host = np.random.default_rng(1).uniform(-1.0, 1.0, n**NDIMS)
-        vals_dev.copy_(torch.from_numpy(vals_host))
+        vals_dev.copy_(torch.from_numpy(spec["vals"]))
     if world > 1:
         if args.backend == "nccl":
             dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
@@ -171,8 +450,7 @@ def main():
             stage = vals_dev.cpu()
             dist.broadcast(stage, src=0)
             vals_dev.copy_(stage)
-    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals_dev, device=local_rank,
-                                          dtype=np.float64)
+    it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
 
     # Observation shard of this rank: i.i.d. uniform over the grid extent, device resident.
     gen = torch.Generator(device=dev)
@@ -180,20 +458,27 @@ def main():
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(NDIMS)]
     out = torch.empty(P, dtype=torch.float64, device=dev)
 
-    def step():
-        it.eval_tensors(obs, out)
-        it.finish()
-
     def barrier():
         if world > 1:
             dist.barrier()
 
     for _ in range(args.warmup):
-        step()
+        it.eval_tensors(obs, out)
+        it.finish()
 
-    # Kernel duration with HIP events on the launch stream (torch's current stream).
+    # Same workload on ONE GPU with the others idle (rank 0 alone), so that the scaling of the
+    # N-rank line can be read against an identical single-GPU figure taken in the same run.
+    solo_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        barrier()
+        if rank == 0:
+            solo_ms = float(np.mean(time_launches(torch, it, obs, out, launches=max(20, min(args.steps, 200)),
+                                                  finish_each=True)))
+        barrier()
+
+    # ---- the timed region: exactly K steps ---------------------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -207,15 +492,24 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
+    kernel_ms_local = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t = torch.tensor([elapsed, kernel_ms_local], dtype=torch.float64, device=coll_dev)
+    per_rank_ms = [kernel_ms_local]
     if world > 1:
+        gathered = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([kernel_ms_local], dtype=torch.float64, device=coll_dev))
+        per_rank_ms = [float(x[0]) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    # Measured device-copy bandwidth (1 read + 1 write of 0.8 GB), reported beside the nominal peak.
-    copy_gbps = None
     if rank == 0:
+        kernel = it.kernel_name()
+        tbytes, si, sj = it.table_layout()
+        total_points = P * world * args.steps
+        value = total_points / elapsed / 1e6
+        achieved = P * bpp / (kernel_ms * 1e-3) / 1e9
+
+        # Measured device-copy bandwidth (1 read + 1 write of 0.8 GB), reported beside the nominal peak.
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         scratch = torch.empty_like(out)
         scratch.copy_(obs[0])
@@ -229,22 +523,9 @@ def main():
         copy_gbps = 2 * 8 * P / (best * 1e-3) / 1e9
         del scratch
 
-    if rank == 0:
-        total_points = P * world * args.steps
-        value = total_points / elapsed / 1e6
-        achieved = P * BYTES_PER_POINT / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("points") == P and tj.get("grid") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = committed_traffic(kernel, P, n, tbytes)
         rec = {
-            "metric": "Mpoints/sec (f64) per GPU + achieved HBM GB/s vs roofline, 3D linear-regular",
+            "metric": METRIC,
             "value": round(value, 1),
             "unit": "Mpoints/s",
             "n_gpus": world,
@@ -257,11 +538,15 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"3D multilinear::regular, {n}^3 f64 grid, {P:.0e} random obs per GPU (BASELINE configs[1])",
+                "workload": f"3D multilinear::regular, {n}^3 f64 grid, {P:.0e} random obs per GPU "
+                            f"({WORKLOADS[workload][1]}" + (f", {P * world:.0e} obs over {world} GPUs)" if world > 1 else ")"),
                 "points_per_gpu": P,
                 "grid": [n] * NDIMS,
                 "sharding": "obs sharded contiguously per rank; grid replicated by one RCCL broadcast; no collective in the loop",
                 "value_per_gpu": round(value / world, 1),
+                "backend": args.backend if world > 1 else None,
+                "launched_by": "bench.py spawn" if os.environ.get("INTERPN_BENCH_SPAWNED") else
+                               ("external launcher" if world > 1 else "single process"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -270,29 +555,76 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "traffic_note": ("FETCH_SIZE+WRITE_SIZE (rocprofv3 --pmc, gfx950 x2 read correction): fabric-side bytes of "
-                                 "the L2, Infinity-Cache hits included; the excess over the algorithmic 3.2 GB is brick "
-                                 "lines of the 5.4 MiB table re-fetched from the 256 MiB Infinity Cache, not HBM re-reads "
-                                 "(profiles/README.md)"),
-                "kernel": "interpn::k_linear_brick<double,3,false,true,1,2,2,0> (bricked grid copy, quad-cooperative gather, 2 points/lane)",
+                "traffic_source": traffic_src,
+                "kernel": kernel,
+                "table_MiB": round(tbytes / 2**20, 2),
+                "layout_steps": [si, sj],
                 "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_point": BYTES_PER_POINT,
+                "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
+                "algorithmic_bytes_per_point": bpp,
                 "measured_copy_GBps": round(copy_gbps, 1),
                 "frac_of_measured_copy": round(achieved / copy_gbps, 4),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            vals_host = vals_dev.cpu().numpy()
-            cb, cpu_out, ncpu = cpu_baseline(dims, starts, steps, vals_host, obs, args.cpu_sample)
-            # the oracle here is the checker, never the thing measured on the GPU side
-            same = bool(np.array_equal(out[:ncpu].cpu().numpy(), cpu_out))
-            cb["gpu_matches_bitwise"] = same
-            rec["cpu_baseline"] = cb
+        if world > 1 and solo_ms:
+            rec["config"]["single_gpu_same_workload"] = {
+                "kernel_ms": round(solo_ms, 4), "Mpoints_per_s": round(P / solo_ms / 1e3, 1),
+                "note": "rank 0 alone on its GPU, the other ranks idle at a barrier, same grid and batch: "
+                        "value / (n_gpus x this) is the scaling efficiency on an identical workload"}
+        if world == 1:
+            # >= 0.5 s of back-to-back launches (the K-step region above may be only 20 launches)
+            ms = time_launches(torch, it, obs, out, seconds=args.sustain_seconds)
+            sk = float(np.mean(ms))
+            rec["roofline"]["sustained"] = {
+                "launches": len(ms), "seconds": round(float(np.sum(ms)) / 1e3, 3), "kernel_ms": round(sk, 4),
+                "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_max": round(float(np.max(ms)), 4),
+                "achieved": round(P * bpp / (sk * 1e-3) / 1e9, 1), "frac": round(P * bpp / (sk * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            if not args.no_ablate:
+                try:
+                    rec["roofline"]["ablation"] = run_ablation(torch, spec, obs, out, it, 0.25)
+                except Exception as e:  # a measurement aid must never take the record down
+                    rec["roofline"]["ablation"] = {"error": repr(e)}
+            # restore `out` (the ablation kernels scribble on it) before it is compared below
+            it.eval_tensors(obs, out)
+            it.finish()
+            if not args.no_cpu_baseline:
+                cb, cpu_out, ncpu = cpu_baseline(spec, obs, args.cpu_sample)
+                # the oracle here is the checker, never the thing measured on the GPU side
+                cb["gpu_matches_bitwise"] = bool(np.array_equal(out[:ncpu].cpu().numpy(), cpu_out))
+                rec["cpu_baseline"] = cb
+            if not args.no_configs and P == 100_000_000:
+                rows = []
+                secs = args.sustain_seconds
+                try:
+                    rows.append(config_row(torch, interpn_amd, "cfg2 3D multilinear::regular 64^3, 1e8 obs",
+                                           build_spec("linear", "regular", 64, 3, False, 1), obs, out, local_rank, secs))
+                    rows.append(config_row(torch, interpn_amd, "cfg3 3D multilinear::rectilinear non-uniform 64^3, 1e8 obs",
+                                           build_spec("linear", "rectilinear", 64, 3, False, 2), obs, out, local_rank, secs))
+                    rows.append(config_row(torch, interpn_amd, "cfg5-shard 3D multilinear::regular 128^3, 1e8 obs (one of 8 shards)",
+                                           build_spec("linear", "regular", 128, 3, False, 1), obs, out, local_rank, secs))
+                    P4 = 10_000_000
+                    obs4 = [o[:P4] for o in obs] + [torch.rand(P4, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0]
+                    for lin in (False, True):
+                        rows.append(config_row(torch, interpn_amd,
+                                               f"cfg4 4D multicubic::regular 32^4, 1e7 obs, linearize_extrapolation={str(lin).lower()}",
+                                               build_spec("cubic", "regular", 32, 4, lin, 4), obs4, out[:P4], local_rank, secs))
+                except Exception as e:
+                    rows.append({"error": repr(e)})
+                rec["configs"] = rows
         print(json.dumps(rec), flush=True)
 
     it.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -1,366 +1,10 @@
-// N-D multilinear (N >= 3; regular and rectilinear; f64 and f32) on a bricked copy of the grid
-// with a quad-cooperative gather.
-//
-// Why: with the grid in C order a point's 2^N corners lie on 2^(N-1) different 128-B lines, and on
-// MI355X the per-XCD L2 -> L1 line rate (16 lines/clk/XCD, ~2.7e11 lines/s chip-wide), not HBM,
-// bounds the kernel (profiles/r01_tune_*).  Here the handle keeps a second
-// copy of the grid in which the LAST THREE dimensions (i, j, k) are cut into 2 x 2 x KW bricks of
-// one 128-B line each (KW = 4 for f64, 8 for f32), stepped KW-1 along k (a k-pair never leaves a
-// brick row) and 1 or 2 along i and j (overlapping bricks = duplicated planes / rows); leading
-// dimensions, if any, index whole brick tables.  A 3-D cell then spans 1 (steps 1,1), 1.5 (1,2)
-// or 2.25 (2,2) lines instead of 4.25.  Because the TCP only merges lanes of the same instruction,
-// the four lanes of a quad fetch the four (i,j) k-pairs of ONE point per load instruction, so
-// pieces on the same line become a single L2 request; the pieces are transposed back through LDS
-// and every lane finishes its own point with the reference's arithmetic and operation order
-// (leading dimensions are reduced first, exactly as dims 0..N-4 are in the reference's tree,
-// src/multilinear/regular.rs:347-403), so results are bit-identical to the C-order kernels.
+// Host side of the bricked multilinear path (N = 3..6): table geometry, the table builder's
+// launcher and the kernel launchers.  The device code lives in linear_brick.h.
 #include <cstdlib>
 
-#include "rect_args.h"
+#include "linear_brick.h"
 
 namespace interpn {
-
-template <typename T> struct BrickGeom {
-  static constexpr int KW = 32 / (int)sizeof(T);  // elements per brick row (32 B)
-  static constexpr int SK = KW - 1;               // brick step along k
-  static constexpr int ELEMS = 4 * KW;            // elements per brick (128 B)
-};
-
-template <typename T, int N>
-struct BrickArgs {
-  const T* bricks;
-  const T* obs[N];
-  T* out;
-  unsigned long long* first_bad;
-  size_t npts;
-  T start[N];
-  T step[N];
-  int n[N];
-  AxisArgs<T, N> ax;
-  unsigned lead_stride[N > 3 ? N - 3 : 1];  // elements of the brick table per unit of a leading index
-  unsigned nbj, nbk;
-  unsigned iters;  // kBlock-wide iterations per workgroup
-};
-
-template <typename T, int SI, int SJ>
-__device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj) {
-  constexpr int KW = BrickGeom<T>::KW;
-  int bi, oi, bj, oj;
-  if (SI == 1) { bi = i; oi = di; }
-  else { bi = i >> 1; oi = (i & 1) + di; if (oi == 2) { bi += 1; oi = 0; } }
-  if (SJ == 1) { bj = j; oj = dj; }
-  else { bj = j >> 1; oj = (j & 1) + dj; if (oj == 2) { bj += 1; oj = 0; } }
-  return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
-}
-
-#ifndef INTERPN_PIECE_ROW
-#define INTERPN_PIECE_ROW 5
-#endif
-constexpr int kPieceRow = INTERPN_PIECE_ROW;  // piece slots per point row in LDS (4 used + 1 pad against bank conflicts)
-
-template <typename T>
-struct Cell {
-  T v[2][2][2];  // [di][dj][dk]
-};
-
-// One cooperative gather: lane q of a quad loads piece q of the quad's points r = 0..3 (offsets in
-// `toff`, plus the wave-uniform `delta` of the current leading-dimension combination), then the
-// 4x4 piece matrix is transposed through LDS so that every lane owns its point's four pieces.
-template <typename T>
-__device__ __forceinline__ Cell<T> gather_cell(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
-                                               typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q) {
-  typedef typename LeafVec<T, 2>::type P;
-  P pc[4];
-// (non-temporal gathers were measured: 64^3 2.4 ms, 128^3 2.9 ms -- both much worse -- so the
-  // table is read with the default cache policy)
-  pc[0] = *reinterpret_cast<const P*>(bricks + toff.x + delta);
-  pc[1] = *reinterpret_cast<const P*>(bricks + toff.y + delta);
-  pc[2] = *reinterpret_cast<const P*>(bricks + toff.z + delta);
-  pc[3] = *reinterpret_cast<const P*>(bricks + toff.w + delta);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pc[r];
-  wave_sync();
-  Cell<T> c;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const P w = lds_piece[(quad * 4 + q) * kPieceRow + p];
-    c.v[p >> 1][p & 1][0] = w.x;
-    c.v[p >> 1][p & 1][1] = w.y;
-  }
-  wave_sync();
-  return c;
-}
-
-// Reduce leading dimensions 0..D-1 (dim 0 innermost), element-wise on the 8 trailing corners.
-template <typename T, int D, bool FMA>
-struct LeadReduce {
-  __device__ __forceinline__ static Cell<T> run(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
-                                                const unsigned* lead_stride, const T* t,
-                                                typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q) {
-    const Cell<T> a = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta, lead_stride, t, lds_piece, quad, q);
-    const Cell<T> b = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta + lead_stride[D - 1], lead_stride, t, lds_piece, quad, q);
-    Cell<T> r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const T y0 = a.v[e >> 2][(e >> 1) & 1][e & 1];
-      const T dy = b.v[e >> 2][(e >> 1) & 1][e & 1] - y0;
-      r.v[e >> 2][(e >> 1) & 1][e & 1] = mul_add<FMA>(t[D - 1], dy, y0);  // regular.rs:378-385
-    }
-    return r;
-  }
-};
-template <typename T, bool FMA>
-struct LeadReduce<T, 0, FMA> {
-  __device__ __forceinline__ static Cell<T> run(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
-                                                const unsigned*, const T*, typename LeafVec<T, 2>::type* lds_piece,
-                                                unsigned quad, unsigned q) {
-    return gather_cell<T>(bricks, toff, delta, lds_piece, quad, q);
-  }
-};
-
-// PPL = points per lane.  With PPL = 2 a lane owns two consecutive points, so coordinates and
-// results move as 2*sizeof(T)-byte vectors (16 B in f64): the streams then cost the L2 fewer
-// channel-cycles per line (measured -4 % at 64^3, -7 % at 32^3; tools/tune_layout ... w).  Needs all
-// obs/out pointers aligned to 2*sizeof(T); the launcher falls back to PPL = 1 otherwise.
-// AXR != 0 (rectilinear, every axis <= 64 coordinates): the axes live in registers, one
-// coordinate per lane, and are searched with cross-lane reads instead of LDS gathers.
-//   AXR == 1: the reference's binary-search probe sequence, six lockstep steps (any axis);
-//   AXR == 2: a 255-bucket lane table (sorted finite axes) brackets the answer to the bucket's
-//             few coordinates: 1 + 2*scan probes instead of 14 (the LDS pipe is what the
-//             rectilinear kernel waits for, profiles/r01_sq_counters_regular_vs_rectilinear.txt).
-template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0>
-__global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
-  typedef typename LeafVec<T, 2>::type P;
-  constexpr int L = N - 3;
-  constexpr int SK = BrickGeom<T>::SK;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
-  lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
-  unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
-  T greg[N];
-  unsigned ltab[N];
-  unsigned scan = 0;
-  if constexpr (RECT && AXR != 0) {
-    const int wl = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int d = 0; d < N; ++d) {
-      const T* g = reinterpret_cast<const T*>(a.ax.image + a.ax.g_off[d]);
-      greg[d] = g[wl < a.ax.n[d] ? wl : a.ax.n[d] - 1];
-      if constexpr (AXR == 2) {
-        const unsigned* words = reinterpret_cast<const unsigned*>(a.ax.image + a.ax.ltab_off[d]);
-        ltab[d] = words[wl];
-        const unsigned pop = words[64];  // uniform
-        scan = pop > scan ? pop : scan;
-      }
-    }
-    scan = __builtin_amdgcn_readfirstlane(scan);
-  } else if (RECT && a.ax.use_lds) {
-    stage_axes<T, N>(a.ax, lds_axes);
-  }
-  const unsigned char* axis_base = (RECT && AXR == 0 && a.ax.use_lds) ? lds_axes : a.ax.image;
-  const unsigned lane = threadIdx.x;
-  const unsigned q = lane & 3;
-  const unsigned quad = lane >> 2;
-  typedef T T2 __attribute__((ext_vector_type(2)));
-  // Block b owns the contiguous lane slots [b, b+1) * iters * kBlock (PPL points per slot); the
-  // grid covers the batch once, so the hardware dispatcher balances the load across XCDs.
-  const size_t nslots = (a.npts + PPL - 1) / PPL;
-  const size_t first = (size_t)blockIdx.x * a.iters * kBlock;
-  for (unsigned it = 0; it < a.iters; ++it) {
-    // Every lane runs every iteration (dead lanes still fetch pieces for their quad).
-    const size_t s0 = first + (size_t)it * kBlock + lane;
-    if (s0 - lane >= nslots) break;  // block-uniform
-    const size_t i0 = s0 * PPL;
-    T xin[PPL][N];
-    bool live[PPL];
-#pragma unroll
-    for (int h = 0; h < PPL; ++h) live[h] = i0 + h < a.npts;
-    if (PPL == 2) {
-#pragma unroll
-      for (int d = 0; d < N; ++d) {
-        T2 v;
-        v.x = RECT ? (T)0 : a.start[d];
-        v.y = v.x;
-        if (live[PPL - 1]) v = stream_load(reinterpret_cast<const T2*>(a.obs[d] + i0));
-        else if (live[0]) v.x = stream_load(a.obs[d] + i0);
-        xin[0][d] = v.x;
-        xin[PPL - 1][d] = v.y;
-      }
-    } else {
-#pragma unroll
-      for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? stream_load(a.obs[d] + i0) : (RECT ? (T)0 : a.start[d]);
-    }
-    // AXR: the PPL x N binary searches advance in lockstep (six fixed halving steps cover 64
-    // coordinates), so every step issues PPL*N independent cross-lane reads instead of one.
-    int cell_r[PPL][N];
-    T x0_r[PPL][N], x1_r[PPL][N];
-    if constexpr (RECT && AXR != 0) {
-      // cell_r <- partition_point(g < x) (multilinear/rectilinear.rs:363) ...
-      if constexpr (AXR == 1) {
-        int size[N];
-#pragma unroll
-        for (int d = 0; d < N; ++d) size[d] = a.ax.n[d];
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d) cell_r[h][d] = 0;
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-#pragma unroll
-          for (int d = 0; d < N; ++d) {
-            const int half = size[d] >> 1;  // 0 once size is 1: the probe then re-reads g[base] and keeps base
-#pragma unroll
-            for (int h = 0; h < PPL; ++h) {
-              const int mid = cell_r[h][d] + half;
-              cell_r[h][d] = (half > 0 && __shfl(greg[d], mid) < xin[h][d]) ? mid : cell_r[h][d];
-            }
-            size[d] -= half;
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d)
-            cell_r[h][d] += (__shfl(greg[d], cell_r[h][d]) < xin[h][d]) ? 1 : 0;
-      } else {
-        // Coordinates in earlier buckets are < x and those in later buckets are >= x (bucket_of is
-        // monotone and the table was built with it), so starting at the bucket's first coordinate
-        // and stepping while g[idx] < x — at most `scan` times — lands on the count of g < x.
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d) {
-            const int b = bucket_of<T>(xin[h][d], a.ax.g0[d], a.ax.lscale[d], kLaneBuckets);
-            const unsigned w = __shfl(ltab[d], b >> 2);
-            cell_r[h][d] = (int)((w >> ((b & 3) * 8)) & 0xFFu);
-          }
-        for (unsigned s = 0; s < scan; ++s) {  // uniform trip count
-#pragma unroll
-          for (int h = 0; h < PPL; ++h)
-#pragma unroll
-            for (int d = 0; d < N; ++d) {
-              const int n = a.ax.n[d];
-              const int idx = cell_r[h][d];
-              const T gi = __shfl(greg[d], idx < n ? idx : n - 1);
-              cell_r[h][d] = idx + ((idx < n && gi < xin[h][d]) ? 1 : 0);
-            }
-        }
-      }
-      // ... then the cell: clamp(partition_point - 1, 0, n-2) (rectilinear.rs:365-367)
-#pragma unroll
-      for (int h = 0; h < PPL; ++h)
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          const int n = a.ax.n[d];
-          int l = cell_r[h][d] - 1;
-          l = l > 0 ? l : 0;
-          l = l < n - 2 ? l : n - 2;
-          cell_r[h][d] = l;
-        }
-#pragma unroll
-      for (int h = 0; h < PPL; ++h)
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          x0_r[h][d] = __shfl(greg[d], cell_r[h][d]);
-          x1_r[h][d] = __shfl(greg[d], cell_r[h][d] + 1);
-        }
-    }
-    T resv[PPL];
-#pragma unroll
-    for (int h = 0; h < PPL; ++h) {
-      T t[N];
-      int loc[N];
-      bool ok = true;
-#pragma unroll
-      for (int d = 0; d < N; ++d) {
-        const T x = xin[h][d];
-        if (RECT) {
-          T x0, x1;
-          int l;
-          if constexpr (AXR != 0) {
-            l = cell_r[h][d];
-            x0 = x0_r[h][d];
-            x1 = x1_r[h][d];
-          } else {
-            const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-            l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
-          }
-          const T step = x1 - x0;
-          t[d] = (x - x0) / step;                       // rectilinear.rs:310-313
-          loc[d] = l;
-        } else {
-          T floc;
-          ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);          // multilinear/regular.rs:415-418
-          const int l = clamp_loc<T>(floc, a.n[d] - 2);                     // regular.rs:420-422
-          const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);          // regular.rs:334-337
-          t[d] = (x - izl) / a.step[d];                                     // regular.rs:339
-          loc[d] = l;
-        }
-      }
-      if (!RECT && !ok && live[h]) atomicMin(a.first_bad, (unsigned long long)(i0 + h));
-      // Offsets of my point's four pieces (lower corner of the leading dims included) -> LDS,
-      // transposed: lane q reads piece q of points 0..3.
-      unsigned lead = 0;
-#pragma unroll
-      for (int d = 0; d < L; ++d) lead += (unsigned)loc[d] * a.lead_stride[d];
-      const unsigned bk = (unsigned)loc[N - 1] / (unsigned)SK;
-      const unsigned kpart = bk * (unsigned)BrickGeom<T>::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
-      wave_sync();
-      const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
-      const Cell<T> c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
-      // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
-      T r[2];
-#pragma unroll
-      for (int dk = 0; dk < 2; ++dk) {
-        const T c0 = mul_add<FMA>(t[N - 3], c.v[1][0][dk] - c.v[0][0][dk], c.v[0][0][dk]);
-        const T c1 = mul_add<FMA>(t[N - 3], c.v[1][1][dk] - c.v[0][1][dk], c.v[0][1][dk]);
-        r[dk] = mul_add<FMA>(t[N - 2], c1 - c0, c0);
-      }
-      resv[h] = mul_add<FMA>(t[N - 1], r[1] - r[0], r[0]);
-    }
-    if (PPL == 2) {
-      if (live[PPL - 1]) {
-        T2 v;
-        v.x = resv[0];
-        v.y = resv[PPL - 1];
-        stream_store(reinterpret_cast<T2*>(a.out + i0), v);
-      } else if (live[0]) {
-        stream_store(a.out + i0, resv[0]);
-      }
-    } else if (live[0]) {
-      stream_store(a.out + i0, resv[0]);
-    }
-  }
-}
-
-// Brick table builder: one thread per brick element.
-template <typename T>
-__global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ vals, T* __restrict__ bricks, size_t nlead,
-                                                         int n0, int n1, int n2, int si, int sj, unsigned nbi, unsigned nbj,
-                                                         unsigned nbk) {
-  constexpr int KW = BrickGeom<T>::KW;
-  constexpr int EL = BrickGeom<T>::ELEMS;
-  const size_t per_lead = (size_t)nbi * nbj * nbk * EL;
-  const size_t total = nlead * per_lead;
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
-    const size_t lead = e / per_lead;
-    size_t b = e - lead * per_lead;
-    const unsigned within = (unsigned)(b % EL);
-    b /= EL;
-    const unsigned bk = (unsigned)(b % nbk); b /= nbk;
-    const unsigned bj = (unsigned)(b % nbj); b /= nbj;
-    const unsigned bi = (unsigned)b;
-    const int i = (int)bi * si + (int)(within / (2 * KW));
-    const int j = (int)bj * sj + (int)((within / KW) & 1);
-    const int k = (int)bk * (KW - 1) + (int)(within % KW);
-    T v = (T)0;
-    if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];
-    bricks[e] = v;
-  }
-}
 
 // Bricks needed per dimension (cell indices run 0 .. n-2):
 //   step 1:      brick = cell index                      -> n-1 bricks
@@ -411,13 +55,13 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
   return hipGetLastError();
 }
 
-// Axes small enough to sit one coordinate per lane (3-D only: the instantiation count is kept
-// bounded).  0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane
-// tables.  The handle's `axis_regs` option (latched from INTERPN_HIP_AXIS_REGS at creation)
-// overrides: 0 | 1 | 2, where 2 falls back to 1 when a table is missing.
+// Axes small enough to sit one coordinate per lane (every axis <= 64 coordinates).
+// 0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane tables.
+// The handle's `axis_regs` option (latched from INTERPN_HIP_AXIS_REGS at creation) overrides:
+// 0 | 1 | 2, where 2 falls back to 1 when a table is missing.
 template <int N>
 static int axes_in_lanes(const GridDesc& g) {
-  if (N != 3 || g.kind != kRectilinear) return 0;
+  if (g.kind != kRectilinear) return 0;
   bool tables = true;
   for (int d = 0; d < N; ++d) {
     if (g.n[d] > 64) return 0;
@@ -439,14 +83,12 @@ static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds,
   if (g.kind == kRegular)
     return g.fma ? launch_steps<T, N, false, true, PPL, 0>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, false, false, PPL, 0>(g, a, lds, blocks, stream);
-  if constexpr (N == 3) {
-    if (axr == 2)
-      return g.fma ? launch_steps<T, N, true, true, PPL, 2>(g, a, lds, blocks, stream)
-                   : launch_steps<T, N, true, false, PPL, 2>(g, a, lds, blocks, stream);
-    if (axr == 1)
-      return g.fma ? launch_steps<T, N, true, true, PPL, 1>(g, a, lds, blocks, stream)
-                   : launch_steps<T, N, true, false, PPL, 1>(g, a, lds, blocks, stream);
-  }
+  if (axr == 2)
+    return g.fma ? launch_steps<T, N, true, true, PPL, 2>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, true, false, PPL, 2>(g, a, lds, blocks, stream);
+  if (axr == 1)
+    return g.fma ? launch_steps<T, N, true, true, PPL, 1>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, true, false, PPL, 1>(g, a, lds, blocks, stream);
   return g.fma ? launch_steps<T, N, true, true, PPL, 0>(g, a, lds + axis_lds, blocks, stream)
                : launch_steps<T, N, true, false, PPL, 0>(g, a, lds + axis_lds, blocks, stream);
 }

@@ -698,6 +698,178 @@ def test_device_tensors_full_size_properties(oracle):
     assert float((out2 - exact).abs().max()) < 1e-12
 
 
+def _full_size_checks(torch, it, obs, oracle_fn, sample, sub_range):
+    """Shared body of the BASELINE-size tests: one launch over the whole batch, then (a) a random
+    sample bit-compared with the oracle, (b) a sub-range evaluated on its own == the slice."""
+    dev = obs[0].device
+    P = obs[0].numel()
+    out = it.eval_tensors(obs)
+    it.finish()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)
+    idx = torch.randint(0, P, (sample,), device=dev, generator=gen)
+    sub = [o[idx].cpu().numpy() for o in obs]
+    want = np.zeros(sample)
+    oracle_fn(sub, want)
+    got = out[idx].cpu().numpy()
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    assert np.all(same), (int((~same).sum()), float(np.nanmax(np.abs(got - want))))
+    lo, hi = sub_range
+    part = it.eval_tensors([o[lo:hi].contiguous() for o in obs])
+    it.finish()
+    assert torch.equal(part, out[lo:hi])
+    return out
+
+
+def test_cfg3_full_size_rectilinear(oracle):
+    """BASELINE config 3 at full size: 3-D multilinear-rectilinear, non-uniform 64^3 grid, 1e8
+    unordered obs (~5 % outside the grid: rectilinear extrapolates, it never fails).
+    multilinear/rectilinear.rs:244-370."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n, P = 64, 100_000_000
+    rng = np.random.default_rng(21)
+    g = np.linspace(-1.0, 1.0, n)
+    step = g[1] - g[0]
+    grids = []
+    for _ in range(3):
+        j = (rng.random(n) - 0.5) * 0.5 * step
+        j[0] = j[-1] = 0.0
+        grids.append(g + j)
+    vals = rng.uniform(-1, 1, n**3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
+    it = interpn_amd.Interpolator.rectilinear("linear", grids, vals)
+    _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_rectilinear(grids, vals, sub, want), 500_000,
+                      (31_234_567, 47_000_001))
+    name = it.kernel_name()
+    assert name.startswith("interpn::k_linear_brick<double, 3, true, true,") and name.endswith(", 2, 2>"), name
+    it.close()
+
+
+@pytest.mark.parametrize("linearize", [False, True], ids=["quad", "lin"])
+def test_cfg4_full_size_cubic_4d(oracle, linearize):
+    """BASELINE config 4 at its grid size: 4-D multicubic-regular, 32^4 f64 grid (the 128 MiB
+    fully overlapped tile table and its plane strides), 1e7 obs of which ~10 % extrapolate so
+    that both `linearize_extrapolation` flags differ.  multicubic/regular.rs:325-623."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n, P = 32, 10_000_000
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n] * 4, np.full(4, -1.0), np.full(4, g[1] - g[0])
+    vals = np.random.default_rng(22).uniform(-1, 1, n**4)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(78)
+    obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(4)]
+    it = interpn_amd.Interpolator.regular("cubic", dims, starts, steps, vals, linearize_extrapolation=linearize)
+    _full_size_checks(torch, it, obs,
+                      lambda sub, want: oracle.cubic_regular(dims, starts, steps, vals, linearize, sub, want), 200_000,
+                      (1_234_567, 4_700_001))
+    name = it.kernel_name()
+    tbytes, si, sj = it.table_layout()
+    assert name.startswith("interpn::k_cubic_brick<double, 4, false, true,"), name
+    assert tbytes >= 8 * n**4  # a re-laid copy is in use (its layout is the heuristic's choice)
+    it.close()
+
+
+def test_cfg5_shard_full_size(oracle):
+    """One shard of BASELINE config 5: 3-D multilinear-regular on the 128^3 grid (86 MiB fully
+    overlapped brick table, Infinity-Cache resident), 1e8 obs.  Also the linear-field property at
+    this size (multilinear reproduces a field that is linear in every coordinate to 1e-12)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n, P = 128, 100_000_000
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0])
+    vals = np.random.default_rng(23).uniform(-1, 1, n**3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(79)
+    obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(3)]
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
+    _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
+                      500_000, (61_234_567, 77_000_001))
+    name = it.kernel_name()
+    assert name.startswith("interpn::k_linear_brick<double, 3, false, true,"), name
+    it.close()
+    mesh = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    lin = np.ascontiguousarray(mesh @ np.array([0.5, -1.25, 2.0]) + 0.75)
+    it2 = interpn_amd.Interpolator.regular("linear", dims, starts, steps, lin)
+    out2 = it2.eval_tensors(obs)
+    it2.finish()
+    exact = 0.5 * obs[0] - 1.25 * obs[1] + 2.0 * obs[2] + 0.75
+    assert float((out2 - exact).abs().max()) < 1e-12
+    it2.close()
+
+
+def test_handle_options_and_kernel_name(oracle):
+    """Tuning knobs are per-handle state (latched from the environment at creation, changed with
+    interpn_hip_set_option), never read on the launch path; the kernel name is reported by the
+    handle."""
+    import interpn_amd
+
+    case = synthetic_case("linear", "regular", 3, [20, 21, 22], 50_001, 5)
+    want = run_oracle(oracle, case, True)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    assert it.kernel_name() == ""
+    assert it.get_option("ppl") == 0 and it.get_option("force_generic") == 0
+    out = it.eval_host(case.obs, np.zeros_like(want))
+    assert np.array_equal(out, want)
+    first = it.kernel_name()
+    assert first.startswith("interpn::k_linear_brick<double, 3, false, true,"), first
+    it.set_option("force_generic", 1)
+    out = it.eval_host(case.obs, np.zeros_like(want))
+    assert np.array_equal(out, want)
+    assert it.kernel_name().startswith("interpn::k_generic<double,"), it.kernel_name()
+    it.set_option("force_generic", 0)
+    it.set_option("ppl", 1)
+    out = it.eval_host(case.obs, np.zeros_like(want))
+    assert np.array_equal(out, want)
+    assert it.kernel_name().endswith(", 1, 0>"), it.kernel_name()
+    with pytest.raises(ValueError):
+        it.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        it.set_option("ppl", 7)
+    it.close()
+
+
+def test_destroy_does_not_wait_for_other_streams(oracle):
+    """interpn_hip_destroy waits for the handle's own work only: a long-running
+    kernel on an unrelated stream must still be running when destroy returns."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = synthetic_case("linear", "regular", 3, [16, 16, 16], 10_000, 6)
+    want = run_oracle(oracle, case, True)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    side = torch.cuda.Stream(device=dev)
+    big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    done = torch.cuda.Event()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(60):  # ~1 GiB written 60 times: tens of milliseconds of unrelated work
+            big.add_(1.0)
+        done.record(side)
+    out = it.eval_tensors(obs)  # on torch's current (default) stream
+    it.close()
+    still_running = not done.query()
+    assert np.array_equal(out.cpu().numpy(), want)
+    side.synchronize()
+    assert still_running, "destroy waited for an unrelated stream"
+
+
 def test_differential_fuzz_short(oracle):
     """A fixed-seed slice of tools/fuzz_parity.py (random method / kind / N / axis sizes / dtype /
     layout and scheduling knobs / special coordinates): every case bit-identical to the oracle.

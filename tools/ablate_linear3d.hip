@@ -1,0 +1,113 @@
+// Ablation harness for the headline kernel (3-D multilinear-regular, f64, fma flavour):
+// instantiates the PRODUCT kernel source (interpn_amd/csrc/linear_brick.h) with its measurement
+// flag ABL = 0 (unmodified), 1 (stream-only) and 2 (gather-only) on the brick layouts the library
+// can choose.  Loaded only by bench.py (`roofline.ablation`): it times kernels, it is not on the
+// product path and its ABL != 0 outputs are meaningless by construction.
+//
+//   void* ablate_create(const double* vals_dev, int n, int si, int sj, double step)
+//   int   ablate_launch(void* h, int mode, x, y, z, out, npts, hipStream_t)   -> hipError_t
+//   void  ablate_destroy(void* h)
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "../interpn_amd/csrc/linear_brick.h"
+
+using namespace interpn;
+
+namespace {
+
+struct Ablate {
+  double* bricks = nullptr;
+  unsigned long long* first_bad = nullptr;
+  int n = 0, si = 0, sj = 0;
+  unsigned nb[3] = {0, 0, 0};
+  double step = 0;
+};
+
+unsigned along(int n, int step) {  // k_linear_brick.hip::bricks_along
+  if (step == 1) return (unsigned)(n - 1);
+  if (step == 2) return (unsigned)((n - 1) / 2 + 1);
+  return (unsigned)((n - 2) / step + 1);
+}
+
+template <int SI, int SJ, int ABL>
+hipError_t go(const Ablate& h, const BrickArgs<double, 3>& a, unsigned blocks, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((k_linear_brick<double, 3, false, true, SI, SJ, 2, 0, ABL>), dim3(blocks), dim3(kBlock), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int ABL>
+hipError_t go_steps(const Ablate& h, const BrickArgs<double, 3>& a, unsigned blocks, size_t lds, hipStream_t s) {
+  if (h.si == 1 && h.sj == 1) return go<1, 1, ABL>(h, a, blocks, lds, s);
+  if (h.si == 1 && h.sj == 2) return go<1, 2, ABL>(h, a, blocks, lds, s);
+  return go<2, 2, ABL>(h, a, blocks, lds, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) {
+  if (!vals_dev || n < 2 || !((si == 1 || si == 2) && (sj == 1 || sj == 2)) || (si == 2 && sj == 1)) return nullptr;
+  Ablate* h = new (std::nothrow) Ablate();
+  if (!h) return nullptr;
+  h->n = n; h->si = si; h->sj = sj; h->step = step;
+  h->nb[0] = along(n, si); h->nb[1] = along(n, sj); h->nb[2] = along(n, 3);
+  const size_t elems = (size_t)h->nb[0] * h->nb[1] * h->nb[2] * 16;
+  if (elems >= 0xFFFFFFFFull || hipMalloc((void**)&h->bricks, elems * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&h->first_bad, 8) != hipSuccess || hipMemset(h->first_bad, 0xFF, 8) != hipSuccess) {
+    (void)hipFree(h->bricks); (void)hipFree(h->first_bad);
+    delete h;
+    return nullptr;
+  }
+  size_t blocks = (elems + kBlock - 1) / kBlock;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(k_build_bricks<double>, dim3((unsigned)blocks), dim3(kBlock), 0, nullptr, vals_dev, h->bricks, (size_t)1,
+                     n, n, n, si, sj, h->nb[0], h->nb[1], h->nb[2]);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(h->bricks); (void)hipFree(h->first_bad);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+int ablate_launch(void* handle, int mode, const double* x, const double* y, const double* z, double* out, size_t npts,
+                  void* stream) {
+  const Ablate* h = static_cast<const Ablate*>(handle);
+  if (!h || !x || !y || !z || !out || npts == 0 || (npts & 1) || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  for (const void* p : {(const void*)x, (const void*)y, (const void*)z, (const void*)out})
+    if (reinterpret_cast<uintptr_t>(p) % 16) return (int)hipErrorInvalidValue;  // the two-points-per-lane form
+  BrickArgs<double, 3> a;
+  a.bricks = h->bricks;
+  a.obs[0] = x; a.obs[1] = y; a.obs[2] = z;
+  a.out = out;
+  a.first_bad = h->first_bad;
+  a.npts = npts;
+  for (int d = 0; d < 3; ++d) { a.start[d] = -1.0; a.step[d] = h->step; a.n[d] = h->n; }
+  a.nbj = h->nb[1];
+  a.nbk = h->nb[2];
+  a.lead_stride[0] = 0;
+  a.ax.use_lds = 0; a.ax.image = nullptr; a.ax.image_bytes = 0;
+  a.iters = 1;  // the library's launch shape for regular grids: one 256-lane row per workgroup
+  typedef LeafVec<double, 2>::type P;
+  const size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16;
+  const size_t nslots = (npts + 1) / 2;
+  const unsigned blocks = (unsigned)((nslots + kBlock - 1) / kBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mode == 0) return (int)go_steps<0>(*h, a, blocks, lds, s);
+  if (mode == 1) return (int)go_steps<1>(*h, a, blocks, lds, s);
+  return (int)go_steps<2>(*h, a, blocks, lds, s);
+}
+
+void ablate_destroy(void* handle) {
+  Ablate* h = static_cast<Ablate*>(handle);
+  if (!h) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(h->bricks);
+  (void)hipFree(h->first_bad);
+  delete h;
+}
+
+}  // extern "C"
