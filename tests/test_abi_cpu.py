@@ -184,3 +184,23 @@ def test_header_is_valid_c99_and_c_consumer_compiles(tmp_path):
     libdir = os.path.join(ROOT, "interpn_amd")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", inc, src, "-L", libdir, "-linterpn_hip", f"-Wl,-rpath,{libdir}",
                            "-lm", "-o", str(tmp_path / "demo")])
+
+
+def test_raw_stub_matches_module():
+    """interpn_amd/raw.pyi (+ py.typed) mirrors the reference's typed surface
+    (src/interpn/raw.pyi:32-147): same 16 names, same parameter names in the same order as the
+    functions raw.py really defines; the committed stub is what tools/gen_raw_stub.py renders."""
+    import ast
+    import inspect
+
+    from interpn_amd import raw
+    from tools.gen_raw_stub import render
+
+    here = os.path.join(ROOT, "interpn_amd")
+    assert os.path.exists(os.path.join(here, "py.typed"))
+    text = open(os.path.join(here, "raw.pyi")).read()
+    assert text == render()
+    stub = {n.name: [a.arg for a in n.args.args] for n in ast.parse(text).body if isinstance(n, ast.FunctionDef)}
+    assert sorted(stub) == sorted(raw.__all__) and len(stub) == 16
+    for name, params in stub.items():
+        assert list(inspect.signature(getattr(raw, name)).parameters) == params, name

@@ -705,6 +705,7 @@ def _full_size_checks(torch, it, obs, oracle_fn, sample, sub_range):
     P = obs[0].numel()
     out = it.eval_tensors(obs)
     it.finish()
+    full_name = it.kernel_name()  # the instantiation the full-size launch ran
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
     idx = torch.randint(0, P, (sample,), device=dev, generator=gen)
@@ -715,10 +716,10 @@ def _full_size_checks(torch, it, obs, oracle_fn, sample, sub_range):
     same = (got == want) | (np.isnan(got) & np.isnan(want))
     assert np.all(same), (int((~same).sum()), float(np.nanmax(np.abs(got - want))))
     lo, hi = sub_range
-    part = it.eval_tensors([o[lo:hi].contiguous() for o in obs])
+    part = it.eval_tensors([o[lo:hi] for o in obs])  # views: an odd `lo` also exercises the 8-byte-aligned path
     it.finish()
     assert torch.equal(part, out[lo:hi])
-    return out
+    return out, full_name
 
 
 def test_cfg3_full_size_rectilinear(oracle):
@@ -744,9 +745,8 @@ def test_cfg3_full_size_rectilinear(oracle):
     gen.manual_seed(77)
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
     it = interpn_amd.Interpolator.rectilinear("linear", grids, vals)
-    _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_rectilinear(grids, vals, sub, want), 500_000,
-                      (31_234_567, 47_000_001))
-    name = it.kernel_name()
+    _, name = _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_rectilinear(grids, vals, sub, want),
+                                500_000, (31_234_567, 47_000_001))
     assert name.startswith("interpn::k_linear_brick<double, 3, true, true,") and name.endswith(", 2, 2>"), name
     it.close()
 
@@ -769,10 +769,9 @@ def test_cfg4_full_size_cubic_4d(oracle, linearize):
     gen.manual_seed(78)
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(4)]
     it = interpn_amd.Interpolator.regular("cubic", dims, starts, steps, vals, linearize_extrapolation=linearize)
-    _full_size_checks(torch, it, obs,
-                      lambda sub, want: oracle.cubic_regular(dims, starts, steps, vals, linearize, sub, want), 200_000,
-                      (1_234_567, 4_700_001))
-    name = it.kernel_name()
+    _, name = _full_size_checks(torch, it, obs,
+                                lambda sub, want: oracle.cubic_regular(dims, starts, steps, vals, linearize, sub, want),
+                                200_000, (1_234_567, 4_700_001))
     tbytes, si, sj = it.table_layout()
     assert name.startswith("interpn::k_cubic_brick<double, 4, false, true,"), name
     assert tbytes >= 8 * n**4  # a re-laid copy is in use (its layout is the heuristic's choice)
@@ -796,10 +795,10 @@ def test_cfg5_shard_full_size(oracle):
     gen.manual_seed(79)
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(3)]
     it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
-    _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
-                      500_000, (61_234_567, 77_000_001))
-    name = it.kernel_name()
-    assert name.startswith("interpn::k_linear_brick<double, 3, false, true,"), name
+    _, name = _full_size_checks(torch, it, obs,
+                                lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
+                                500_000, (61_234_567, 77_000_001))
+    assert name == "interpn::k_linear_brick<double, 3, false, true, 1, 1, 2, 0>", name
     it.close()
     mesh = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
     lin = np.ascontiguousarray(mesh @ np.array([0.5, -1.25, 2.0]) + 0.75)
