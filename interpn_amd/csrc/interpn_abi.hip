@@ -453,7 +453,18 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
   int si = 0, sj = 0;
-  if (env && strlen(env) == 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2')) {
+  bool cell = false;
+  const size_t MiB = (size_t)1 << 20;
+  const size_t esz = g.dtype == kF64 ? 8 : 4;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  auto fits = [&](size_t b) { return b <= free_b / 4 && b <= ((size_t)16 << 30) && b / esz < 0xFFFFFFFFull; };
+  unsigned nbc[4] = {0, 0, 0, 0};
+  size_t bcell = 0;
+  if (g.ndims >= 4) brick_cell_geometry(g, nbc, &bcell);
+  if (env && !strcmp(env, "c4") && g.ndims >= 4) {
+    cell = true;  // forced 4-D cell bricks (tests / tuning); INTERPN_HIP_BRICKS=c4 is ignored for N = 3
+  } else if (env && strlen(env) == 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2')) {
     si = env[0] - '0';
     sj = env[1] - '0';
   } else {
@@ -464,17 +475,19 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     // HBM-resident: random 128-B lines stream at > 5 TB/s, so fewer lines per point is all that
     // counts).  In between (56^3 .. 80^3 in f64) the layouts that stay mostly L2-resident win:
     // (1,2) while it fits, then (2,2).
-    const size_t MiB = (size_t)1 << 20;
+    // N >= 4: the 4-D cell bricks halve the lines per point again (2^(N-4) instead of 2^(N-3) for
+    // the fully overlapped 3-D bricks) at 3x their size; they follow the same rule one level up:
+    // taken while L2-sized, and once the 3-D layouts no longer fit the L2 either.
     unsigned nb[3];
     size_t b11, b12, b22;
     brick_geometry(g, 1, 1, nb, &b11);
     brick_geometry(g, 1, 2, nb, &b12);
     brick_geometry(g, 2, 2, nb, &b22);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-    const size_t esz = g.dtype == kF64 ? 8 : 4;
-    auto fits = [&](size_t b) { return b <= free_b / 4 && b <= ((size_t)16 << 30) && b / esz < 0xFFFFFFFFull; };
-    if (fits(b11)) {
+    // (tools/sweep_linear_nd.py, profiles/r02_sweep_linear_nd.txt: within 6 % of the best forced
+    // layout at every size, N = 4..6)
+    if (g.ndims >= 4 && fits(bcell) && (bcell <= 6 * MiB || b22 > 3 * MiB)) {
+      cell = true;
+    } else if (fits(b11)) {
       if (b11 <= 6 * MiB || b22 > 6 * MiB) { si = 1; sj = 1; }
       else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
       else { si = 2; sj = 2; }
@@ -483,15 +496,22 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     else return INTERPN_HIP_OK;  // stay on the C-order kernel
   }
   size_t bytes;
-  brick_geometry(g, si, sj, g.brick_nb, &bytes);
+  if (cell) {
+    bytes = bcell;
+    for (int k = 0; k < 4; ++k) g.brick_nb[k] = nbc[k];
+    si = sj = 1;
+  } else {
+    brick_geometry(g, si, sj, g.brick_nb, &bytes);
+    g.brick_nb[3] = 0;
+  }
   // brick element offsets are 32-bit in the kernel
-  if (bytes / (g.dtype == kF64 ? 8 : 4) >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) return INTERPN_HIP_OK;
+  if (bytes / esz >= 0xFFFFFFFFull) return INTERPN_HIP_OK;
+  if (bytes > free_b / 2) return INTERPN_HIP_OK;
   g.brick_step[0] = si;
   g.brick_step[1] = sj;
+  g.brick_cell = cell ? 1 : 0;
   hipError_t e = pool_alloc(h->device, &h->bricks_owned, bytes);
-  if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; return INTERPN_HIP_OK; }
+  if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; g.brick_cell = 0; return INTERPN_HIP_OK; }
   HIP_TRY(build_bricks(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   g.bricks = h->bricks_owned;
@@ -970,8 +990,10 @@ size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* st
   if (step_j) *step_j = g.brick_step[1];
   size_t bytes = 0;
   unsigned nb[3];
+  unsigned nb4[4];
   if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
+  else if (g.brick_cell) brick_cell_geometry(g, nb4, &bytes);
   else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   return bytes;
 }

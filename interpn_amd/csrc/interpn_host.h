@@ -37,12 +37,13 @@ struct LaunchConfig {
 struct KernelTag {
   const char* name = nullptr;  // static string, e.g. "k_linear_brick"
   int nargs = 0;
-  int args[8] = {0};
+  int args[12] = {0};
   unsigned bool_mask = 0;      // bit k set: args[k] is a bool template parameter
   void set(const char* nm, std::initializer_list<int> a, unsigned bools) {
     name = nm;
     nargs = 0;
-    for (int v : a) args[nargs++] = v;
+    for (int v : a)
+      if (nargs < 12) args[nargs++] = v;
     bool_mask = bools;
   }
 };
@@ -77,9 +78,12 @@ struct GridDesc {
   double axis_lscale[8] = {0};
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
+  // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell
+  // per line); brick_nb[3] then counts the bricks along dimension N-4.
   const void* bricks = nullptr;
   int brick_step[2] = {2, 2};
-  unsigned brick_nb[3] = {0, 0, 0};
+  unsigned brick_nb[4] = {0, 0, 0, 0};
+  int brick_cell = 0;
   // check_bounds limits per dimension, in the element type's arithmetic
   // (multilinear/regular.rs:160-166: starts + steps*(dims-1), min/max; rectilinear.rs:121-123).
   double bound_lo[8] = {0};
@@ -129,6 +133,7 @@ hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t
 
 // Bricked multilinear path (k_linear_brick.hip).
 void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes);
+void brick_cell_geometry(const GridDesc& g, unsigned nb[4], size_t* bytes);
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,

@@ -27,7 +27,40 @@ void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* b
   *bytes = lead * nb[0] * nb[1] * nb[2] * 128;
 }
 
+// 4-D cell bricks (linear_brick.h, CELL == 1): nb = bricks along (i, j, k, h), all steps 1 except
+// KW-1 along k.
+void brick_cell_geometry(const GridDesc& g, unsigned nb[4], size_t* bytes) {
+  const int N = g.ndims;
+  const int kw = g.dtype == kF64 ? 2 : 4;
+  nb[0] = bricks_along(g.n[N - 3], 1);
+  nb[1] = bricks_along(g.n[N - 2], 1);
+  nb[2] = kw == 2 ? bricks_along(g.n[N - 1], 1) : bricks_along(g.n[N - 1], kw - 1);
+  nb[3] = bricks_along(g.n[N - 4], 1);
+  size_t lead = 1;
+  for (int d = 0; d < N - 4; ++d) lead *= (size_t)g.n[d];
+  *bytes = lead * nb[3] * nb[0] * nb[1] * nb[2] * 128;
+}
+
+static hipError_t build_cell_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
+  const int N = g.ndims;
+  size_t lead = 1;
+  for (int d = 0; d < N - 4; ++d) lead *= (size_t)g.n[d];
+  const size_t elems = lead * g.brick_nb[3] * g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (g.dtype == kF64 ? 16 : 32);
+  size_t blocks = (elems + kBlock - 1) / kBlock;
+  if (blocks > 65535) blocks = 65535;
+  if (g.dtype == kF64)
+    hipLaunchKernelGGL(k_build_cell_bricks<double>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                       static_cast<const double*>(g.vals), static_cast<double*>(bricks), lead, g.n[N - 4], g.n[N - 3],
+                       g.n[N - 2], g.n[N - 1], g.brick_nb[3], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
+  else
+    hipLaunchKernelGGL(k_build_cell_bricks<float>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                       static_cast<const float*>(g.vals), static_cast<float*>(bricks), lead, g.n[N - 4], g.n[N - 3],
+                       g.n[N - 2], g.n[N - 1], g.brick_nb[3], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
+  return hipGetLastError();
+}
+
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
+  if (g.brick_cell) return build_cell_bricks(g, bricks, stream);
   const int N = g.ndims;
   size_t lead = 1;
   for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
@@ -48,7 +81,14 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
 template <typename T, int N, bool RECT, bool FMA, int PPL, int AXR>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
-  g.tag.set("k_linear_brick", {N, RECT, FMA, si == 1 ? 1 : 2, (si == 1 && sj == 1) ? 1 : 2, PPL, AXR}, 0b0000110u);
+  if constexpr (N >= 4) {
+    if (g.brick_cell) {
+      g.tag.set("k_linear_brick", {N, RECT, FMA, 1, 1, PPL, AXR, 0, 1}, 0b000000110u);
+      hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR, 0, 1>), dim3(blocks), dim3(kBlock), lds, stream, a);
+      return hipGetLastError();
+    }
+  }
+  g.tag.set("k_linear_brick", {N, RECT, FMA, si == 1 ? 1 : 2, (si == 1 && sj == 1) ? 1 : 2, PPL, AXR, 0, 0}, 0b000000110u);
   if (si == 1 && sj == 1) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
   else if (si == 1 && sj == 2) hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
   else hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 2, 2, PPL, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a);
@@ -110,11 +150,14 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   }
   a.nbj = g.brick_nb[1];
   a.nbk = g.brick_nb[2];
-  unsigned acc = g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (unsigned)BrickGeom<T>::ELEMS;
+  // Table offset per unit of each leading index.  3-D bricks: every leading dimension indexes
+  // whole tables of the last three.  4-D cell bricks: dimension N-4 (h) indexes bricks (one brick
+  // row per h cell), the dimensions in front of it whole 4-D tables.
+  unsigned acc = g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (g.dtype == kF64 ? 16u : 32u);
   a.lead_stride[0] = 0;
   for (int d = N - 4; d >= 0; --d) {
     a.lead_stride[d] = acc;
-    acc *= (unsigned)g.n[d];
+    acc *= (g.brick_cell && d == N - 4) ? g.brick_nb[3] : (unsigned)g.n[d];
   }
   size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16;
   a.ax.use_lds = 0;

@@ -20,10 +20,18 @@
 
 namespace interpn {
 
-template <typename T> struct BrickGeom {
-  static constexpr int KW = 32 / (int)sizeof(T);  // elements per brick row (32 B)
-  static constexpr int SK = KW - 1;               // brick step along k
-  static constexpr int ELEMS = 4 * KW;            // elements per brick (128 B)
+// CELL == 0: 2(i) x 2(j) x KW(k) bricks over the LAST THREE dimensions, KW = 32 bytes of elements
+//            (4 f64 / 8 f32), stepped (SI, SJ, KW-1); one brick = one (i,j) group = 128 B.
+// CELL == 1: 2(h) x 2(i) x 2(j) x KW(k) bricks over the LAST FOUR dimensions, KW = 16 bytes of
+//            elements (2 f64 / 4 f32), stepped (1, 1, 1, KW-1): a whole 4-D cell (16 f64) is ONE
+//            128-B line, where the 3-D bricks need two (one per h plane).  16x the grid in f64
+//            (10.7x in f32).  The brick holds its two h planes as two (i,j) groups of 64 B, so the
+//            h-pair is reached with an in-brick offset of IJ elements instead of a table stride.
+template <typename T, int CELL = 0> struct BrickGeom {
+  static constexpr int KW = (CELL ? 16 : 32) / (int)sizeof(T);  // elements per brick row
+  static constexpr int SK = KW - 1;                             // brick step along k
+  static constexpr int IJ = 4 * KW;                             // elements of one (i,j) group: the four pieces of a gather
+  static constexpr int ELEMS = (CELL ? 2 : 1) * IJ;             // elements per brick (128 B)
 };
 
 template <typename T, int N>
@@ -42,15 +50,15 @@ struct BrickArgs {
   unsigned iters;  // kBlock-wide iterations per workgroup
 };
 
-template <typename T, int SI, int SJ>
+template <typename T, int SI, int SJ, int CELL = 0>
 __device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj) {
-  constexpr int KW = BrickGeom<T>::KW;
+  constexpr int KW = BrickGeom<T, CELL>::KW;
   int bi, oi, bj, oj;
   if (SI == 1) { bi = i; oi = di; }
   else { bi = i >> 1; oi = (i & 1) + di; if (oi == 2) { bi += 1; oi = 0; } }
   if (SJ == 1) { bj = j; oj = dj; }
   else { bj = j >> 1; oj = (j & 1) + dj; if (oj == 2) { bj += 1; oj = 0; } }
-  return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
+  return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T, CELL>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
 }
 
 #ifndef INTERPN_PIECE_ROW
@@ -91,14 +99,58 @@ __device__ __forceinline__ Cell<T> gather_cell(const T* __restrict__ bricks, con
   return c;
 }
 
+// Two cooperative gathers with all eight loads issued before the first LDS exchange (the two
+// halves of a 4-D cell share one line when CELL == 1; otherwise twice the lines are in flight).
+template <typename T>
+__device__ __forceinline__ void gather_cell_pair(const T* __restrict__ bricks, const uint4& toff, unsigned d0, unsigned d1,
+                                                 typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q,
+                                                 Cell<T>& c0, Cell<T>& c1) {
+  typedef typename LeafVec<T, 2>::type P;
+  P pa[4], pb[4];
+  pa[0] = *reinterpret_cast<const P*>(bricks + toff.x + d0);
+  pa[1] = *reinterpret_cast<const P*>(bricks + toff.y + d0);
+  pa[2] = *reinterpret_cast<const P*>(bricks + toff.z + d0);
+  pa[3] = *reinterpret_cast<const P*>(bricks + toff.w + d0);
+  pb[0] = *reinterpret_cast<const P*>(bricks + toff.x + d1);
+  pb[1] = *reinterpret_cast<const P*>(bricks + toff.y + d1);
+  pb[2] = *reinterpret_cast<const P*>(bricks + toff.z + d1);
+  pb[3] = *reinterpret_cast<const P*>(bricks + toff.w + d1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pa[r];
+  wave_sync();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const P w = lds_piece[(quad * 4 + q) * kPieceRow + p];
+    c0.v[p >> 1][p & 1][0] = w.x;
+    c0.v[p >> 1][p & 1][1] = w.y;
+  }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pb[r];
+  wave_sync();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const P w = lds_piece[(quad * 4 + q) * kPieceRow + p];
+    c1.v[p >> 1][p & 1][0] = w.x;
+    c1.v[p >> 1][p & 1][1] = w.y;
+  }
+  wave_sync();
+}
+
 // Reduce leading dimensions 0..D-1 (dim 0 innermost), element-wise on the 8 trailing corners.
+// `ls[d]` is the table offset between the two footprint values of leading dimension d.
 template <typename T, int D, bool FMA>
 struct LeadReduce {
   __device__ __forceinline__ static Cell<T> run(const T* __restrict__ bricks, const uint4& toff, unsigned delta,
-                                                const unsigned* lead_stride, const T* t,
+                                                const unsigned* ls, const T* t,
                                                 typename LeafVec<T, 2>::type* lds_piece, unsigned quad, unsigned q) {
-    const Cell<T> a = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta, lead_stride, t, lds_piece, quad, q);
-    const Cell<T> b = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta + lead_stride[D - 1], lead_stride, t, lds_piece, quad, q);
+    Cell<T> a, b;
+    if constexpr (D == 1) {
+      gather_cell_pair<T>(bricks, toff, delta, delta + ls[0], lds_piece, quad, q, a, b);
+    } else {
+      a = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta, ls, t, lds_piece, quad, q);
+      b = LeadReduce<T, D - 1, FMA>::run(bricks, toff, delta + ls[D - 1], ls, t, lds_piece, quad, q);
+    }
     Cell<T> r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -144,11 +196,13 @@ __device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int 
   return start + step * ((T)(n - 1) * ((T)(h >> 8) * (T)(1.0 / 16777216.0)));
 }
 
-template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0, int ABL = 0>
+template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0, int ABL = 0, int CELL = 0>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
+  static_assert(CELL == 0 || (N >= 4 && SI == 1 && SJ == 1), "4-D cell bricks: N >= 4, fully overlapped");
   typedef typename LeafVec<T, 2>::type P;
+  typedef BrickGeom<T, CELL> Geom;
   constexpr int L = N - 3;
-  constexpr int SK = BrickGeom<T>::SK;
+  constexpr int SK = Geom::SK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
@@ -325,11 +379,11 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
 #pragma unroll
       for (int d = 0; d < L; ++d) lead += (unsigned)loc[d] * a.lead_stride[d];
       const unsigned bk = (unsigned)loc[N - 1] / (unsigned)SK;
-      const unsigned kpart = bk * (unsigned)BrickGeom<T>::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
+      const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[N - 1] - bk * (unsigned)SK);
       if constexpr (ABL != 1) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
+          lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
         wave_sync();
       }
       Cell<T> c;
@@ -338,7 +392,12 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         for (int e = 0; e < 8; ++e) c.v[e >> 2][(e >> 1) & 1][e & 1] = t[e % N] + (T)(kpart + lead + (unsigned)e);
       } else {
         const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
-        c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, a.lead_stride, t, lds_piece, quad, q);
+        // offsets between the two footprint values of each leading dimension: whole brick tables,
+        // except the h dimension of 4-D cell bricks, whose pair sits inside the brick
+        unsigned ls[L > 0 ? L : 1];
+#pragma unroll
+        for (int d = 0; d < L; ++d) ls[d] = (CELL && d == L - 1) ? (unsigned)Geom::IJ : a.lead_stride[d];
+        c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, ls, t, lds_piece, quad, q);
       }
       // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
       T r[2];
@@ -390,6 +449,34 @@ __global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ v
     const int k = (int)bk * (KW - 1) + (int)(within % KW);
     T v = (T)0;
     if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];
+    bricks[e] = v;
+  }
+}
+
+// 4-D cell bricks: table[lead][bh][bi][bj][bk][dh][di][dj][KW], all steps 1 except KW-1 along k.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_cell_bricks(const T* __restrict__ vals, T* __restrict__ bricks, size_t nlead,
+                                                              int nh, int n0, int n1, int n2, unsigned nbh, unsigned nbi,
+                                                              unsigned nbj, unsigned nbk) {
+  typedef BrickGeom<T, 1> G;
+  const size_t per_lead = (size_t)nbh * nbi * nbj * nbk * G::ELEMS;
+  const size_t total = nlead * per_lead;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const size_t lead = e / per_lead;
+    size_t b = e - lead * per_lead;
+    const unsigned within = (unsigned)(b % G::ELEMS);
+    b /= G::ELEMS;
+    const unsigned bk = (unsigned)(b % nbk); b /= nbk;
+    const unsigned bj = (unsigned)(b % nbj); b /= nbj;
+    const unsigned bi = (unsigned)(b % nbi); b /= nbi;
+    const unsigned bh = (unsigned)b;
+    const int h = (int)bh + (int)(within / G::IJ);
+    const unsigned wij = within % G::IJ;
+    const int i = (int)bi + (int)(wij / (2 * G::KW));
+    const int j = (int)bj + (int)((wij / G::KW) & 1);
+    const int k = (int)bk * G::SK + (int)(wij % G::KW);
+    T v = (T)0;
+    if (h < nh && i < n0 && j < n1 && k < n2) v = vals[(((lead * nh + h) * n0 + i) * n1 + j) * n2 + k];
     bricks[e] = v;
   }
 }

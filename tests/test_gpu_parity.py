@@ -129,7 +129,7 @@ def test_recursive_arm_cubic_8d(oracle, kind, linearize, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
-@pytest.mark.parametrize("layout", ["off", "11", "12", "22"])
+@pytest.mark.parametrize("layout", ["off", "11", "12", "22", "c4"])
 @pytest.mark.parametrize("axis", [[2, 2, 2], [3, 4, 5], [17, 9, 32], [64, 64, 64], [8, 7, 3], [5, 9, 8, 17],
                                   [2, 3, 2, 2, 9], [3, 2, 4, 3, 5, 4]], ids=str)
 def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
@@ -747,7 +747,7 @@ def test_cfg3_full_size_rectilinear(oracle):
     it = interpn_amd.Interpolator.rectilinear("linear", grids, vals)
     _, name = _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_rectilinear(grids, vals, sub, want),
                                 500_000, (31_234_567, 47_000_001))
-    assert name.startswith("interpn::k_linear_brick<double, 3, true, true,") and name.endswith(", 2, 2>"), name
+    assert name.startswith("interpn::k_linear_brick<double, 3, true, true,") and name.endswith(", 2, 2, 0, 0>"), name
     it.close()
 
 
@@ -798,7 +798,7 @@ def test_cfg5_shard_full_size(oracle):
     _, name = _full_size_checks(torch, it, obs,
                                 lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
                                 500_000, (61_234_567, 77_000_001))
-    assert name == "interpn::k_linear_brick<double, 3, false, true, 1, 1, 2, 0>", name
+    assert name == "interpn::k_linear_brick<double, 3, false, true, 1, 1, 2, 0, 0, 0>", name
     it.close()
     mesh = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
     lin = np.ascontiguousarray(mesh @ np.array([0.5, -1.25, 2.0]) + 0.75)
@@ -833,7 +833,7 @@ def test_handle_options_and_kernel_name(oracle):
     it.set_option("ppl", 1)
     out = it.eval_host(case.obs, np.zeros_like(want))
     assert np.array_equal(out, want)
-    assert it.kernel_name().endswith(", 1, 0>"), it.kernel_name()
+    assert it.kernel_name().endswith(", 1, 0, 0, 0>"), it.kernel_name()  # PPL = 1, AXR = 0, ABL = 0, CELL = 0
     with pytest.raises(ValueError):
         it.set_option("no_such_option", 1)
     with pytest.raises(ValueError):

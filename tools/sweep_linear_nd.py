@@ -10,7 +10,7 @@ import interpn_amd
 dev = torch.device("cuda:0")
 P = 50_000_000
 gen = torch.Generator(device=dev); gen.manual_seed(5)
-obs_all = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(5)]
+obs_all = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(6)]
 out = torch.empty(P, dtype=torch.float64, device=dev)
 
 
@@ -30,10 +30,14 @@ def run(N, n, lay):
     return round(sorted(ms)[2], 3)
 
 
-for N, sizes in ((3, (20, 28, 40, 52, 60, 68, 76, 88, 112, 160)), (4, (8, 12, 16, 20, 24, 28, 32, 40, 48)), (5, (6, 8, 10, 12, 16, 20))):
+ONLY = [int(a) for a in sys.argv[1:]]  # optional: the dimension counts to sweep
+for N, sizes in ((3, (20, 28, 40, 52, 60, 68, 76, 88, 112, 160)), (4, (8, 12, 16, 20, 24, 28, 32, 40, 48)), (5, (6, 8, 10, 12, 16, 20)),
+                 (6, (4, 6, 8, 10))):
+    if ONLY and N not in ONLY:
+        continue
     for n in sizes:
         row = {}
-        for lay in ("off", "22", "12", "11", "auto"):
+        for lay in ("off", "22", "12", "11") + (("c4",) if N >= 4 else ()) + ("auto",):
             try:
                 row[lay] = run(N, n, lay)
             except Exception as e:  # noqa: BLE001
