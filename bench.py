@@ -5,14 +5,17 @@ oracle timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-* `--gpus 1` (default): BASELINE.json configs[1] — 64^3 f64 grid, 1e8 random obs on one MI355X.
-* `--gpus N` (N > 1): BASELINE.json configs[4] — 128^3 f64 grid, 1e8 obs PER RANK (8e8 at N = 8),
-  observation points sharded contiguously, the grid generated on rank 0 and replicated by ONE RCCL
-  broadcast, no collective in the timed loop (weak scaling).  When no launcher has set WORLD_SIZE
-  this process only SPAWNS the N ranks (fresh child processes, created before anything touches a
-  GPU here) and relays rank 0's line; under `python -m torch.distributed.run ... bench.py --gpus N`
-  it is one of the ranks.
-* `--workload cfg2|cfg5` overrides the choice (e.g. the cfg5 shard on one GPU).
+* The headline (`value`, `roofline`) is BASELINE.json configs[1] at every N: 3-D multilinear-regular,
+  64^3 f64 grid, 1e8 random obs PER GPU (weak scaling over a fixed grid, as north_star asks), so
+  value(N) / value(1) compares identical per-GPU work.
+* `--gpus N` (N > 1): observation points sharded contiguously, the grid generated on rank 0 and
+  replicated by ONE RCCL broadcast, no collective in the timed loop.  The record then carries a
+  second block `cfg5` = BASELINE.json configs[4] measured by the same protocol: 128^3 grid, 1e8 obs
+  per rank (8e8 over 8 GPUs), with per-rank kernel times and the same workload on one GPU alone.
+  When no launcher has set WORLD_SIZE this process only SPAWNS the N ranks (fresh child processes,
+  created before anything touches a GPU here) and relays rank 0's line; under
+  `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
+* `--workload cfg5` makes the 128^3 grid the headline instead (e.g. its shard on one GPU).
 
 A step is one pass of the hot path over one batch: one `interpn_hip_eval_device` launch over the
 rank's device-resident points followed by the status check (`interpn_hip_finish`).  Inputs are
@@ -59,13 +62,14 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg5"],
-                    help="auto = cfg2 on one GPU, cfg5 (128^3, 1e8 obs per rank) on several")
+                    help="headline grid: auto = cfg2 (64^3) at every N; cfg5 = 128^3")
     ap.add_argument("--points", type=int, default=100_000_000, help="observation points per GPU")
     ap.add_argument("--grid", type=int, default=0, help="grid points per axis (0 = the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="points for the CPU baseline (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration table (N = 1)")
     ap.add_argument("--no-ablate", action="store_true", help="skip the stream-only / gather-only ablation (N = 1)")
+    ap.add_argument("--no-cfg5", action="store_true", help="N > 1: skip the second block on the 128^3 grid (BASELINE configs[4])")
     ap.add_argument("--sustain-seconds", type=float, default=0.5)
     # Test aids for a 1-GPU box: run the multi-rank control flow with every rank on cuda:0 over
     # gloo (RCCL refuses two ranks on one device).  The driver never passes these.
@@ -432,25 +436,13 @@ def worker(args):
         world = dist.get_world_size()  # what the process group actually is
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    workload = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg5")
-    n = args.grid or WORKLOADS[workload][0]
     P = args.points
     NDIMS = 3
     bpp = 8 * (NDIMS + 1)  # read 3 f64 coordinates + write 1 f64 result
-    spec = build_spec("linear", "regular", n, NDIMS, False, seed=1)
 
-    # Grid: generated on rank 0, replicated read-only on every GPU by ONE RCCL broadcast.
-    vals_dev = torch.empty(n**NDIMS, dtype=torch.float64, device=dev)
-    if rank == 0:
-        vals_dev.copy_(torch.from_numpy(spec["vals"]))
-    if world > 1:
-        if args.backend == "nccl":
-            dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
-        else:
-            stage = vals_dev.cpu()
-            dist.broadcast(stage, src=0)
-            vals_dev.copy_(stage)
-    it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     # Observation shard of this rank: i.i.d. uniform over the grid extent, device resident.
     gen = torch.Generator(device=dev)
@@ -458,49 +450,88 @@ def worker(args):
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(NDIMS)]
     out = torch.empty(P, dtype=torch.float64, device=dev)
 
-    def barrier():
+    def measure(n):
+        """One workload (n^3 grid, this rank's P points) by the bench contract: grid generated on
+        rank 0 and replicated by ONE broadcast, W warm-up steps, EXACTLY K timed steps between
+        barrier + synchronize pairs, max over ranks.  Returns (record pieces, handle, spec)."""
+        spec = build_spec("linear", "regular", n, NDIMS, False, seed=1)
+        vals_dev = torch.empty(n**NDIMS, dtype=torch.float64, device=dev)
+        if rank == 0:
+            vals_dev.copy_(torch.from_numpy(spec["vals"]))
         if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        it.eval_tensors(obs, out)
-        it.finish()
-
-    # Same workload on ONE GPU with the others idle (rank 0 alone), so that the scaling of the
-    # N-rank line can be read against an identical single-GPU figure taken in the same run.
-    solo_ms = None
-    if world > 1:
+            if args.backend == "nccl":
+                dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
+            else:
+                stage = vals_dev.cpu()
+                dist.broadcast(stage, src=0)
+                vals_dev.copy_(stage)
+        it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
+        for _ in range(args.warmup):
+            it.eval_tensors(obs, out)
+            it.finish()
+        # Same workload on ONE GPU with the others idle (rank 0 alone), so that the N-rank figure can
+        # be read against an identical single-GPU one taken in the same run.
+        solo_ms = None
+        if world > 1:
+            torch.cuda.synchronize()
+            barrier()
+            if rank == 0:
+                solo_ms = float(np.mean(time_launches(torch, it, obs, out, launches=max(20, min(args.steps, 200)),
+                                                      finish_each=True)))
+            barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         torch.cuda.synchronize()
         barrier()
-        if rank == 0:
-            solo_ms = float(np.mean(time_launches(torch, it, obs, out, launches=max(20, min(args.steps, 200)),
-                                                  finish_each=True)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            it.eval_tensors(obs, out)
+            ev[k][1].record()
+            it.finish()
+        torch.cuda.synchronize()
         barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms_local = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        t = torch.tensor([elapsed, kernel_ms_local], dtype=torch.float64, device=coll_dev)
+        per_rank_ms = [kernel_ms_local]
+        if world > 1:
+            gathered = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+            dist.all_gather(gathered, torch.tensor([kernel_ms_local], dtype=torch.float64, device=coll_dev))
+            per_rank_ms = [float(x[0]) for x in gathered]
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"elapsed": float(t[0]), "kernel_ms": float(t[1]), "per_rank_ms": per_rank_ms, "solo_ms": solo_ms,
+                "vals_dev": vals_dev}, it, spec
 
-    # ---- the timed region: exactly K steps ---------------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        it.eval_tensors(obs, out)
-        ev[k][1].record()
-        it.finish()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    kernel_ms_local = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms_local], dtype=torch.float64, device=coll_dev)
-    per_rank_ms = [kernel_ms_local]
-    if world > 1:
-        gathered = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([kernel_ms_local], dtype=torch.float64, device=coll_dev))
-        per_rank_ms = [float(x[0]) for x in gathered]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms = float(t[0]), float(t[1])
+    # The headline workload keeps ONE grid for every N (north_star: "throughput on synthetic random
+    # obs over a fixed grid reported at 1/2/4/8 GPUs"): BASELINE configs[1]'s 64^3 grid, 1e8 obs per
+    # rank (weak scaling), so value(N) / value(1) is a scaling figure on identical per-GPU work.
+    # BASELINE configs[4] (128^3 grid, 1e8 obs per rank = 8e8 over 8 GPUs) is measured by the same
+    # protocol as a second block ("cfg5") whenever N > 1; at N = 1 its shard is a row of configs[].
+    workload = args.workload if args.workload != "auto" else "cfg2"
+    n = args.grid or WORKLOADS[workload][0]
+    m, it, spec = measure(n)
+    elapsed, kernel_ms, per_rank_ms, solo_ms = m["elapsed"], m["kernel_ms"], m["per_rank_ms"], m["solo_ms"]
+    second = None
+    if world > 1 and workload == "cfg2" and not args.grid and not args.no_cfg5:
+        m5, it5, _ = measure(WORKLOADS["cfg5"][0])
+        if rank == 0:
+            tb5, si5, sj5 = it5.table_layout()
+            v5 = P * world * args.steps / m5["elapsed"] / 1e6
+            a5 = P * bpp / (m5["kernel_ms"] * 1e-3) / 1e9
+            second = {
+                "workload": f"3D multilinear::regular, 128^3 f64 grid, {P:.0e} random obs per GPU = {P * world:.0e} obs over "
+                            f"{world} GPUs (BASELINE configs[4]); grid replicated by one RCCL broadcast, obs sharded, no collective in the loop",
+                "value": round(v5, 1), "unit": "Mpoints/s", "value_per_gpu": round(v5 / world, 1),
+                "ms_per_step": round(m5["elapsed"] / args.steps * 1e3, 4), "kernel": it5.kernel_name(),
+                "table_MiB": round(tb5 / 2**20, 2), "layout_steps": [si5, sj5],
+                "kernel_ms": round(m5["kernel_ms"], 4), "kernel_ms_per_rank": [round(x, 4) for x in m5["per_rank_ms"]],
+                "achieved_GBps_per_gpu": round(a5, 1), "frac": round(a5 / HBM_PEAK_GBPS, 4),
+                "single_gpu_same_workload": {"kernel_ms": round(m5["solo_ms"], 4),
+                                             "Mpoints_per_s": round(P / m5["solo_ms"] / 1e3, 1)} if m5["solo_ms"] else None,
+            }
+        it5.close()
+        del m5
 
     if rank == 0:
         kernel = it.kernel_name()
@@ -566,6 +597,8 @@ def worker(args):
                 "frac_of_measured_copy": round(achieved / copy_gbps, 4),
             },
         }
+        if second is not None:
+            rec["cfg5"] = second
         if world > 1 and solo_ms:
             rec["config"]["single_gpu_same_workload"] = {
                 "kernel_ms": round(solo_ms, 4), "Mpoints_per_s": round(P / solo_ms / 1e3, 1),

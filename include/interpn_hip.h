@@ -182,6 +182,14 @@ typedef struct interpn_hip_interp interpn_hip_interp;
 INTERPN_HIP_DECLARE_CREATE(double, f64)
 INTERPN_HIP_DECLARE_CREATE(float, f32)
 
+/* Clone `src` onto `device` (-1 = current) of the same process: the grid (and the axes of a
+ * rectilinear grid) travels device to device (hipMemcpyPeer, i.e. xGMI between the GPUs of one
+ * node; no host staging, no second upload), the re-laid table is rebuilt on the target.  The
+ * single-process way to "replicate the read-only grid on every GPU"  in
+ * front of interpn_hip_eval_host_sharded; multi-process callers broadcast `vals` with RCCL and
+ * create from the device pointer (INTERPN_HIP_MEM_DEVICE).  The clone owns its copy. */
+int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip_interp** out);
+
 /* sizeof of the element type of the interpolator (8 or 4), number of dimensions, device. */
 int interpn_hip_elem_size(const interpn_hip_interp* h);
 int interpn_hip_ndims(const interpn_hip_interp* h);

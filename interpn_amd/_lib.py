@@ -105,6 +105,7 @@ def load() -> ctypes.CDLL:
             sz, c_size_t, p, c_size_t, p, c_size_t, pp, sz, c_size_t, ct, POINTER(c_uint8), c_size_t]
         getattr(lib, f"interpn_hip_check_bounds_rectilinear_{sfx}").argtypes = [
             pp, sz, c_size_t, pp, sz, c_size_t, ct, POINTER(c_uint8), c_size_t]
+    lib.interpn_hip_replicate.argtypes = [c_void_p, c_int, POINTER(c_void_p)]
     lib.interpn_hip_elem_size.argtypes = [c_void_p]
     lib.interpn_hip_ndims.argtypes = [c_void_p]
     lib.interpn_hip_device.argtypes = [c_void_p]

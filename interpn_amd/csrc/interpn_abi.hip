@@ -940,6 +940,56 @@ int interpn_hip_device_count(void) {
 DEFINE_CREATE(double, f64)
 DEFINE_CREATE(float, f32)
 
+// Clone an interpolator onto another device of this process.  The grid (`vals`, and the axis image
+// of a rectilinear grid: coordinates + search tables) is copied DEVICE TO DEVICE with
+// hipMemcpyPeer — between two GPUs of one node that is an xGMI transfer, no host staging and no
+// second H2D upload —, the re-laid table is rebuilt on the target device.  This is the
+// single-process counterpart of the one RCCL broadcast the multi-process path does
+// (interpn_amd/sharded.py): SURVEY.md section 8(e) "grid replicated read-only on every GPU".
+int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip_interp** out) {
+  if (!src || !out) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int dev;
+  int st = resolve_device(device, &dev);
+  if (st) return st;
+  DeviceGuard guard(dev);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  interpn_hip_interp* h = new (std::nothrow) interpn_hip_interp();
+  if (!h) return INTERPN_HIP_ERR_OUT_OF_MEMORY;
+  h->device = dev;
+  GridDesc& g = h->desc;
+  g = src->desc;  // scalars, axis-image offsets, options; every device pointer is replaced below
+  g.vals = nullptr;
+  g.bricks = nullptr;
+  g.brick_cell = 0;
+  g.axis_image = nullptr;
+  g.tag = KernelTag();
+  for (int d = 0; d < 8; ++d) g.grid[d] = nullptr;
+  const size_t elem = g.dtype == kF64 ? 8 : 4;
+  hipError_t e = pool_alloc(dev, &h->vals_owned, g.nvals * elem);
+  if (e == hipSuccess) e = hipMemcpyPeer(h->vals_owned, dev, src->desc.vals, src->device, g.nvals * elem);
+  if (e == hipSuccess && src->desc.axis_image && g.axis_image_bytes) {
+    e = pool_alloc(dev, &h->grids_owned, g.axis_image_bytes);
+    if (e == hipSuccess) e = hipMemcpyPeer(h->grids_owned, dev, src->desc.axis_image, src->device, g.axis_image_bytes);
+    if (e == hipSuccess) {
+      g.axis_image = h->grids_owned;
+      for (int d = 0; d < g.ndims; ++d) g.grid[d] = (const char*)h->grids_owned + g.axis_g_off[d];
+    }
+  }
+  if (e != hipSuccess) {
+    interpn_hip_destroy(h);
+    return hip_fail(e);
+  }
+  // finish_create with a device `vals` borrows the pointer; here the clone owns it (vals_owned).
+  st = finish_create(h, h->vals_owned, g.nvals, elem, INTERPN_HIP_MEM_DEVICE);
+  if (st) {
+    interpn_hip_destroy(h);
+    return st;
+  }
+  *out = h;
+  return INTERPN_HIP_OK;
+}
+
 int interpn_hip_elem_size(const interpn_hip_interp* h) { return h ? (h->desc.dtype == kF64 ? 8 : 4) : 0; }
 int interpn_hip_ndims(const interpn_hip_interp* h) { return h ? h->desc.ndims : 0; }
 int interpn_hip_device(const interpn_hip_interp* h) { return h ? h->device : -1; }

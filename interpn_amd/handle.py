@@ -78,6 +78,13 @@ class Interpolator:
         _lib.raise_for_status(st)
         return cls(h.value, dtype, ng, keep if mem == _lib.MEM_DEVICE else None)
 
+    def replicate(self, device: int = -1) -> "Interpolator":
+        """Clone onto another GPU of this process, grid copied device to device
+        (`interpn_hip_replicate`); the clone owns its copy."""
+        h = c_void_p()
+        _lib.raise_for_status(_lib.load().interpn_hip_replicate(self._h, int(device), ctypes.byref(h)))
+        return Interpolator(h.value, self.dtype, self._ndims)
+
     # -- evaluation -----------------------------------------------------------------------
     def ndims(self) -> int:
         return self._ndims

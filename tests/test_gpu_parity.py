@@ -841,6 +841,33 @@ def test_handle_options_and_kernel_name(oracle):
     it.close()
 
 
+@pytest.mark.parametrize("method,kind,axis", [("linear", "regular", [20, 21, 22]), ("linear", "rectilinear", [33, 9, 40]),
+                                              ("cubic", "rectilinear", [9, 8, 7]), ("linear", "regular", [9, 8, 7, 6]),
+                                              ("nearest", "rectilinear", [300, 40])])
+def test_replicate_device_to_device(oracle, method, kind, axis):
+    """interpn_hip_replicate clones a handle onto a device with a device-to-device copy of the grid
+    (and of the rectilinear axis image) and rebuilds the re-laid table there.  On a 1-GPU box the
+    target is the same device: the clone must own its memory (the source is destroyed first) and
+    give the oracle's bits; the pair then serves interpn_hip_eval_host_sharded."""
+    import interpn_amd
+    from interpn_amd.handle import eval_host_sharded
+
+    case = synthetic_case(method, kind, len(axis), axis, 30_011, 17 + sum(axis), np.float64, linearize=True, extrap=0.1)
+    want = run_oracle(oracle, case, True)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals, True)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals, True)
+    clone = it.replicate(0)
+    both = eval_host_sharded([it, clone], case.obs, np.zeros_like(want))
+    assert_parity(case, both, want)
+    it.close()
+    out = clone.eval_host(case.obs, np.zeros_like(want))
+    assert_parity(case, out, want)
+    assert clone.table_layout()[0] > 0 or method == "nearest"
+    clone.close()
+
+
 def test_destroy_does_not_wait_for_other_streams(oracle):
     """interpn_hip_destroy waits for the handle's own work only: a long-running
     kernel on an unrelated stream must still be running when destroy returns."""
