@@ -864,7 +864,6 @@ def test_replicate_device_to_device(oracle, method, kind, axis):
     it.close()
     out = clone.eval_host(case.obs, np.zeros_like(want))
     assert_parity(case, out, want)
-    assert clone.table_layout()[0] > 0 or method == "nearest"
     clone.close()
 
 
