@@ -588,6 +588,7 @@ def worker(args):
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel": kernel,
+                "table_bytes": tbytes,
                 "table_MiB": round(tbytes / 2**20, 2),
                 "layout_steps": [si, sj],
                 "kernel_ms": round(kernel_ms, 4),

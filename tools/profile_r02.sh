@@ -44,6 +44,9 @@ for lay in off 44 24 22 14 11 auto; do
   timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --kernel-trace --output-format csv -d $OUT/c4_layout_$lay -- $PY $R/tools/bench_configs.py --only "cfg4 4D cubic regular 32^4 1e7 (linearize=false)" > $OUT/c4_layout_$lay.log 2>&1 || echo "layout $lay pmc failed"
 done
 unset INTERPN_HIP_BRICKS
+# ---- E: host-pointer paths (PCIe-inclusive) and small-call latency; 4-D linear after the cell bricks
+timeout 300 $PY $R/tools/bench_host_path.py > $OUT/host_path.txt 2>&1
+timeout 300 $PY $R/tools/bench_configs.py > $OUT/bench_configs.txt 2>&1
 
 $PY - <<'PY'
 import csv, glob, json, os, collections
@@ -79,7 +82,7 @@ if res.get('FETCH_SIZE_bench_KiB') and res.get('WRITE_SIZE_bench_KiB'):
     res.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr, points=P, grid=64)
     if bench:
         res['kernel'] = bench['roofline']['kernel']
-        res['table_bytes'] = int(round(bench['roofline']['table_MiB'] * 2**20))
+        res['table_bytes'] = bench['roofline'].get('table_bytes')
     res['source'] = ('profiles/r02_bench_traffic.json: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of bench.py '
                      '(tools/profile_r02.sh), read side corrected by the factor measured on a stream kernel of known byte count '
                      'with the same 16-B/lane non-temporal access pattern; fabric-side bytes of the L2, Infinity-Cache hits included')
