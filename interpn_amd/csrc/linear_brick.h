@@ -188,6 +188,8 @@ struct LeadReduce<T, 0, FMA> {
 //   ABL == 2  gather-only: the table gathers, the LDS exchange and the arithmetic run as usual on
 //             coordinates synthesised from the point index (uniform over the grid), nothing is
 //             read from obs and nothing is stored.
+//   ABL == 3  the unmodified data movement with the six IEEE divisions per point replaced by
+//             multiplications with a reciprocal (results differ in the last bits: timing only).
 // Their outputs are meaningless by construction.
 template <typename T>
 __device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int n) {
@@ -365,10 +367,15 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
           loc[d] = l;
         } else {
           T floc;
-          ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);          // multilinear/regular.rs:415-418
+          if constexpr (ABL == 3) {  // timing probe: what would the six IEEE divides per point cost?
+            floc = dev_floor<T>((x - a.start[d]) * ((T)1 / a.step[d]));
+          } else {
+            ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);        // multilinear/regular.rs:415-418
+          }
           const int l = clamp_loc<T>(floc, a.n[d] - 2);                     // regular.rs:420-422
           const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);          // regular.rs:334-337
-          t[d] = (x - izl) / a.step[d];                                     // regular.rs:339
+          if constexpr (ABL == 3) t[d] = (x - izl) * ((T)1 / a.step[d]);
+          else t[d] = (x - izl) / a.step[d];                                // regular.rs:339
           loc[d] = l;
         }
       }
