@@ -9,6 +9,7 @@
 // swap the piece they hold for the other point with a quad-permute DPP move — no LDS.  Arithmetic
 // and operation order are the reference's (src/multilinear/regular.rs:296-404), results are
 // bit-identical to the C-order kernel.
+#include "lane_axes.h"
 #include "rect_args.h"
 
 namespace interpn {
@@ -44,14 +45,17 @@ __device__ __forceinline__ double dpp_swap1(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-template <typename T, bool RECT, bool FMA>
+// AXR != 0 (rectilinear, both axes <= 64 coordinates): axes in lanes, see lane_axes.h.
+template <typename T, bool RECT, bool FMA, int AXR = 0>
 __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a) {
   typedef typename LeafVec<T, 2>::type P;
   constexpr int KW = Brick2Geom<T>::KW;
   constexpr int SJ = Brick2Geom<T>::SJ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (RECT && a.ax.use_lds) stage_axes<T, 2>(a.ax, smem_raw);
-  const unsigned char* axis_base = (RECT && a.ax.use_lds) ? smem_raw : a.ax.image;
+  LaneAxes<T, 2> la;
+  if constexpr (RECT && AXR != 0) la = load_lane_axes<T, 2, AXR>(a.ax);
+  else if (RECT && a.ax.use_lds) stage_axes<T, 2>(a.ax, smem_raw);
+  const unsigned char* axis_base = (RECT && AXR == 0 && a.ax.use_lds) ? smem_raw : a.ax.image;
   const unsigned lane = threadIdx.x;
   const unsigned q = lane & 1;  // which row piece this lane fetches
   const size_t nthreads = (size_t)gridDim.x * kBlock;
@@ -62,13 +66,29 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
     T t[2];
     int loc[2];
     bool ok = true;
+    T xin[1][2];
+    int cell[1][2];
+    T x0r[1][2], x1r[1][2];
+    if constexpr (RECT && AXR != 0) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) xin[0][d] = live ? stream_load(a.obs[d] + i0) : (T)0;
+      lane_axes_locate<T, 2, 1, AXR>(a.ax, la, xin, cell, x0r, x1r);
+    }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       if (RECT) {
-        const T x = live ? stream_load(a.obs[d] + i0) : (T)0;
-        const Axis<T> ax = make_axis<T, 2>(a.ax, axis_base, d);
-        T x0, x1;
-        const int l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
+        T x, x0, x1;
+        int l;
+        if constexpr (AXR != 0) {
+          x = xin[0][d];
+          l = cell[0][d];
+          x0 = x0r[0][d];
+          x1 = x1r[0][d];
+        } else {
+          x = live ? stream_load(a.obs[d] + i0) : (T)0;
+          const Axis<T> ax = make_axis<T, 2>(a.ax, axis_base, d);
+          l = axis_cell<T>(ax, x, &x0, &x1);  // multilinear/rectilinear.rs:353-370, :310-311
+        }
         const T step = x1 - x0;
         t[d] = (x - x0) / step;
         loc[d] = l;
@@ -167,10 +187,14 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax, /*big_lds=*/true);
-  const unsigned blocks = g.kind == kRegular ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
-#define GO(RECT, FMA) do { g.tag.set("k_linear2_brick", {RECT, FMA}, 0b11u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
-  if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
-  else { if (g.fma) GO(true, true); else GO(true, false); }
+  const int axr = lane_axes_mode(g);  // both axes <= 64 coordinates: searched across lanes, no LDS image
+  if (axr) lds = 0;
+  const unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
+#define GO(RECT, FMA, AXR) do { g.tag.set("k_linear2_brick", {RECT, FMA, AXR}, 0b011u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
+  if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
+  else if (axr == 2) { if (g.fma) GO(true, true, 2); else GO(true, false, 2); }
+  else if (axr == 1) { if (g.fma) GO(true, true, 1); else GO(true, false, 1); }
+  else { if (g.fma) GO(true, true, 0); else GO(true, false, 0); }
 #undef GO
   return hipGetLastError();
 }

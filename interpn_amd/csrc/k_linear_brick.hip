@@ -95,27 +95,9 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
   return hipGetLastError();
 }
 
-// Axes small enough to sit one coordinate per lane (every axis <= 64 coordinates).
-// 0: axes in LDS; 1: axes in registers, probe-sequence search; 2: registers + lane tables.
-// The handle's `axis_regs` option (latched from INTERPN_HIP_AXIS_REGS at creation) overrides:
-// 0 | 1 | 2, where 2 falls back to 1 when a table is missing.
-template <int N>
-static int axes_in_lanes(const GridDesc& g) {
-  if (g.kind != kRectilinear) return 0;
-  bool tables = true;
-  for (int d = 0; d < N; ++d) {
-    if (g.n[d] > 64) return 0;
-    tables = tables && g.axis_ltab_off[d] != 0;
-  }
-  int mode = tables ? 2 : 1;
-  if (g.cfg.axis_regs == 0) mode = 0;
-  else if (g.cfg.axis_regs == 1) mode = 1;
-  return mode;
-}
-
 template <typename T, int N, int PPL>
 static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t axis_lds, size_t npts, hipStream_t stream) {
-  const int axr = axes_in_lanes<N>(g);
+  const int axr = lane_axes_mode(g);  // axes in lanes (lane_axes.h) or 0 = LDS / L2 search
   a.iters = brick_iters(g, npts, PPL, /*per_block_setup=*/g.kind == kRectilinear && axr == 0);
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;

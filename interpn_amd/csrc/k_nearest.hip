@@ -2,6 +2,7 @@
 // src/nearest/rectilinear.rs:36-60, :193-262).  The same per-dimension index stage as the
 // multilinear kernels, then ONE gather per point: the node at origin + (dt <= 0.5 ? 0 : 1).
 // 64-bit indexing throughout (a single gather, nothing to save with 32-bit offsets).
+#include "lane_axes.h"
 #include "rect_args.h"
 
 namespace interpn {
@@ -20,23 +21,43 @@ struct NearestArgs {
   AxisArgs<T, N> ax;
 };
 
-template <typename T, int N, bool RECT, bool FMA, bool LDS>
+template <typename T, int N, bool RECT, bool FMA, bool LDS, int AXR>
 __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const unsigned char* lds) {
   const unsigned char* axbase = LDS ? lds : a.ax.image;
   const T half = (T)1 / ((T)1 + (T)1);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.npts; i += nthreads) {
+  LaneAxes<T, N> la;
+  if constexpr (RECT && AXR != 0) la = load_lane_axes<T, N, AXR>(a.ax);
+  // Wave-uniform trip count: with the axes in lanes every lane of a wave must stay active for the
+  // cross-lane reads, so the loop runs over the wave's first point and dead lanes are masked at
+  // the store only (they search for coordinate 0).
+  const size_t wave0 = (size_t)blockIdx.x * kBlock + (threadIdx.x & ~63u);
+  for (size_t w = wave0; w < a.npts; w += nthreads) {
+    const size_t i = w + (threadIdx.x & 63u);
+    const bool live = i < a.npts;
     unsigned long long idx = 0;
     bool ok = true;
+    T xin[1][N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) xin[0][d] = live ? stream_load(a.obs[d] + i) : (RECT ? (T)0 : a.start[d]);
+    int cell[1][N];
+    T x0r[1][N], x1r[1][N];
+    if constexpr (RECT && AXR != 0) lane_axes_locate<T, N, 1, AXR>(a.ax, la, xin, cell, x0r, x1r);
 #pragma unroll
     for (int d = 0; d < N; ++d) {
-      const T x = stream_load(a.obs[d] + i);
+      const T x = xin[0][d];
       int loc;
       T dt;
       if (RECT) {
-        const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
         T x0, x1;
-        loc = axis_cell<T>(ax, x, &x0, &x1);  // nearest/rectilinear.rs:248-262, :223-224
+        if constexpr (AXR != 0) {
+          loc = cell[0][d];
+          x0 = x0r[0][d];
+          x1 = x1r[0][d];
+        } else {
+          const Axis<T> ax = make_axis<T, N>(a.ax, axbase, d);
+          loc = axis_cell<T>(ax, x, &x0, &x1);  // nearest/rectilinear.rs:248-262, :223-224
+        }
         const T step = x1 - x0;
         dt = (x - x0) / step;  // rectilinear.rs:223-227
       } else {
@@ -49,19 +70,22 @@ __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const u
       const int offset = (dt <= half) ? 0 : 1;  // regular.rs:283-287 (NaN compares false => 1)
       idx += (unsigned long long)(loc + offset) * a.stride[d];
     }
-    if (!RECT && !ok) atomicMin(a.first_bad, (unsigned long long)i);
-    stream_store(a.out + i, a.vals[idx]);
+    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i);
+    if (live) stream_store(a.out + i, a.vals[idx]);
   }
 }
 
-template <typename T, int N, bool RECT, bool FMA>
+// AXR != 0 (rectilinear, every axis <= 64 coordinates): axes in lanes, see lane_axes.h.
+template <typename T, int N, bool RECT, bool FMA, int AXR = 0>
 __global__ void __launch_bounds__(kBlock) k_nearest(const NearestArgs<T, N> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (RECT && a.ax.use_lds) {
+  if constexpr (RECT && AXR != 0) {
+    nearest_body<T, N, RECT, FMA, false, AXR>(a, nullptr);
+  } else if (RECT && a.ax.use_lds) {
     stage_axes<T, N>(a.ax, smem_raw);
-    nearest_body<T, N, RECT, FMA, true>(a, smem_raw);
+    nearest_body<T, N, RECT, FMA, true, 0>(a, smem_raw);
   } else {
-    nearest_body<T, N, RECT, FMA, false>(a, nullptr);
+    nearest_body<T, N, RECT, FMA, false, 0>(a, nullptr);
   }
 }
 
@@ -87,10 +111,14 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);
-  const unsigned blocks = (g.kind == kRegular && !g.cfg.persistent) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
-#define GO(RECT, FMA) do { g.tag.set("k_nearest", {N, RECT, FMA}, 0b110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
-  if (g.kind == kRegular) { if (g.fma) GO(false, true); else GO(false, false); }
-  else GO(true, true);  // no FMA site in the rectilinear path
+  const int axr = lane_axes_mode(g);  // rectilinear axes of <= 64 coordinates: searched across lanes, no LDS image
+  if (axr) lds = 0;
+  const unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
+#define GO(RECT, FMA, AXR) do { g.tag.set("k_nearest", {N, RECT, FMA, AXR}, 0b0110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
+  if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
+  else if (axr == 2) GO(true, true, 2);  // no FMA site in the rectilinear path
+  else if (axr == 1) GO(true, true, 1);
+  else GO(true, true, 0);
 #undef GO
   return hipGetLastError();
 }

@@ -16,6 +16,7 @@
 // src/multilinear/regular.rs:347-403), so results are bit-identical to the C-order kernels.
 #pragma once
 
+#include "lane_axes.h"
 #include "rect_args.h"
 
 namespace interpn {
@@ -209,23 +210,9 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]
   unsigned char* lds_axes = smem_raw + kBlock * kPieceRow * sizeof(P) + kBlock * 16;
-  T greg[N];
-  unsigned ltab[N];
-  unsigned scan = 0;
+  LaneAxes<T, N> la;
   if constexpr (RECT && AXR != 0) {
-    const int wl = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int d = 0; d < N; ++d) {
-      const T* g = reinterpret_cast<const T*>(a.ax.image + a.ax.g_off[d]);
-      greg[d] = g[wl < a.ax.n[d] ? wl : a.ax.n[d] - 1];
-      if constexpr (AXR == 2) {
-        const unsigned* words = reinterpret_cast<const unsigned*>(a.ax.image + a.ax.ltab_off[d]);
-        ltab[d] = words[wl];
-        const unsigned pop = words[64];  // uniform
-        scan = pop > scan ? pop : scan;
-      }
-    }
-    scan = __builtin_amdgcn_readfirstlane(scan);
+    la = load_lane_axes<T, N, AXR>(a.ax);
   } else if (RECT && a.ax.use_lds) {
     stage_axes<T, N>(a.ax, lds_axes);
   }
@@ -267,81 +254,10 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
 #pragma unroll
       for (int d = 0; d < N; ++d) xin[0][d] = live[0] ? stream_load(a.obs[d] + i0) : (RECT ? (T)0 : a.start[d]);
     }
-    // AXR: the PPL x N binary searches advance in lockstep (six fixed halving steps cover 64
-    // coordinates), so every step issues PPL*N independent cross-lane reads instead of one.
+    // AXR: the PPL x N axis searches advance in lockstep across lanes (lane_axes.h).
     int cell_r[PPL][N];
     T x0_r[PPL][N], x1_r[PPL][N];
-    if constexpr (RECT && AXR != 0) {
-      // cell_r <- partition_point(g < x) (multilinear/rectilinear.rs:363) ...
-      if constexpr (AXR == 1) {
-        int size[N];
-#pragma unroll
-        for (int d = 0; d < N; ++d) size[d] = a.ax.n[d];
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d) cell_r[h][d] = 0;
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-#pragma unroll
-          for (int d = 0; d < N; ++d) {
-            const int half = size[d] >> 1;  // 0 once size is 1: the probe then re-reads g[base] and keeps base
-#pragma unroll
-            for (int h = 0; h < PPL; ++h) {
-              const int mid = cell_r[h][d] + half;
-              cell_r[h][d] = (half > 0 && __shfl(greg[d], mid) < xin[h][d]) ? mid : cell_r[h][d];
-            }
-            size[d] -= half;
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d)
-            cell_r[h][d] += (__shfl(greg[d], cell_r[h][d]) < xin[h][d]) ? 1 : 0;
-      } else {
-        // Coordinates in earlier buckets are < x and those in later buckets are >= x (bucket_of is
-        // monotone and the table was built with it), so starting at the bucket's first coordinate
-        // and stepping while g[idx] < x — at most `scan` times — lands on the count of g < x.
-#pragma unroll
-        for (int h = 0; h < PPL; ++h)
-#pragma unroll
-          for (int d = 0; d < N; ++d) {
-            const int b = bucket_of<T>(xin[h][d], a.ax.g0[d], a.ax.lscale[d], kLaneBuckets);
-            const unsigned w = __shfl(ltab[d], b >> 2);
-            cell_r[h][d] = (int)((w >> ((b & 3) * 8)) & 0xFFu);
-          }
-        for (unsigned s = 0; s < scan; ++s) {  // uniform trip count
-#pragma unroll
-          for (int h = 0; h < PPL; ++h)
-#pragma unroll
-            for (int d = 0; d < N; ++d) {
-              const int n = a.ax.n[d];
-              const int idx = cell_r[h][d];
-              const T gi = __shfl(greg[d], idx < n ? idx : n - 1);
-              cell_r[h][d] = idx + ((idx < n && gi < xin[h][d]) ? 1 : 0);
-            }
-        }
-      }
-      // ... then the cell: clamp(partition_point - 1, 0, n-2) (rectilinear.rs:365-367)
-#pragma unroll
-      for (int h = 0; h < PPL; ++h)
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          const int n = a.ax.n[d];
-          int l = cell_r[h][d] - 1;
-          l = l > 0 ? l : 0;
-          l = l < n - 2 ? l : n - 2;
-          cell_r[h][d] = l;
-        }
-#pragma unroll
-      for (int h = 0; h < PPL; ++h)
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          x0_r[h][d] = __shfl(greg[d], cell_r[h][d]);
-          x1_r[h][d] = __shfl(greg[d], cell_r[h][d] + 1);
-        }
-    }
+    if constexpr (RECT && AXR != 0) lane_axes_locate<T, N, PPL, AXR>(a.ax, la, xin, cell_r, x0_r, x1_r);
     T resv[PPL];
 #pragma unroll
     for (int h = 0; h < PPL; ++h) {

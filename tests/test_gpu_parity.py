@@ -174,6 +174,43 @@ def test_rectilinear_axes_in_registers(oracle, monkeypatch, dtype, axis_regs, pp
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("axis_regs", ["0", "1", "2"])
+@pytest.mark.parametrize("method,axis", [("linear", [64, 61]), ("linear", [2, 64]), ("linear", [65, 64]), ("linear", [9, 8, 7, 6]),
+                                         ("linear", [2, 64, 3, 5]), ("linear", [4, 3, 5, 6, 7]), ("linear", [3, 4, 2, 5, 3, 4]),
+                                         ("nearest", [64]), ("nearest", [33, 64]), ("nearest", [64, 2, 17]),
+                                         ("nearest", [5, 6, 7, 8]), ("nearest", [3, 4, 5, 2, 6, 3]), ("nearest", [65, 9])],
+                         ids=str)
+def test_lane_resident_axes_everywhere(oracle, monkeypatch, dtype, axis_regs, method, axis):
+    """Round 2: the cross-lane axis search (lane_axes.h) also serves the 2-D brick kernel, the
+    4-D..6-D brick kernels (both brick layouts) and the nearest kernel whenever every axis has at
+    most 64 coordinates; modes 0 (LDS), 1 (probe sequence) and 2 (lane table) must agree bit for
+    bit, dead lanes of partial waves included (batch sizes that are not multiples of 64), and a
+    65-point axis must fall back to LDS."""
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_AXIS_REGS", axis_regs)
+    n = len(axis)
+    for nobs in (40_001, 63, 64, 65, 1):
+        case = synthetic_case(method, "rectilinear", n, axis, nobs, 4100 + sum(axis) + nobs, dtype, extrap=0.3,
+                              specials=min(axis) >= 8)
+        if nobs > 100:
+            case.obs[0][77] = np.nan
+            case.obs[n - 1][78] = np.inf
+            case.obs[0][79] = -np.inf
+        assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+    cv = lambda a: np.ascontiguousarray(a, dtype=dtype)
+    it = interpn_amd.Interpolator.rectilinear(method, [cv(g) for g in case.grids], cv(case.vals))
+    it.eval_host([cv(o) for o in case.obs], np.zeros(1, dtype=dtype))
+    name = it.kernel_name()
+    it.close()
+    in_lanes = max(axis) <= 64 and axis_regs != "0"
+    if name.startswith("interpn::k_nearest<") or name.startswith("interpn::k_linear2_brick<"):
+        assert name.endswith(f", {axis_regs if in_lanes else 0}>"), name
+    elif name.startswith("interpn::k_linear_brick<"):
+        assert f", {axis_regs if in_lanes else 0}, 0, " in name, name  # ..., PPL, AXR, ABL, CELL>
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("axis_regs", ["0", "1", "2"])
 def test_rectilinear_clustered_and_unsorted_axes(oracle, monkeypatch, dtype, axis_regs):
     """Lane-table corner cases: many coordinates inside one bucket (the scan length grows to the
     bucket population), coordinates a few ulps apart, and an unsorted axis (legal input: the
