@@ -75,6 +75,9 @@ def parse(argv=None):
     # gloo (RCCL refuses two ranks on one device).  The driver never passes these.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true")
+    # 1-GPU check of the RCCL calls themselves: initialise the process group (backend nccl = RCCL)
+    # even with one rank, so that broadcast / all_gather / all_reduce / barrier run on device tensors.
+    ap.add_argument("--force-dist", action="store_true")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0)
     # CPU test of the spawn / rendezvous path only (tests/test_bench_spawn.py): no GPU work, every
     # rank joins a gloo group and rank 0 prints who took part.  Not a benchmark.
@@ -428,7 +431,12 @@ def worker(args):
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -441,7 +449,7 @@ def worker(args):
     bpp = 8 * (NDIMS + 1)  # read 3 f64 coordinates + write 1 f64 result
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # Observation shard of this rank: i.i.d. uniform over the grid extent, device resident.
@@ -458,7 +466,7 @@ def worker(args):
         vals_dev = torch.empty(n**NDIMS, dtype=torch.float64, device=dev)
         if rank == 0:
             vals_dev.copy_(torch.from_numpy(spec["vals"]))
-        if world > 1:
+        if use_dist:
             if args.backend == "nccl":
                 dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
             else:
@@ -495,7 +503,7 @@ def worker(args):
         kernel_ms_local = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         t = torch.tensor([elapsed, kernel_ms_local], dtype=torch.float64, device=coll_dev)
         per_rank_ms = [kernel_ms_local]
-        if world > 1:
+        if use_dist:
             gathered = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
             dist.all_gather(gathered, torch.tensor([kernel_ms_local], dtype=torch.float64, device=coll_dev))
             per_rank_ms = [float(x[0]) for x in gathered]
@@ -648,7 +656,7 @@ def worker(args):
         print(json.dumps(rec), flush=True)
 
     it.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
