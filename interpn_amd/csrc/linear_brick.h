@@ -191,6 +191,10 @@ struct LeadReduce<T, 0, FMA> {
 //             read from obs and nothing is stored.
 //   ABL == 3  the unmodified data movement with the six IEEE divisions per point replaced by
 //             multiplications with a reciprocal (results differ in the last bits: timing only).
+//   ABL == 4  coordinates streamed by LDS-DMA (`global_load_lds_dwordx4`, non-temporal) into a
+//             per-wave LDS slab and read back with ds_read_b128, instead of VGPR-destination loads
+//             (PPL = 2, regular grids, full rows only — the harness launches whole rows).  Correct
+//             results; kept out of the library because it measured no gain.
 // Their outputs are meaningless by construction.
 template <typename T>
 __device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int n) {
@@ -239,6 +243,21 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
       for (int h = 0; h < PPL; ++h)
 #pragma unroll
         for (int d = 0; d < N; ++d) xin[h][d] = ablate_coord<T>(i0 + h, d, a.start[d], a.step[d], a.n[d]);
+    } else if constexpr (ABL == 4 && PPL == 2 && !RECT) {
+      // one 1-KiB LDS-DMA per dimension and wave: lane l's 16 bytes land at slab + 16*l
+      unsigned char* slab = lds_axes + (threadIdx.x >> 6) * (N * 1024u);
+#pragma unroll
+      for (int d = 0; d < N; ++d)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.obs[d] + i0),
+                                         (__attribute__((address_space(3))) void*)(slab + d * 1024u), 16, 0, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        const T2 v = *reinterpret_cast<const T2*>(slab + d * 1024u + (threadIdx.x & 63u) * 16u);
+        xin[0][d] = v.x;
+        xin[PPL - 1][d] = v.y;
+      }
+      wave_sync();
     } else if (PPL == 2) {
 #pragma unroll
       for (int d = 0; d < N; ++d) {

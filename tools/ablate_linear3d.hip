@@ -76,7 +76,7 @@ void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) 
 int ablate_launch(void* handle, int mode, const double* x, const double* y, const double* z, double* out, size_t npts,
                   void* stream) {
   const Ablate* h = static_cast<const Ablate*>(handle);
-  if (!h || !x || !y || !z || !out || npts == 0 || (npts & 1) || mode < 0 || mode > 3) return (int)hipErrorInvalidValue;
+  if (!h || !x || !y || !z || !out || npts == 0 || (npts & 1) || mode < 0 || mode > 4) return (int)hipErrorInvalidValue;
   for (const void* p : {(const void*)x, (const void*)y, (const void*)z, (const void*)out})
     if (reinterpret_cast<uintptr_t>(p) % 16) return (int)hipErrorInvalidValue;  // the two-points-per-lane form
   BrickArgs<double, 3> a;
@@ -99,7 +99,9 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
   if (mode == 0) return (int)go_steps<0>(*h, a, blocks, lds, s);
   if (mode == 1) return (int)go_steps<1>(*h, a, blocks, lds, s);
   if (mode == 2) return (int)go_steps<2>(*h, a, blocks, lds, s);
-  return (int)go_steps<3>(*h, a, blocks, lds, s);
+  if (mode == 3) return (int)go_steps<3>(*h, a, blocks, lds, s);
+  if (npts % 512) return (int)hipErrorInvalidValue;  // the LDS-DMA variant handles whole rows only
+  return (int)go_steps<4>(*h, a, blocks, lds + 4 * 3 * 1024, s);
 }
 
 void ablate_destroy(void* handle) {

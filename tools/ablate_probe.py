@@ -14,25 +14,33 @@ lib.ablate_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctype
 lib.ablate_launch.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
 lib.ablate_destroy.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
-PMAX = 100_000_000
+PMAX = 100_000_256 // 512 * 512
 gen = torch.Generator(device=dev); gen.manual_seed(3)
 obs = [torch.rand(PMAX, dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3)]
 out = torch.empty(PMAX, dtype=torch.float64, device=dev)
 stream = torch.cuda.current_stream(dev).cuda_stream
 
 
-def run(h, mode, P, reps):
-    ms = []
-    for k in range(reps + 2):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        rc = lib.ablate_launch(h, mode, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), P, stream)
-        b.record()
-        assert rc == 0, rc
-        torch.cuda.synchronize()
-        if k >= 2:
-            ms.append(a.elapsed_time(b))
-    return float(np.median(ms))
+MODES = ("full", "stream", "gather", "nodiv", "ldsdma")
+
+
+def run_interleaved(h, P, rounds=8, per_round=3):
+    """Interleaved rounds in ONE process (cdna_hip_programming.md rule 24): every round times each
+    variant `per_round` times back to back; the per-variant median over all rounds is reported, so
+    clock / thermal drift hits every variant alike."""
+    ms = {m: [] for m in MODES}
+    for r in range(rounds + 1):
+        for i, m in enumerate(MODES):
+            for k in range(per_round):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = lib.ablate_launch(h, i, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), P, stream)
+                b.record()
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                if r > 0:
+                    ms[m].append(a.elapsed_time(b))
+    return {m: float(np.median(v)) for m, v in ms.items()}
 
 
 for n in (32, 48, 64, 96, 128):
@@ -41,11 +49,17 @@ for n in (32, 48, 64, 96, 128):
     for si, sj in ((1, 1), (1, 2), (2, 2)):
         h = lib.ablate_create(vals.data_ptr(), n, si, sj, step)
         assert h
-        for P in (100_000_000,):
-            reps = 40 if P < 1e7 else 8
-            r = {m: run(h, i, P, reps) for i, m in enumerate(("full", "stream", "gather", "nodiv"))}
-            scale = 1e8 / P
-            print(json.dumps({"grid": n, "layout": [si, sj], "points": P,
-                              "ms_per_1e8": {k: round(v * scale, 3) for k, v in r.items()},
-                              "sum_minus_full": round((r["stream"] + r["gather"] - r["full"]) * scale, 3)}), flush=True)
+        P = PMAX
+        r = run_interleaved(h, P)
+        scale = 1e8 / P
+        print(json.dumps({"grid": n, "layout": [si, sj], "points": P,
+                          "ms_per_1e8": {k: round(v * scale, 3) for k, v in r.items()},
+                          "sum_minus_full": round((r["stream"] + r["gather"] - r["full"]) * scale, 3)}), flush=True)
+        # the LDS-DMA variant computes real results: they must equal the unmodified kernel's
+        lib.ablate_launch(h, 0, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), PMAX, stream)
+        torch.cuda.synchronize(); ref = out.clone(); out.zero_()
+        lib.ablate_launch(h, 4, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), PMAX, stream)
+        torch.cuda.synchronize()
+        print(json.dumps({"grid": n, "layout": [si, sj], "ldsdma_equals_full": bool(torch.equal(ref, out))}), flush=True)
+        del ref
         lib.ablate_destroy(h)
