@@ -63,6 +63,29 @@ int main(void) {
   st = interpn_hip_eval_host(h, (const void* const*)obs, obs_lens, 2, out2, P);
   CHECK(st == INTERPN_HIP_OK && memcmp(out, out2, sizeof out) == 0, "handle eval_host bit-identical to the one-shot call");
 
+  /* --- which kernel ran; a device-to-device clone; both handles sharing one batch ------------ */
+  {
+    char kname[160];
+    st = interpn_hip_kernel_name(h, kname, sizeof kname);
+    CHECK(st == INTERPN_HIP_OK && strncmp(kname, "interpn::k_", 11) == 0, "kernel_name reports the instantiation that ran");
+    printf("       (%s)\n", kname);
+    interpn_hip_interp* clone = NULL;
+    st = interpn_hip_replicate(h, interpn_hip_device(h), &clone); /* another GPU of the node in a multi-GPU process */
+    CHECK(st == INTERPN_HIP_OK && clone != NULL, "replicate (grid copied device to device)");
+    interpn_hip_interp* pair[2];
+    pair[0] = h;
+    pair[1] = clone;
+    uint64_t bad = 0;
+    for (int k = 0; k < P; ++k) out2[k] = 0.0;
+    st = interpn_hip_eval_host_sharded(pair, 2, (const void* const*)obs, obs_lens, 2, out2, P, &bad);
+    CHECK(st == INTERPN_HIP_OK && memcmp(out, out2, sizeof out) == 0, "eval_host_sharded over two handles bit-identical");
+    long long ppl = -1;
+    CHECK(interpn_hip_get_option(h, "ppl", &ppl) == INTERPN_HIP_OK && ppl == 0 &&
+              interpn_hip_set_option(h, "no_such_option", 1) == INTERPN_HIP_ERR_INVALID_ARGUMENT,
+          "per-handle options by name");
+    interpn_hip_destroy(clone);
+  }
+
   /* --- abort at the first unrepresentable coordinate: prefix written, rest untouched -------- */
   for (int k = 0; k < P; ++k) out2[k] = -7.0;
   const double keep = x[500];
