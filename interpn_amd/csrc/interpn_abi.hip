@@ -99,6 +99,7 @@ struct DevPool {
   struct Kit { hipStream_t stream; unsigned long long* flag_host; };
   std::vector<Kit> kits;
   std::vector<unsigned long long*> pinned_words;
+  std::vector<void*> small_buffers;  // pinned, device-mapped staging of the small-batch path (kSmallBytes each)
 };
 
 // Devices beyond the table are not pooled at all (plain hipMalloc / hipFree): two devices must never
@@ -236,6 +237,38 @@ void pool_return_pinned_word(int device, unsigned long long* word) {
   (void)hipHostFree(word);
 }
 
+// Staging of the small-batch host path: pinned host memory the kernel reads and writes directly
+// over PCIe (zero-copy).  One fixed size serves every interpolator: 8 coordinate arrays + 1 result
+// array of kSmallPoints f64 elements.
+constexpr size_t kSmallPoints = 8192;
+constexpr size_t kSmallBytes = (size_t)(8 + 1) * kSmallPoints * 8;
+
+hipError_t pool_take_small(int device, void** buf) {
+  DevPool& pool = dev_pool(device);
+  if (pooled_device(device)) {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (!pool.small_buffers.empty()) {
+      *buf = pool.small_buffers.back();
+      pool.small_buffers.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipHostMalloc(buf, kSmallBytes, hipHostMallocMapped);
+}
+
+void pool_return_small(int device, void* buf) {
+  if (!buf) return;
+  DevPool& pool = dev_pool(device);
+  if (pooled_device(device)) {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (pool.small_buffers.size() < 16 && pool_cap_bytes() > 0) {
+      pool.small_buffers.push_back(buf);
+      return;
+    }
+  }
+  (void)hipHostFree(buf);
+}
+
 int device_num_cus(int device) {
   static std::atomic<int> cached[kMaxPoolDevices];
   if (device >= 0 && device < kMaxPoolDevices && cached[device].load() > 0) return cached[device].load();
@@ -280,6 +313,10 @@ struct interpn_hip_interp {
     unsigned long long* flag_host = nullptr;   // pinned
     hipStream_t stream = nullptr;
   } lane[2];
+  // Small batches skip the staging copies altogether (eval_host_impl): pinned host buffer that
+  // the kernel reads the coordinates from and writes the results to, and its device address.
+  void* small_host = nullptr;
+  void* small_dev = nullptr;
 };
 
 namespace {
@@ -1073,6 +1110,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
     pool_free(h->device, l.obs);
     pool_free(h->device, l.out);
   }
+  pool_return_small(h->device, h->small_host);
   pool_free(h->device, h->first_bad);
   pool_return_pinned_word(h->device, h->finish_word);
   pool_free(h->device, h->grids_owned);
@@ -1195,6 +1233,60 @@ struct HostPipeline {
   }
 };
 
+// Small batches (<= kSmallPoints points; BASELINE configs[0] is 1e3): zero-copy.  The CPU copies
+// the coordinates into a pinned, device-mapped buffer, the kernel reads them and writes the results
+// over PCIe, and the call costs one launch, one 8-byte status copy and ONE stream synchronisation
+// instead of N + 2 staged copies and two synchronisations (1e3 points: 51 -> 2x us, see
+// profiles/r02_host_path.txt).  Abort semantics as everywhere: only out[0..first_bad) is copied
+// to the caller's array.
+constexpr int kSmallPathUnavailable = -1;
+
+static int eval_host_small(interpn_hip_interp* h, const void* const* obs, void* out, size_t nout, size_t* bad_index) {
+  interpn_hip_interp::HostLane& l = h->lane[0];
+  if (!h->small_host) {
+    void* buf = nullptr;
+    if (pool_take_small(h->device, &buf) != hipSuccess) { (void)hipGetLastError(); return kSmallPathUnavailable; }
+    void* dbuf = nullptr;
+    if (hipHostGetDevicePointer(&dbuf, buf, 0) != hipSuccess || !dbuf) {
+      (void)hipGetLastError();
+      pool_return_small(h->device, buf);
+      return kSmallPathUnavailable;
+    }
+    h->small_host = buf;
+    h->small_dev = dbuf;
+  }
+  if (!l.stream) HIP_TRY(pool_take_kit(h->device, &l.stream, &l.flag_host));
+  if (!l.flag_dev) {
+    HIP_TRY(pool_alloc(h->device, (void**)&l.flag_dev, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));
+  }
+  const size_t elem = h->desc.dtype == kF64 ? 8 : 4;
+  const int nd = h->desc.ndims;
+  const size_t stride = kSmallPoints * 8;  // bytes between the arrays: keeps every one 16-byte aligned
+  const void* dev_obs[8];
+  for (int d = 0; d < nd; ++d) {
+    memcpy((char*)h->small_host + (size_t)d * stride, obs[d], nout * elem);
+    dev_obs[d] = (const char*)h->small_dev + (size_t)d * stride;
+  }
+  char* host_out = (char*)h->small_host + (size_t)8 * stride;
+  void* dev_out = (char*)h->small_dev + (size_t)8 * stride;
+  HIP_TRY(launch_any(h->desc, dev_obs, dev_out, nout, l.flag_dev, l.stream));
+  HIP_TRY(hipMemcpyAsync(l.flag_host, l.flag_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream));
+  HIP_TRY(hipStreamSynchronize(l.stream));
+  const unsigned long long bad = *l.flag_host;
+  size_t good = nout;
+  if (bad != kNoBadIndexHost) {
+    HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));
+    good = (size_t)bad;
+  }
+  if (good) memcpy(out, host_out, good * elem);
+  if (bad != kNoBadIndexHost) {
+    if (bad_index) *bad_index = (size_t)bad;
+    return INTERPN_HIP_ERR_UNREPRESENTABLE;
+  }
+  return INTERPN_HIP_OK;
+}
+
 // Points per pipeline chunk: one chunk when the batch is small, else 2 Mi-point chunks.
 constexpr size_t kPipelineChunkPoints = (size_t)2 << 20;
 
@@ -1204,6 +1296,10 @@ static int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t 
   std::lock_guard<std::mutex> host_lock(h->host_mu);
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  if (nout <= kSmallPoints && h->desc.cfg.host_chunk < 1) {
+    const int sst = eval_host_small(h, obs, out, nout, bad_index);
+    if (sst != kSmallPathUnavailable) return sst;
+  }
   HostPipeline p;
   p.h = h;
   p.obs = obs;

@@ -372,6 +372,40 @@ def test_unrepresentable_aborts_at_first_bad_point(oracle, method, bad):
     assert np.all(got[k:] == -123.0)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("nobs,k", [(1, 0), (1000, 0), (1000, 999), (5000, 4321), (8192, 8191), (8193, 8192), (8193, 10)])
+def test_small_batch_zero_copy_path(oracle, dtype, nobs, k):
+    """Host batches of at most 8192 points take the zero-copy path (pinned staging the kernel reads
+    and writes over PCIe, one synchronisation; interpn_abi.hip::eval_host_small); 8193 points take
+    the staged pipeline.  Same bits, and the same abort contract at the first failing point —
+    prefix written, the rest of the caller's `out` untouched — on a resident handle used twice
+    (the sticky status word must be clean again) and through the one-shot entry point."""
+    import interpn_amd
+    from interpn_amd import raw
+
+    case = synthetic_case("linear", "regular", 3, [20, 21, 22], nobs, 600 + nobs + k, dtype, specials=False)
+    cv = lambda a: np.ascontiguousarray(a, dtype=dtype)
+    obs = [cv(o) for o in case.obs]
+    want = run_oracle(oracle, case, True)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, cv(case.starts), cv(case.steps), cv(case.vals))
+    assert np.array_equal(it.eval_host(obs, np.zeros(nobs, dtype=dtype)), want)
+    bad = [o.copy() for o in obs]
+    bad[1][k] = np.nan
+    if k + 3 < nobs:
+        bad[0][k + 3] = np.inf  # a later failure must not win
+    got = np.full(nobs, -5.0, dtype=dtype)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+        it.eval_host(bad, got)
+    assert np.array_equal(got[:k], want[:k]) and np.all(got[k:] == -5.0)
+    assert np.array_equal(it.eval_host(obs, np.zeros(nobs, dtype=dtype)), want)  # status word reset
+    it.close()
+    got = np.full(nobs, -5.0, dtype=dtype)
+    fn = raw.interpn_linear_regular_f64 if dtype == np.float64 else raw.interpn_linear_regular_f32
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+        fn(case.dims, cv(case.starts), cv(case.steps), cv(case.vals), bad, got)
+    assert np.array_equal(got[:k], want[:k]) and np.all(got[k:] == -5.0)
+
+
 @pytest.mark.parametrize("method", ["linear", "cubic"])
 def test_rectilinear_never_errors_and_propagates_nan(oracle, method):
     """multilinear/rectilinear.rs:353-370: NaN lands in cell 0 and the result is NaN; +-inf

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, the driver's bench commands, the 2-rank path on one GPU.
 # Usage: gpurun --timeout 2400 -- ./tools/gpu_session.sh [tag]
-TAG=${1:-r02d}
+TAG=${1:-r02g}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
