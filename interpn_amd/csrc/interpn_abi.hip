@@ -773,6 +773,15 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     g.grid[i] = gdev;
   }
   e = hipStreamSynchronize(nullptr);
+  // The largest bucket population of each lane table decides which form of the cross-lane search
+  // the kernels run (lane_axes.h): 4 bytes per axis, once per handle.
+  for (size_t i = 0; i < ngrids && e == hipSuccess; ++i) {
+    if (!g.axis_ltab_off[i]) continue;
+    unsigned pop = 0;
+    e = hipMemcpy(&pop, (const char*)h->grids_owned + g.axis_ltab_off[i] + 64 * sizeof(unsigned), sizeof(unsigned),
+                  hipMemcpyDeviceToHost);
+    g.axis_lscan[i] = (int)pop;
+  }
   if (e != hipSuccess) {
     interpn_hip_destroy(h);
     return hip_fail(e);

@@ -76,6 +76,7 @@ struct GridDesc {
   // followed by one word holding the largest bucket population.  0 = none.
   unsigned axis_ltab_off[8] = {0};
   double axis_lscale[8] = {0};
+  int axis_lscan[8] = {0};  // largest bucket population of the lane table (read back when it is built)
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell
@@ -96,8 +97,11 @@ struct GridDesc {
 // 256-lane rows) instead of a persistent grid-stride loop: the dispatcher then balances the XCDs
 // dynamically (measured on 1e8 points, 64^3: 1.36 -> 1.29 ms).  Rectilinear kernels stage their
 // axes per workgroup and want a few rows each to amortise that.
-inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane, bool per_block_setup) {
-  unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (per_block_setup ? 8u : 1u);
+// `setup`: 0 = none (regular grids), 1 = per-wave register loads of lane-resident axes (6 small
+// loads per wave: 4 rows amortise them, cfg3 1.39 -> 1.30..1.36 ms, 4-D rectilinear 2.26 -> 2.14),
+// 2 = per-workgroup LDS staging of the axis image (8 rows).
+inline unsigned brick_iters(const GridDesc& g, size_t npts, int points_per_lane, int setup) {
+  unsigned iters = g.cfg.iters_per_block > 0 ? (unsigned)g.cfg.iters_per_block : (setup == 2 ? 8u : (setup == 1 ? 4u : 1u));
   // keep the grid below 2^23 workgroups (the dispatch packet counts work-items in 32 bits)
   const size_t rows = (npts + (size_t)256 * points_per_lane - 1) / ((size_t)256 * points_per_lane);
   while ((rows + iters - 1) / iters > (1u << 23)) iters *= 2;

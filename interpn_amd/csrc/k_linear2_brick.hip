@@ -189,10 +189,11 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax, /*big_lds=*/true);
   const int axr = lane_axes_mode(g);  // both axes <= 64 coordinates: searched across lanes, no LDS image
   if (axr) lds = 0;
-  const unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
+  const unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, axr ? 4 : 1) : grid_blocks(npts, 1, g.cfg);
 #define GO(RECT, FMA, AXR) do { g.tag.set("k_linear2_brick", {RECT, FMA, AXR}, 0b011u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
   else if (axr == 2) { if (g.fma) GO(true, true, 2); else GO(true, false, 2); }
+  else if (axr == 3) { if (g.fma) GO(true, true, 3); else GO(true, false, 3); }
   else if (axr == 1) { if (g.fma) GO(true, true, 1); else GO(true, false, 1); }
   else { if (g.fma) GO(true, true, 0); else GO(true, false, 0); }
 #undef GO

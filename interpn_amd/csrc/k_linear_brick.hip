@@ -98,7 +98,7 @@ static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size
 template <typename T, int N, int PPL>
 static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t axis_lds, size_t npts, hipStream_t stream) {
   const int axr = lane_axes_mode(g);  // axes in lanes (lane_axes.h) or 0 = LDS / L2 search
-  a.iters = brick_iters(g, npts, PPL, /*per_block_setup=*/g.kind == kRectilinear && axr == 0);
+  a.iters = brick_iters(g, npts, PPL, /*setup=*/g.kind != kRectilinear ? 0 : (axr == 0 ? 2 : 1));
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;
   const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);
@@ -108,6 +108,9 @@ static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds,
   if (axr == 2)
     return g.fma ? launch_steps<T, N, true, true, PPL, 2>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, true, false, PPL, 2>(g, a, lds, blocks, stream);
+  if (axr == 3)
+    return g.fma ? launch_steps<T, N, true, true, PPL, 3>(g, a, lds, blocks, stream)
+                 : launch_steps<T, N, true, false, PPL, 3>(g, a, lds, blocks, stream);
   if (axr == 1)
     return g.fma ? launch_steps<T, N, true, true, PPL, 1>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, true, false, PPL, 1>(g, a, lds, blocks, stream);

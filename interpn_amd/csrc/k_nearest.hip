@@ -113,10 +113,12 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);
   const int axr = lane_axes_mode(g);  // rectilinear axes of <= 64 coordinates: searched across lanes, no LDS image
   if (axr) lds = 0;
-  const unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, 1) : grid_blocks(npts, 1, g.cfg);
+  // lane-resident axes cost six small loads per wave: four rows per wave amortise them
+  const unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, axr ? 4 : 1) : grid_blocks(npts, 1, g.cfg);
 #define GO(RECT, FMA, AXR) do { g.tag.set("k_nearest", {N, RECT, FMA, AXR}, 0b0110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA, AXR>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
   else if (axr == 2) GO(true, true, 2);  // no FMA site in the rectilinear path
+  else if (axr == 3) GO(true, true, 3);
   else if (axr == 1) GO(true, true, 1);
   else GO(true, true, 0);
 #undef GO

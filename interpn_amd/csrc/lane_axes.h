@@ -7,9 +7,15 @@
 //           src/multilinear/rectilinear.rs:363), six lockstep steps — valid for ANY axis the
 //           reference accepts (its `new` only checks g[1] > g[0]);
 //   MODE 2  a 255-bucket lane table (sorted finite axes; built at handle creation): the byte
-//           count of coordinates in front of each bucket, four per lane, brackets the answer, so a
-//           search is 1 table probe + `scan` coordinate probes (scan = the largest bucket
-//           population, 1 for evenly spread axes) instead of 7.
+//           count of coordinates in front of each bucket, four per lane, brackets the answer.
+//           No bucket holds more than one coordinate (evenly spread axes; the host reads the
+//           largest bucket population back when the table is built): one coordinate read decides
+//           the cell and is itself one of the two brackets, so a search is 3 cross-lane reads
+//           (table, probe, other bracket) instead of the probe sequence's 9.
+//   MODE 3  the same table for clustered axes: `scan` (> 1) coordinate probes walk the bucket,
+//           then the two brackets are read.
+// (Two modes rather than one kernel with both paths: together they cost 110 VGPRs and two waves
+// of occupancy per SIMD, cfg3 1.38 -> 1.43 ms.)
 //
 // Every function here must run with the WHOLE wave active (inactive lanes cannot be read): the
 // callers keep dead lanes alive with a harmless coordinate and mask only the store.
@@ -36,7 +42,7 @@ __device__ __forceinline__ LaneAxes<T, N> load_lane_axes(const AxisArgs<T, N>& a
     const T* g = reinterpret_cast<const T*>(ax.image + ax.g_off[d]);
     la.g[d] = g[wl < ax.n[d] ? wl : ax.n[d] - 1];
     la.tab[d] = 0;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
       const unsigned* words = reinterpret_cast<const unsigned*>(ax.image + ax.ltab_off[d]);
       la.tab[d] = words[wl];
       const unsigned pop = words[64];  // uniform
@@ -90,6 +96,46 @@ __device__ __forceinline__ void lane_axes_locate(const AxisArgs<T, N>& ax, const
         const unsigned w = __shfl(la.tab[d], b >> 2);
         cell[h][d] = (int)((w >> ((b & 3) * 8)) & 0xFFu);
       }
+    if constexpr (MODE == 2) {
+      // One coordinate probe decides the cell, and that coordinate is always one of the two
+      // bracketing ones: with c = min(idx, n-1) the probed index and l the clamped cell, c is l
+      // (probed = x0) or l+1 (probed = x1) in every case — idx = 0, 1..n-1, n, either outcome of
+      // the compare — so only the OTHER bracket is fetched: 1 + 2 + 2 cross-lane reads per search
+      // in f64 instead of 1 + 2 + 4.
+      // (three lockstep levels, each issuing its PPL*N independent reads before any is consumed)
+      int cidx[PPL][N];
+      T gi[PPL][N];
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const int n = ax.n[d];
+          cidx[h][d] = cell[h][d] < n ? cell[h][d] : n - 1;
+          gi[h][d] = __shfl(la.g[d], cidx[h][d]);
+        }
+      T other[PPL][N];
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const int n = ax.n[d];
+          const int idx = cell[h][d];
+          int l = idx + ((idx < n && gi[h][d] < xin[h][d]) ? 1 : 0) - 1;  // partition_point - 1
+          l = l > 0 ? l : 0;
+          l = l < n - 2 ? l : n - 2;
+          cell[h][d] = l;
+          other[h][d] = __shfl(la.g[d], cidx[h][d] == l ? l + 1 : l);
+        }
+#pragma unroll
+      for (int h = 0; h < PPL; ++h)
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          const bool probed_is_x0 = cidx[h][d] == cell[h][d];
+          x0[h][d] = probed_is_x0 ? gi[h][d] : other[h][d];
+          x1[h][d] = probed_is_x0 ? other[h][d] : gi[h][d];
+        }
+      return;
+    }
     for (unsigned s = 0; s < la.scan; ++s) {  // uniform trip count
 #pragma unroll
       for (int h = 0; h < PPL; ++h)
@@ -124,15 +170,18 @@ __device__ __forceinline__ void lane_axes_locate(const AxisArgs<T, N>& ax, const
 
 // Host side: which mode a rectilinear grid gets (0 = the axes do not fit one coordinate per lane).
 // The handle's `axis_regs` option (latched from INTERPN_HIP_AXIS_REGS at creation) overrides:
-// 0 | 1 | 2, where 2 falls back to 1 when a lane table is missing (axis not proven sorted).
+// 0 | 1 | 2, where 2 (= use the lane tables) resolves to mode 2 or 3 by the largest bucket
+// population and falls back to 1 when a table is missing (axis not proven sorted).
 inline int lane_axes_mode(const GridDesc& g) {
   if (g.kind != kRectilinear) return 0;
   bool tables = true;
+  int scan = 0;
   for (int d = 0; d < g.ndims; ++d) {
     if (g.n[d] > 64) return 0;
     tables = tables && g.axis_ltab_off[d] != 0;
+    scan = g.axis_lscan[d] > scan ? g.axis_lscan[d] : scan;
   }
-  int mode = tables ? 2 : 1;
+  int mode = tables ? (scan <= 1 ? 2 : 3) : 1;
   if (g.cfg.axis_regs == 0) mode = 0;
   else if (g.cfg.axis_regs == 1) mode = 1;
   return mode;
