@@ -203,10 +203,12 @@ def test_lane_resident_axes_everywhere(oracle, monkeypatch, dtype, axis_regs, me
     name = it.kernel_name()
     it.close()
     in_lanes = max(axis) <= 64 and axis_regs != "0"
+    want = {"0": (0,), "1": (1,), "2": (2, 3)}[axis_regs] if in_lanes else (0,)  # "2" = lane tables: mode 2 or 3
+    args = [x.strip() for x in name[name.index("<") + 1:-1].split(",")]
     if name.startswith("interpn::k_nearest<") or name.startswith("interpn::k_linear2_brick<"):
-        assert name.endswith(f", {axis_regs if in_lanes else 0}>"), name
+        assert int(args[-2]) in want, name  # ..., AXR, PPL>
     elif name.startswith("interpn::k_linear_brick<"):
-        assert f", {axis_regs if in_lanes else 0}, 0, " in name, name  # ..., PPL, AXR, ABL, CELL>
+        assert int(args[-3]) in want, name  # ..., PPL, AXR, ABL, CELL>
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
@@ -619,6 +621,43 @@ def test_device_eval_alignment_and_tails(oracle, npts):
         assert np.array_equal(out.cpu().numpy(), want)
         # nothing outside the requested range was written
         assert float(out_full[shift + npts]) == -5.0 and (shift == 0 or float(out_full[0]) == -5.0)
+
+
+@pytest.mark.parametrize("method,axis", [("linear", [40, 50]), ("nearest", [30, 20, 10]), ("nearest", [500])])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("npts", [1, 2, 3, 127, 128, 129, 100_001])
+def test_two_points_per_lane_2d_and_nearest(oracle, method, kind, axis, npts):
+    """Round 2: the 2-D brick kernel and the nearest kernel move two points per lane as 16-byte
+    vectors when every stream is 16-byte aligned, and fall back to the scalar form otherwise: both
+    forms (tensor views at element offset 0 and 1), odd batch sizes and single points give the
+    oracle's bits; `ppl` = 1 forces the scalar form."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = synthetic_case(method, kind, len(axis), axis, npts, 71 + npts + len(axis), np.float64, extrap=0.2, specials=False)
+    want = run_oracle(oracle, case, True)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals)
+    for off, forced in ((0, 0), (1, 0), (0, 1)):
+        it.set_option("ppl", forced)
+        bufs = [torch.zeros(npts + 2, dtype=torch.float64, device=dev) for _ in range(len(axis) + 1)]
+        obs = []
+        for b, o in zip(bufs, case.obs):
+            b[off:off + npts] = torch.from_numpy(o).to(dev)
+            obs.append(b[off:off + npts])
+        out = bufs[-1][off:off + npts]
+        it.eval_tensors(obs, out)
+        it.finish()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want) or np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+        name = it.kernel_name()
+        if name.startswith(("interpn::k_nearest<", "interpn::k_linear2_brick<")):
+            assert name.endswith(", 2>" if (off == 0 and not forced) else ", 1>"), (name, off, forced)
+    it.close()
 
 
 def test_eval_device_is_graph_capturable(oracle):
