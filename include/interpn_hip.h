@@ -247,11 +247,6 @@ int interpn_hip_kernel_name(const interpn_hip_interp* h, char* buf, size_t bufle
  * *step_i / *step_j (optional) receive the layout's brick / tile steps. */
 size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* step_j);
 
-/* Split of a multilinear brick layout (N = 3..6): a dimension stepped 2 keeps step 1 for its
- * first *split_i / *split_j cells (their planes / rows are duplicated, so those cells span fewer
- * lines), which sizes the table to what an XCD's L2 holds.  0 = plain layout or no split. */
-void interpn_hip_table_split(const interpn_hip_interp* h, int* split_i, int* split_j);
-
 /* Waits only for work enqueued through THIS handle (an event behind its last launch on every
  * caller stream, plus its own staging streams) before its device memory is recycled; other
  * streams of the device keep running.  Launches captured into a graph cannot be tracked: the

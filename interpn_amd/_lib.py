@@ -122,8 +122,6 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_kernel_name.argtypes = [c_void_p, ctypes.c_char_p, c_size_t]
     lib.interpn_hip_table_bytes.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.interpn_hip_table_bytes.restype = c_size_t
-    lib.interpn_hip_table_split.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
-    lib.interpn_hip_table_split.restype = None
     lib.interpn_hip_destroy.argtypes = [c_void_p]
     lib.interpn_hip_destroy.restype = None
     _lib = lib

@@ -489,7 +489,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (!(g.method == kLinear && g.ndims >= 3 && g.ndims <= 6)) return INTERPN_HIP_OK;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
-  int si = 0, sj = 0, isplit = 0, jsplit = 0;
+  int si = 0, sj = 0;
   bool cell = false;
   const size_t MiB = (size_t)1 << 20;
   const size_t esz = g.dtype == kF64 ? 8 : 4;
@@ -501,20 +501,9 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (g.ndims >= 4) brick_cell_geometry(g, nbc, &bcell);
   if (env && !strcmp(env, "c4") && g.ndims >= 4) {
     cell = true;  // forced 4-D cell bricks (tests / tuning); INTERPN_HIP_BRICKS=c4 is ignored for N = 3
-  } else if (env && strlen(env) >= 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2') &&
-             (env[2] == 0 || env[2] == ':')) {
-    // "SiSj" or "SiSj:split" / "22:isplit,jsplit" (split layouts: the first `split` cells of a
-    // dimension stepped 2 keep step 1; "12:s" splits j, "22:s" splits i)
+  } else if (env && strlen(env) == 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2')) {
     si = env[0] - '0';
     sj = env[1] - '0';
-    if (env[2] == ':') {
-      char* end = nullptr;
-      const long a = strtol(env + 3, &end, 10);
-      long b = 0;
-      if (end && *end == ',') b = strtol(end + 1, nullptr, 10);
-      if (si == 2) { isplit = (int)a; jsplit = (int)b; }
-      else if (sj == 2) jsplit = (int)a;
-    }
   } else {
     if (grid_is_l1_resident(g)) return INTERPN_HIP_OK;
     // Measured on MI355X (tools/sweep_layouts.py, 3-D f64, 24^3 .. 384^3, non-temporal streams):
@@ -549,10 +538,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     for (int k = 0; k < 4; ++k) g.brick_nb[k] = nbc[k];
     si = sj = 1;
   } else {
-    const int ni = g.n[g.ndims - 3], nj = g.n[g.ndims - 2];
-    isplit = si == 2 ? (isplit < 0 ? 0 : (isplit > ni - 1 ? ni - 1 : isplit)) : 0;
-    jsplit = sj == 2 ? (jsplit < 0 ? 0 : (jsplit > nj - 1 ? nj - 1 : jsplit)) : 0;
-    brick_geometry(g, si, sj, g.brick_nb, &bytes, isplit, jsplit);
+    brick_geometry(g, si, sj, g.brick_nb, &bytes);
     g.brick_nb[3] = 0;
   }
   // brick element offsets are 32-bit in the kernel
@@ -560,8 +546,6 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (bytes > free_b / 2) return INTERPN_HIP_OK;
   g.brick_step[0] = si;
   g.brick_step[1] = sj;
-  g.brick_split[0] = cell ? 0 : isplit;
-  g.brick_split[1] = cell ? 0 : jsplit;
   g.brick_cell = cell ? 1 : 0;
   hipError_t e = pool_alloc(h->device, &h->bricks_owned, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; g.brick_cell = 0; return INTERPN_HIP_OK; }
@@ -1106,15 +1090,8 @@ size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* st
   if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
   else if (g.brick_cell) brick_cell_geometry(g, nb4, &bytes);
-  else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes, g.brick_split[0], g.brick_split[1]);
+  else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   return bytes;
-}
-
-// Split of a stepped-2 brick layout (multilinear N = 3..6): cells in front of the split keep step 1.
-void interpn_hip_table_split(const interpn_hip_interp* h, int* split_i, int* split_j) {
-  const bool bricks3 = h && h->desc.bricks && h->desc.method == kLinear && h->desc.ndims >= 3 && !h->desc.brick_cell;
-  if (split_i) *split_i = bricks3 ? h->desc.brick_split[0] : 0;
-  if (split_j) *split_j = bricks3 ? h->desc.brick_split[1] : 0;
 }
 
 void interpn_hip_destroy(interpn_hip_interp* h) {

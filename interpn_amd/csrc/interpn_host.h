@@ -83,10 +83,6 @@ struct GridDesc {
   // per line); brick_nb[3] then counts the bricks along dimension N-4.
   const void* bricks = nullptr;
   int brick_step[2] = {2, 2};
-  // Split layouts: a dimension stepped 2 keeps step 1 for its first brick_split[] cells (planes /
-  // rows duplicated there, the pair never leaves a brick), so the table can be sized to what the
-  // 4 MiB L2 of an XCD holds; 0 = plain step 2.
-  int brick_split[2] = {0, 0};
   unsigned brick_nb[4] = {0, 0, 0, 0};
   int brick_cell = 0;
   // check_bounds limits per dimension, in the element type's arithmetic
@@ -140,7 +136,7 @@ hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t
                           unsigned long long* first_bad, hipStream_t stream);
 
 // Bricked multilinear path (k_linear_brick.hip).
-void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes, int isplit = 0, int jsplit = 0);
+void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes);
 void brick_cell_geometry(const GridDesc& g, unsigned nb[4], size_t* bytes);
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>

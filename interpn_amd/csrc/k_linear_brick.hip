@@ -10,23 +10,17 @@ namespace interpn {
 //   step 1:      brick = cell index                      -> n-1 bricks
 //   step 2:      brick = i>>1, +1 when i is odd (i+1 spills into the next brick) -> (n-1)/2 + 1
 //   step KW-1 (k): the pair never leaves its brick row   -> (n-2)/(KW-1) + 1
-//   step 2 with the first `split` cells at step 1 (linear_brick.h::split_step): `split` bricks,
-//   then a stepped-2 axis of the remaining n - split points
-static unsigned bricks_along(int n, int step, int split = 0) {
+static unsigned bricks_along(int n, int step) {
   if (step == 1) return (unsigned)(n - 1);
-  if (step == 2) {
-    if (split >= n - 1) return (unsigned)(n - 1);
-    if (split < 0) split = 0;
-    return (unsigned)(split + (n - split - 1) / 2 + 1);
-  }
+  if (step == 2) return (unsigned)((n - 1) / 2 + 1);
   return (unsigned)((n - 2) / step + 1);
 }
 
-void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes, int isplit, int jsplit) {
+void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes) {
   const int N = g.ndims;
   const int kw = g.dtype == kF64 ? 4 : 8;
-  nb[0] = bricks_along(g.n[N - 3], si, isplit);
-  nb[1] = bricks_along(g.n[N - 2], sj, jsplit);
+  nb[0] = bricks_along(g.n[N - 3], si);
+  nb[1] = bricks_along(g.n[N - 2], sj);
   nb[2] = bricks_along(g.n[N - 1], kw - 1);
   size_t lead = 1;
   for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
@@ -76,13 +70,11 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
   if (g.dtype == kF64)
     hipLaunchKernelGGL(k_build_bricks<double>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
                        static_cast<const double*>(g.vals), static_cast<double*>(bricks), lead, g.n[N - 3], g.n[N - 2],
-                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2],
-                       g.brick_split[0], g.brick_split[1]);
+                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
   else
     hipLaunchKernelGGL(k_build_bricks<float>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
                        static_cast<const float*>(g.vals), static_cast<float*>(bricks), lead, g.n[N - 3], g.n[N - 2],
-                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2],
-                       g.brick_split[0], g.brick_split[1]);
+                       g.n[N - 1], g.brick_step[0], g.brick_step[1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
   return hipGetLastError();
 }
 
@@ -143,8 +135,6 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   }
   a.nbj = g.brick_nb[1];
   a.nbk = g.brick_nb[2];
-  a.isplit = g.brick_split[0];
-  a.jsplit = g.brick_split[1];
   // Table offset per unit of each leading index.  3-D bricks: every leading dimension indexes
   // whole tables of the last three.  4-D cell bricks: dimension N-4 (h) indexes bricks (one brick
   // row per h cell), the dimensions in front of it whole 4-D tables.

@@ -49,31 +49,16 @@ struct BrickArgs {
   unsigned lead_stride[N > 3 ? N - 3 : 1];  // elements of the brick table per unit of a leading index
   unsigned nbj, nbk;
   unsigned iters;  // kBlock-wide iterations per workgroup
-  // Split layouts (steps of 2 only): the first isplit (jsplit) cells of dimension i (j) keep step 1
-  // -- their planes / rows are duplicated, the pair never leaves a brick -- and the rest step 2.
-  // 0 = the plain stepped-2 layout; n-1 = the same table as step 1.
-  int isplit, jsplit;
 };
 
-// Brick index and in-brick offset of grid index c + dc (dc = 0, 1) along a dimension stepped 2
-// whose first `split` cells keep step 1.
-__device__ __forceinline__ void split_step(int c, int dc, int split, int& b, int& o) {
-  const int cc = c - split;
-  if (cc < 0) { b = c; o = dc; return; }
-  b = split + (cc >> 1);
-  o = (cc & 1) + dc;
-  if (o == 2) { b += 1; o = 0; }
-}
-
 template <typename T, int SI, int SJ, int CELL = 0>
-__device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj,
-                                                int isplit, int jsplit) {
+__device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj) {
   constexpr int KW = BrickGeom<T, CELL>::KW;
   int bi, oi, bj, oj;
   if (SI == 1) { bi = i; oi = di; }
-  else split_step(i, di, isplit, bi, oi);
+  else { bi = i >> 1; oi = (i & 1) + di; if (oi == 2) { bi += 1; oi = 0; } }
   if (SJ == 1) { bj = j; oj = dj; }
-  else split_step(j, dj, jsplit, bj, oj);
+  else { bj = j >> 1; oj = (j & 1) + dj; if (oj == 2) { bj += 1; oj = 0; } }
   return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T, CELL>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
 }
 
@@ -340,8 +325,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
       if constexpr (ABL != 1) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1,
-                                                                                 a.isplit, a.jsplit);
+          lds_off[(quad * 4 + p) * 4 + q] = lead + brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[N - 3], loc[N - 2], kpart, p >> 1, p & 1);
         wave_sync();
       }
       Cell<T> c;
@@ -389,7 +373,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ vals, T* __restrict__ bricks, size_t nlead,
                                                          int n0, int n1, int n2, int si, int sj, unsigned nbi, unsigned nbj,
-                                                         unsigned nbk, int isplit, int jsplit) {
+                                                         unsigned nbk) {
   constexpr int KW = BrickGeom<T>::KW;
   constexpr int EL = BrickGeom<T>::ELEMS;
   const size_t per_lead = (size_t)nbi * nbj * nbk * EL;
@@ -402,11 +386,8 @@ __global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ v
     const unsigned bk = (unsigned)(b % nbk); b /= nbk;
     const unsigned bj = (unsigned)(b % nbj); b /= nbj;
     const unsigned bi = (unsigned)b;
-    // first plane / row of the brick: step 1 in front of the split, step 2 behind it
-    const int i0 = (si == 1 || (int)bi < isplit) ? (int)bi : isplit + ((int)bi - isplit) * 2;
-    const int j0 = (sj == 1 || (int)bj < jsplit) ? (int)bj : jsplit + ((int)bj - jsplit) * 2;
-    const int i = i0 + (int)(within / (2 * KW));
-    const int j = j0 + (int)((within / KW) & 1);
+    const int i = (int)bi * si + (int)(within / (2 * KW));
+    const int j = (int)bj * sj + (int)((within / KW) & 1);
     const int k = (int)bk * (KW - 1) + (int)(within % KW);
     T v = (T)0;
     if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];

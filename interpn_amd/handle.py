@@ -116,12 +116,6 @@ class Interpolator:
         nbytes = _lib.load().interpn_hip_table_bytes(self._h, ctypes.byref(si), ctypes.byref(sj))
         return int(nbytes), int(si.value), int(sj.value)
 
-    def table_split(self):
-        """(split_i, split_j) of a multilinear brick layout: cells in front of the split keep step 1."""
-        a, b = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.load().interpn_hip_table_split(self._h, ctypes.byref(a), ctypes.byref(b))
-        return int(a.value), int(b.value)
-
     def _check_same_device(self, what: str, tensor) -> None:
         """Kernels run under the handle's device with the grid resident there: a tensor on another
         GPU would be read across devices on a stream of the wrong device."""

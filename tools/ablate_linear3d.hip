@@ -5,7 +5,6 @@
 // product path and its ABL != 0 outputs are meaningless by construction.
 //
 //   void* ablate_create(const double* vals_dev, int n, int si, int sj, double step)
-//   void* ablate_create_split(vals_dev, n, si, sj, step, isplit, jsplit)   (split layouts, linear_brick.h)
 //   int   ablate_launch(void* h, int mode, x, y, z, out, npts, hipStream_t)   -> hipError_t
 //   void  ablate_destroy(void* h)
 #include <hip/hip_runtime.h>
@@ -21,14 +20,14 @@ namespace {
 struct Ablate {
   double* bricks = nullptr;
   unsigned long long* first_bad = nullptr;
-  int n = 0, si = 0, sj = 0, isplit = 0, jsplit = 0;
+  int n = 0, si = 0, sj = 0;
   unsigned nb[3] = {0, 0, 0};
   double step = 0;
 };
 
-unsigned along(int n, int step, int split = 0) {  // k_linear_brick.hip::bricks_along
+unsigned along(int n, int step) {  // k_linear_brick.hip::bricks_along
   if (step == 1) return (unsigned)(n - 1);
-  if (step == 2) return split >= n - 1 ? (unsigned)(n - 1) : (unsigned)(split + (n - split - 1) / 2 + 1);
+  if (step == 2) return (unsigned)((n - 1) / 2 + 1);
   return (unsigned)((n - 2) / step + 1);
 }
 
@@ -49,14 +48,12 @@ hipError_t go_steps(const Ablate& h, const BrickArgs<double, 3>& a, unsigned blo
 
 extern "C" {
 
-void* ablate_create_split(const double* vals_dev, int n, int si, int sj, double step, int isplit, int jsplit) {
+void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) {
   if (!vals_dev || n < 2 || !((si == 1 || si == 2) && (sj == 1 || sj == 2)) || (si == 2 && sj == 1)) return nullptr;
-  if (isplit < 0 || jsplit < 0) return nullptr;
   Ablate* h = new (std::nothrow) Ablate();
   if (!h) return nullptr;
   h->n = n; h->si = si; h->sj = sj; h->step = step;
-  h->isplit = si == 2 ? isplit : 0; h->jsplit = sj == 2 ? jsplit : 0;
-  h->nb[0] = along(n, si, h->isplit); h->nb[1] = along(n, sj, h->jsplit); h->nb[2] = along(n, 3);
+  h->nb[0] = along(n, si); h->nb[1] = along(n, sj); h->nb[2] = along(n, 3);
   const size_t elems = (size_t)h->nb[0] * h->nb[1] * h->nb[2] * 16;
   if (elems >= 0xFFFFFFFFull || hipMalloc((void**)&h->bricks, elems * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&h->first_bad, 8) != hipSuccess || hipMemset(h->first_bad, 0xFF, 8) != hipSuccess) {
@@ -67,17 +64,13 @@ void* ablate_create_split(const double* vals_dev, int n, int si, int sj, double 
   size_t blocks = (elems + kBlock - 1) / kBlock;
   if (blocks > 65535) blocks = 65535;
   hipLaunchKernelGGL(k_build_bricks<double>, dim3((unsigned)blocks), dim3(kBlock), 0, nullptr, vals_dev, h->bricks, (size_t)1,
-                     n, n, n, si, sj, h->nb[0], h->nb[1], h->nb[2], h->isplit, h->jsplit);
+                     n, n, n, si, sj, h->nb[0], h->nb[1], h->nb[2]);
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     (void)hipFree(h->bricks); (void)hipFree(h->first_bad);
     delete h;
     return nullptr;
   }
   return h;
-}
-
-void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) {
-  return ablate_create_split(vals_dev, n, si, sj, step, 0, 0);
 }
 
 int ablate_launch(void* handle, int mode, const double* x, const double* y, const double* z, double* out, size_t npts,
@@ -95,8 +88,6 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
   for (int d = 0; d < 3; ++d) { a.start[d] = -1.0; a.step[d] = h->step; a.n[d] = h->n; }
   a.nbj = h->nb[1];
   a.nbk = h->nb[2];
-  a.isplit = h->isplit;
-  a.jsplit = h->jsplit;
   a.lead_stride[0] = 0;
   a.ax.use_lds = 0; a.ax.image = nullptr; a.ax.image_bytes = 0;
   a.iters = 1;  // the library's launch shape for regular grids: one 256-lane row per workgroup
