@@ -46,7 +46,11 @@ hipError_t go_steps(const Ablate& h, const BrickArgs<double, 3>& a, unsigned blo
 
 }  // namespace
 
+static size_t g_extra_lds = 0;  // occupancy probe: extra dynamic LDS per workgroup (bytes)
+
 extern "C" {
+
+void ablate_set_extra_lds(size_t bytes) { g_extra_lds = bytes; }
 
 void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) {
   if (!vals_dev || n < 2 || !((si == 1 || si == 2) && (sj == 1 || sj == 2)) || (si == 2 && sj == 1)) return nullptr;
@@ -92,7 +96,7 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
   a.ax.use_lds = 0; a.ax.image = nullptr; a.ax.image_bytes = 0;
   a.iters = 1;  // the library's launch shape for regular grids: one 256-lane row per workgroup
   typedef LeafVec<double, 2>::type P;
-  const size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16;
+  const size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16 + g_extra_lds;
   const size_t nslots = (npts + 1) / 2;
   const unsigned blocks = (unsigned)((nslots + kBlock - 1) / kBlock);
   hipStream_t s = static_cast<hipStream_t>(stream);
