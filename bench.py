@@ -232,6 +232,13 @@ def config_row(torch, interpn_amd, name, spec, obs, out, device, seconds, check_
            "Mpoints_per_s": round(P / kernel_ms / 1e3, 1), "algorithmic_bytes_per_point": bpp,
            "achieved_GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
            "oracle_check": {"points": check_points, "bitwise_equal": same}}
+    if it.get_option("last_binned"):
+        # 4-D multicubic: the batch is counting-sorted by table position first (3 more launches on
+        # the same stream); kernel_ms is the whole evaluation.  The same handle with the points
+        # evaluated in place, for comparison:
+        it.set_option("binned", 0)
+        ms0 = time_launches(torch, it, obs, out, seconds=seconds / 2)
+        row["binned"] = {"launches_per_evaluation": 4, "unsorted_kernel_ms": round(float(np.mean(ms0)), 4)}
     it.close()
     return row
 

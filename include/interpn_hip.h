@@ -216,7 +216,13 @@ int interpn_hip_eval_host_sharded(interpn_hip_interp* const* handles, size_t nha
 
 /* Evaluate on device arrays (asynchronous on `stream`, a hipStream_t; NULL = default stream).
  * `obs` is a HOST array of `nobs` DEVICE pointers, each to `npoints` elements; `out` is a device
- * pointer to `npoints` elements.  Returns as soon as the kernel is enqueued. */
+ * pointer to `npoints` elements.  Returns as soon as the work is enqueued: one kernel, no copy and
+ * no synchronisation, so the call can be captured into a hipGraph.  One exception outside capture:
+ * large batches on 4-D multicubic grids whose re-laid table is far beyond the L2 are first
+ * counting-sorted by the table position of their footprint (three more launches on `stream`
+ * into a scratch block the handle keeps; allocated on the first such call), which makes the
+ * 16 table lines a point reads L2 hits instead of misses (option "binned": -1 auto, 0 never,
+ * 1 always for N = 2..4).  Results and the first-failing-index contract are unchanged. */
 int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out,
                             size_t npoints, void* stream);
 
@@ -230,7 +236,8 @@ int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu);
 
 /* Per-handle tuning / testing options by name (the list is in the header comment above:
  * "blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic", "generic_runtime",
- * "generic_vec", "persistent", "axis_lds_kb", "host_chunk").  Their defaults are latched from the
+ * "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal"; read-only:
+ * "last_binned" = 1 if the most recent device-pointer evaluation sorted its points first).  Their defaults are latched from the
  * INTERPN_HIP_* environment variables when the handle is created.  INTERPN_HIP_ERR_INVALID_ARGUMENT
  * for an unknown name or a value out of range.  Not synchronised against evaluations running
  * concurrently on the same handle. */

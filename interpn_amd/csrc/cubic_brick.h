@@ -32,6 +32,16 @@ struct CubicBrickArgs {
   unsigned plane_stride[N];  // d >= 2: table elements per unit index of dim d
   unsigned nbj;
   int linearize;
+  // Binned evaluation (k_bin_points.hip): `obs` then holds the points in table order, point k
+  // being point scatter[k] of the caller's slice; its result goes to out[scatter[k]] and a failing
+  // coordinate reports index_base + scatter[k].  nullptr = points are evaluated in place.
+  const unsigned* scatter;
+  size_t index_base;
+  // Binned evaluation, dealing the sorted order out to the XCDs: workgroups with equal
+  // blockIdx % 8 (one XCD under the observed round-robin placement; speed only) walk one
+  // contiguous eighth of the points, `eighth` points long (a multiple of 256; 0 = off), so that
+  // an XCD's L2 only ever holds its own part of the table.
+  size_t eighth;
 };
 
 #ifdef INTERPN_DEBUG_OFFSETS
@@ -133,10 +143,17 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
   // private to the group's wave): index it with the data matrix' group stride.
   const unsigned goff = group * (unsigned)(16 * kCubRow * sizeof(T) / 4);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
-  const size_t niter = (a.npts + nthreads - 1) / nthreads;
+  const size_t per_xcd = (size_t)(gridDim.x >> 3) * kBlock;  // points one XCD's workgroups cover per iteration
+  const size_t niter = a.eighth ? (a.eighth + per_xcd - 1) / per_xcd : (a.npts + nthreads - 1) / nthreads;
   for (size_t it = 0; it < niter; ++it) {
-    const size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
-    const bool live = i0 < a.npts;
+    size_t i0 = it * nthreads + (size_t)blockIdx.x * kBlock + lane;
+    bool live = i0 < a.npts;
+    if (a.eighth) {
+      const size_t within = it * per_xcd + (size_t)(blockIdx.x >> 3) * kBlock + lane;
+      i0 = (size_t)(blockIdx.x & 7u) * a.eighth + within;
+      live = within < a.eighth && i0 < a.npts;
+    }
+    const size_t dst = (a.scatter && live) ? (size_t)a.scatter[i0] : i0;  // where the result goes
     DimT dim[N];
     int loc[N];
     bool ok = true;
@@ -168,7 +185,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
         loc[d] = l;
       }
     }
-    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)i0);
+    if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)(a.index_base + dst));
     // Offsets of my point's 16 footprint elements (plane base included) -> LDS, transposed.
     unsigned pbase = 0;
 #pragma unroll
@@ -186,7 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
     wave_sync();
     const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim);
-    if (live) stream_store(a.out + i0, res);
+    if (live) stream_store(a.out + dst, res);
   }
 }
 

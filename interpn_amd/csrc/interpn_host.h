@@ -28,6 +28,8 @@ struct LaunchConfig {
   int persistent = 0;      // C-order regular / nearest kernels: persistent grid instead of one pass
   int axis_lds_kb = -1;    // LDS budget for the rectilinear axis image in KiB (-1 = the kernel's default)
   long long host_chunk = 0;  // points per chunk of the host-pointer pipeline (0 = default)
+  int deal = 1;            // binned evaluation: deal the sorted points out to the XCDs (cubic_brick.h `eighth`)
+  int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
 };
 
 // What the most recent launch through a handle ran: the kernel template and its arguments in
@@ -91,6 +93,7 @@ struct GridDesc {
   double bound_hi[8] = {0};
   LaunchConfig cfg;
   mutable KernelTag tag;
+  mutable int last_binned = 0;  // the most recent device-pointer evaluation sorted its points first (binned evaluation)
 };
 
 // Brick kernels cover the batch with ONE pass of small workgroups (each owning `iters` consecutive
@@ -153,9 +156,37 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
 // Tiled multicubic path (k_cubic_brick.hip): dims 0,1 in 4 x 4 tiles stepped brick_step[0..1].
 void cubic_tile_geometry(const GridDesc& g, int si, int sj, unsigned nb[2], size_t* bytes);
 hipError_t build_cubic_tiles(const GridDesc& g, void* tiles, hipStream_t stream);
+// `scatter` / `index_base`: binned evaluation (below); nullptr / 0 = points evaluated in place.
 template <typename T>
 hipError_t launch_cubic_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                              unsigned long long* first_bad, hipStream_t stream);
+                              unsigned long long* first_bad, hipStream_t stream, const unsigned* scatter = nullptr,
+                              size_t index_base = 0);
+
+// Binned evaluation of the tiled multicubic kernels (k_bin_points.hip).  A 4-D cubic point reads
+// 16 table lines; with unordered points and a table far beyond the 4 MiB L2 every one of them is
+// an L2 miss and the kernel runs at the fabric's line rate (cfg4: 2.8 ms per 1e7 points).  The
+// points of a batch are therefore first counting-sorted by the tile position of their footprint
+// in dims 0,1 — a copy of the coordinates in table order plus the original index of every point —
+// so that the workgroups in flight at any moment share a few hundred KiB of the table; the cubic
+// kernel then reads the sorted copy and scatters its results to out[original index].  The key is
+// only a locality hint (any assignment of points to bins gives the same results).
+struct BinPlan {
+  int nbins = 0;      // <= kMaxBins
+  int nb1 = 0;        // bins along dim 1
+  int mult = 1;       // bins are visited in the order key * mult mod nbins (k_bin_points.hip::bin_key)
+  int ncell[2] = {0, 0};   // footprint origins per dim: n - 3
+  int shift[2] = {0, 0};   // bin = cell >> shift
+  double start[2] = {0, 0};
+  double scale[2] = {0, 0};  // cell ~ floor((x - start) * scale) - 1
+};
+constexpr int kMaxBins = 256;  // a key fits one byte; 841 exact tile positions (cfg4) evaluated no faster than 225 bins
+constexpr size_t kBinSlicePoints = (size_t)1 << 25;  // points sorted and evaluated per slice (bounds the scratch)
+bool make_bin_plan(const GridDesc& g, BinPlan* plan);
+size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points);
+// Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
+// original indices (within the slice).
+hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
+                      const void** binned_obs, const unsigned** index, hipStream_t stream);
 
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>

@@ -44,12 +44,14 @@ static hipError_t launch_steps(const GridDesc& g, const CubicBrickArgs<T, N>& a,
 
 template <typename T, int N>
 static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
-                           hipStream_t stream) {
+                           hipStream_t stream, const unsigned* scatter, size_t index_base) {
   CubicBrickArgs<T, N> a;
   a.bricks = static_cast<const T*>(g.bricks);
   a.out = out;
   a.first_bad = first_bad;
   a.npts = npts;
+  a.scatter = scatter;
+  a.index_base = index_base;
   a.linearize = g.linearize;
   for (int d = 0; d < N; ++d) {
     a.obs[d] = obs[d];
@@ -71,6 +73,8 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
   const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  a.eighth = 0;
+  if (scatter && g.cfg.deal && blocks >= 64 && blocks % 8 == 0) a.eighth = ((npts + 7) / 8 + kBlock - 1) / kBlock * kBlock;
   if (g.kind == kRegular)
     return g.fma ? launch_steps<T, N, false, true>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, false, false>(g, a, lds, blocks, stream);
@@ -80,16 +84,18 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
 
 template <typename T>
 hipError_t launch_cubic_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                              unsigned long long* first_bad, hipStream_t stream) {
+                              unsigned long long* first_bad, hipStream_t stream, const unsigned* scatter, size_t index_base) {
   switch (g.ndims) {
-    case 2: return launch_n<T, 2>(g, obs, out, npts, first_bad, stream);
-    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream);
-    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream);
+    case 2: return launch_n<T, 2>(g, obs, out, npts, first_bad, stream, scatter, index_base);
+    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream, scatter, index_base);
+    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream, scatter, index_base);
     default: return hipErrorInvalidValue;
   }
 }
 
-template hipError_t launch_cubic_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
-template hipError_t launch_cubic_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_cubic_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t,
+                                               const unsigned*, size_t);
+template hipError_t launch_cubic_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t,
+                                              const unsigned*, size_t);
 
 }  // namespace interpn

@@ -1159,3 +1159,111 @@ def test_rectilinear_long_axes(oracle, monkeypatch, method, axis):
         case = synthetic_case(method, "rectilinear", len(axis), axis, 60_007, 5000 + sum(axis), np.float64,
                               linearize=True, extrap=0.1)
         assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+def _make_interp(interpn_amd, case):
+    if case.kind == "regular":
+        return interpn_amd.Interpolator.regular(case.method, case.dims, case.starts, case.steps, case.vals,
+                                                linearize_extrapolation=case.linearize)
+    return interpn_amd.Interpolator.rectilinear(case.method, case.grids, case.vals, linearize_extrapolation=case.linearize)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("axis,layout", [([9, 7], "11"), ([6, 5, 7], "44"), ([5, 6, 4, 7], "11"), ([4, 4, 4, 4], "24"),
+                                         ([40, 37, 5, 4], "11")], ids=str)
+def test_binned_multicubic_evaluation(oracle, monkeypatch, dtype, kind, axis, layout):
+    """Binned evaluation (k_bin_points.hip): the points of a device-resident batch are
+    counting-sorted by the tile position of their footprint, the tiled multicubic kernel reads the
+    sorted copy and scatters its results to out[original index].  Forced here for N = 2..4 at
+    small sizes: batches of one point, less than a chunk (4096), several chunks with a ragged
+    tail, grids with more tile positions than bins (key shifts), minimum-size grids (one bin),
+    sorted order dealt out to the XCDs or not, several tile layouts (forced: grids this small
+    would stay on the C-order kernels, which have no binned form) — always the oracle's bits,
+    NaN / inf coordinates and out-of-range points included.  src/multicubic/regular.rs:297-313 (a point's result depends
+    on its own coordinates only)."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
+    dev = torch.device("cuda:0")
+    n = len(axis)
+    want_t = torch.float64 if dtype == np.float64 else torch.float32
+    for nobs, deal in ((1, 1), (255, 1), (4097, 0), (16_384, 1), (32_700, 1), (32_700, 0), (70_001, 1), (600_011, 1)):
+        case = synthetic_case("cubic", kind, n, axis, nobs, 9100 + sum(axis) + nobs, dtype, linearize=bool(nobs % 2),
+                              extrap=0.3, specials=min(axis) >= 8)
+        if kind == "rectilinear" and nobs > 100:  # rectilinear grids never fail per point: NaN propagates
+            case.obs[0][17] = np.nan
+            case.obs[n - 1][18] = np.inf
+        want = run_oracle(oracle, case, True)
+        it = _make_interp(interpn_amd, case)
+        it.set_option("binned", 1)
+        it.set_option("deal", deal)
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)
+        out = out_full[1:1 + nobs]
+        it.eval_tensors(obs, out)
+        it.finish()
+        assert it.get_option("last_binned") == 1
+        got = out.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), (nobs, deal)
+        assert float(out_full[0]) == -5.0 and float(out_full[-1]) == -5.0  # nothing outside the batch was written
+        # the same handle with the points evaluated in place gives the same bits
+        it.set_option("binned", 0)
+        got0 = it.eval_tensors(obs).cpu().numpy()
+        it.finish()
+        assert it.get_option("last_binned") == 0
+        assert np.array_equal(np.isnan(got0), np.isnan(got)) and np.array_equal(got0[~np.isnan(got0)], got[~np.isnan(got)])
+        it.close()
+
+
+def test_binned_evaluation_first_bad_index_and_concurrency(oracle, monkeypatch):
+    """Binned evaluation keeps the device-pointer contract: the sticky status reports the SMALLEST
+    failing original index although the points were evaluated in table order; two streams
+    evaluating through one handle take turns in its scratch (the second waits on the first's
+    event); under graph capture the call falls back to the one-kernel form."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    case = synthetic_case("cubic", "regular", 4, [6, 7, 5, 6], 200_000, 9300, np.float64, extrap=0.2, specials=False)
+    want = run_oracle(oracle, case, True)
+    it = _make_interp(interpn_amd, case)
+    it.set_option("binned", 1)
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    bad = [o.clone() for o in obs]
+    bad[2][150_000] = float("nan")
+    bad[0][60_123] = float("inf")
+    bad[3][199_999] = float("nan")
+    out = it.eval_tensors(bad)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as err:
+        it.finish()
+    assert err.value.first_bad_index == 60_123
+    assert it.get_option("last_binned") == 1
+    assert np.array_equal(out[:60_123].cpu().numpy(), want[:60_123])
+    # two streams, one handle
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(it.eval_tensors(obs))
+    torch.cuda.synchronize()
+    it.finish()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), want)
+    # capture: no allocation, no extra launches -> the direct kernel
+    res = torch.zeros(200_000, dtype=torch.float64, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        it.eval_tensors(obs, res)
+    assert it.get_option("last_binned") == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), want)
+    it.finish()
+    it.close()
