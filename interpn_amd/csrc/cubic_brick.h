@@ -73,7 +73,8 @@ __device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typena
 // Gather one (i, j) footprint plane at table offset `delta` for all lanes, reduce dims 0 and 1.
 template <typename T, bool RECT, bool FMA>
 __device__ __forceinline__ T gather_plane(const T* __restrict__ bricks, const unsigned* toff, unsigned delta, T __attribute__((may_alias))* lds_data,
-                                          unsigned group, unsigned me, const typename CubicDimSel<T, RECT>::type* dim) {
+                                          unsigned group, unsigned me, const typename CubicDimSel<T, RECT>::type* dim,
+                                          unsigned interior) {
   T val[16];
 #ifdef INTERPN_DEBUG_OFFSETS
 #pragma unroll
@@ -95,9 +96,22 @@ __device__ __forceinline__ T gather_plane(const T* __restrict__ bricks, const un
   wave_sync();
   // element e = ei*4 + ej; reduce dim 0 (i) for every j, then dim 1 (j)
   T w[4];
+  if constexpr (!RECT) {
+    // wave-uniform: every lane interior along the dimension -> the select-free node (same bits)
+    if (interior & 1u) {
 #pragma unroll
-  for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
-  return cubic_node_sel<RECT, FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+      for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_regular_node_interior<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0].tt);
+    } else {
+#pragma unroll
+      for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_regular_node<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
+    }
+    if (interior & 2u) return cubic_regular_node_interior<FMA, T>(w[0], w[1], w[2], w[3], dim[1].tt);
+    return cubic_regular_node<FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+  } else {
+#pragma unroll
+    for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
+    return cubic_node_sel<RECT, FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+  }
 }
 
 // Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
@@ -105,12 +119,12 @@ template <typename T, int D, bool RECT, bool FMA>
 struct PlaneReduce {
   __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
                                           const unsigned* plane_stride, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
-                                          const typename CubicDimSel<T, RECT>::type* dim) {
+                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
     T s[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
       s[o] = PlaneReduce<T, D - 1, RECT, FMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D], plane_stride, lds_data,
-                                                   group, me, dim);
+                                                   group, me, dim, interior);
     return cubic_node_sel<RECT, FMA, T>(s[0], s[1], s[2], s[3], dim[D]);
   }
 };
@@ -118,8 +132,8 @@ template <typename T, bool RECT, bool FMA>
 struct PlaneReduce<T, 1, RECT, FMA> {
   __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
                                           const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
-                                          const typename CubicDimSel<T, RECT>::type* dim) {
-    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim);
+                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
   }
 };
 
@@ -202,7 +216,14 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
     wave_sync();
-    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim);
+    // bit d set: every lane of this wave is interior along dim d (d = 0, 1; regular grids)
+    unsigned interior = 0;
+    if constexpr (!RECT) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
+    }
+    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
     if (live) stream_store(a.out + dst, res);
   }
 }

@@ -262,6 +262,21 @@ struct CubicDimRegular {
   int linear;  // OutsideLow/OutsideHigh with linearize_extrapolation
 };
 
+// The same node when the saturation class is known to be None (interior cell, no linearized
+// extrapolation): the reference's `Saturation::None` arm (multicubic/regular.rs:495-505) without
+// the selects.  Used by the tiled kernels when a whole wave is interior along a dimension — the
+// common case once the points are sorted by cell (binned evaluation): 80 of the 85 nodes of a 4-D
+// point belong to dims 0 and 1.  Every operation is the one the select form evaluates for
+// sat == None, so the bits are the same.
+template <bool FMA, typename T>
+__device__ __forceinline__ T cubic_regular_node_interior(T v0, T v1, T v2, T v3, T t) {
+  const T two = (T)2;
+  const T dy = v2 - v1;
+  const T k0 = (v2 - v0) / two;
+  const T k1 = (v3 - v1) / two;
+  return hermite<FMA>(t, v1, dy, k0, k1);
+}
+
 template <bool FMA, typename T>
 __device__ __forceinline__ T cubic_regular_node(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
   const T two = (T)2, one = (T)1;

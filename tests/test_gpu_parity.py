@@ -1267,3 +1267,25 @@ def test_binned_evaluation_first_bad_index_and_concurrency(oracle, monkeypatch):
     assert np.array_equal(res.cpu().numpy(), want)
     it.finish()
     it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("axis,layout", [([12, 11], "11"), ([10, 12, 9], "44"), ([9, 10, 8, 9], "11"), ([9, 10, 8, 9], "22")], ids=str)
+@pytest.mark.parametrize("region", ["interior", "dim0_interior", "mixed"])
+def test_cubic_wave_uniform_interior_nodes(oracle, monkeypatch, dtype, axis, layout, region):
+    """The tiled multicubic kernel evaluates dims 0 and 1 with a select-free node when every lane
+    of a wave sits in an interior cell along that dimension (cubic_regular_node_interior: the
+    reference's Saturation::None arm, multicubic/regular.rs:495-505).  Batches that are interior
+    everywhere, interior along dim 0 only, and mixed must give the oracle's bits; both
+    `linearize_extrapolation` flags."""
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
+    n = len(axis)
+    for linearize in (False, True):
+        case = synthetic_case("cubic", "regular", n, axis, 20_003, 9500 + sum(axis), dtype, linearize=linearize, extrap=0.2,
+                              specials=False)
+        rng = np.random.default_rng(5)
+        for d in range(n):
+            g = case.grids[d].astype(np.float64)
+            if region == "interior" or (region == "dim0_interior" and d == 0):
+                case.obs[d] = rng.uniform(g[1] + 1e-3, g[-2] - 1e-3, 20_003).astype(dtype)
+        assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
