@@ -474,6 +474,48 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   return INTERPN_HIP_OK;
 }
 
+// 1-D multilinear on a rectilinear axis: one record per search bucket (k_linear1_records.hip).
+// M uniform buckets are doubled from 2n until none holds two coordinates; axes that would need
+// more than 128 MiB of records (strongly clustered coordinates), unsorted or non-finite axes keep
+// the general kernel.  INTERPN_HIP_BRICKS=off disables.
+int maybe_build_records1(interpn_hip_interp* h) {
+  GridDesc& g = h->desc;
+  const char* env = getenv("INTERPN_HIP_BRICKS");
+  if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
+  if (!g.axis_buckets[0] || g.n[0] < 2 || !g.grid[0] || !g.vals) return INTERPN_HIP_OK;  // no table: axis not proven sorted
+  // An axis image that fits the LDS budget of the 1-D kernel is searched there at the stream
+  // rate already (<= 512 points: 0.33 ms per 1e8 points against 0.5-0.67 ms from records); the
+  // records serve the longer axes, whose search otherwise goes through L1/L2 (4096 points:
+  // 1.25 -> 0.71 ms).  INTERPN_HIP_BRICKS=on builds them regardless (tests).
+  if (g.axis_image_bytes <= kMaxGridLdsBytesWide && !(env && !strcmp(env, "on"))) return INTERPN_HIP_OK;
+  const double span = g.bound_hi[0] - g.bound_lo[0];
+  if (!(span > 0) || !std::isfinite(span)) return INTERPN_HIP_OK;
+  unsigned* maxpop_dev = nullptr;
+  if (pool_alloc(h->device, (void**)&maxpop_dev, sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return INTERPN_HIP_OK; }
+  int st = INTERPN_HIP_OK;
+  for (long long M = 2LL * g.n[0]; M <= (1LL << 24) && records1_bytes(g, (int)M) <= ((size_t)128 << 20); M *= 2) {
+    double scale = (double)M / span;
+    if (g.dtype == kF32) scale = (double)(float)scale;
+    if (!(scale > 0) || !std::isfinite(scale)) break;
+    void* recs = nullptr;
+    if (pool_alloc(h->device, &recs, records1_bytes(g, (int)M)) != hipSuccess) { (void)hipGetLastError(); break; }
+    unsigned maxpop = 2;
+    hipError_t e = build_records1(g, (int)M, scale, recs, maxpop_dev, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&maxpop, maxpop_dev, sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { pool_free(h->device, recs); st = hip_fail(e); break; }
+    if (maxpop <= 1) {
+      h->bricks_owned = recs;
+      g.bricks = recs;
+      g.rec1_buckets = (int)M;
+      g.rec1_scale = scale;
+      break;
+    }
+    pool_free(h->device, recs);
+  }
+  pool_free(h->device, maxpop_dev);
+  return st;
+}
+
 int maybe_build_bricks(interpn_hip_interp* h) {
   GridDesc& g = h->desc;
   if (g.method == kCubic && g.ndims >= 2 && g.ndims <= 4) return maybe_build_cubic_tiles(h);
@@ -494,6 +536,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     g.bricks = h->bricks_owned;
     return INTERPN_HIP_OK;
   }
+  if (g.method == kLinear && g.ndims == 1 && g.kind == kRectilinear) return maybe_build_records1(h);
   if (!(g.method == kLinear && g.ndims >= 3 && g.ndims <= 6)) return INTERPN_HIP_OK;
   const char* env = getenv("INTERPN_HIP_BRICKS");
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
@@ -827,6 +870,11 @@ hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size
     return launch_cubic_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts,
                                      first_bad, stream);
   }
+  if (g.bricks && npts && g.ndims == 1 && g.method == kLinear && g.rec1_buckets && !g.cfg.force_generic) {
+    if (g.dtype == kF64)
+      return launch_linear1_records<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npts, stream);
+    return launch_linear1_records<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npts, stream);
+  }
   if (g.bricks && npts && g.ndims == 2 && !g.cfg.force_generic) {
     if (g.dtype == kF64)
       return launch_linear2_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out),
@@ -1018,6 +1066,7 @@ int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip
   g.vals = nullptr;
   g.bricks = nullptr;
   g.brick_cell = 0;
+  g.rec1_buckets = 0;
   g.axis_image = nullptr;
   g.tag = KernelTag();
   for (int d = 0; d < 8; ++d) g.grid[d] = nullptr;
@@ -1102,6 +1151,7 @@ size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* st
   unsigned nb[3];
   unsigned nb4[4];
   if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+  else if (g.ndims == 1) bytes = records1_bytes(g, g.rec1_buckets);
   else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
   else if (g.brick_cell) brick_cell_geometry(g, nb4, &bytes);
   else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);

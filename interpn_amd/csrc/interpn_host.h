@@ -84,6 +84,10 @@ struct GridDesc {
   // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell
   // per line); brick_nb[3] then counts the bricks along dimension N-4.
   const void* bricks = nullptr;
+  // 1-D multilinear on a rectilinear axis: `bricks` holds one record per search bucket
+  // (k_linear1_records.hip) when rec1_buckets != 0.
+  int rec1_buckets = 0;
+  double rec1_scale = 0.0;
   int brick_step[2] = {2, 2};
   unsigned brick_nb[4] = {0, 0, 0, 0};
   int brick_cell = 0;
@@ -145,6 +149,12 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
                                unsigned long long* first_bad, hipStream_t stream);
+
+// 1-D multilinear-rectilinear from per-bucket records (k_linear1_records.hip).
+size_t records1_bytes(const GridDesc& g, int M);
+hipError_t build_records1(const GridDesc& g, int M, double scale, void* recs, unsigned* maxpop_dev, hipStream_t stream);
+template <typename T>
+hipError_t launch_linear1_records(const GridDesc& g, const T* const* obs, T* out, size_t npts, hipStream_t stream);
 
 // Bricked 2-D multilinear path (k_linear2_brick.hip): 2 x KW2 bricks, steps (1, KW2-1).
 void brick2_geometry(const GridDesc& g, unsigned nb[2], size_t* bytes);

@@ -1289,3 +1289,64 @@ def test_cubic_wave_uniform_interior_nodes(oracle, monkeypatch, dtype, axis, lay
             if region == "interior" or (region == "dim0_interior" and d == 0):
                 case.obs[d] = rng.uniform(g[1] + 1e-3, g[-2] - 1e-3, 20_003).astype(dtype)
         assert_parity(case, run_hip_raw(case), run_oracle(oracle, case, True))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("axis", ["n2", "n3", "jitter_100", "jitter_9000", "log_300", "two_scales_6000", "dense_pairs"])
+def test_linear_1d_rectilinear_records(oracle, monkeypatch, dtype, fma, axis):
+    """1-D multilinear on a rectilinear axis from one record per search bucket
+    (k_linear1_records.hip): chosen by itself for axes too long for the LDS search (9000 points),
+    forced here for short ones (INTERPN_HIP_BRICKS=on); axes on which no bucket count separates
+    the coordinates within the table budget keep the general kernel.  Exact nodes, both ends,
+    NaN, +-inf and far-away coordinates included; multilinear/rectilinear.rs:353-370 (the cell),
+    :310-313 and :339-344 (the arithmetic)."""
+    import interpn_amd
+    from interpn_amd import _lib
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "on")
+    rng = np.random.default_rng(77)
+    if axis == "n2":
+        g = np.array([-0.5, 2.0])
+    elif axis == "n3":
+        g = np.array([-1.0, -0.75, 3.0])
+    elif axis.startswith("jitter"):
+        n = int(axis.split("_")[1])
+        g = np.linspace(-1.0, 1.0, n)
+        g[1:-1] += (rng.uniform(size=n - 2) - 0.5) * 0.5 * (g[1] - g[0])
+    elif axis == "log_300":
+        g = -1.0 + 2.0 * (np.logspace(0, 3, 300) - 1.0) / 999.0
+    elif axis == "two_scales_6000":
+        g = np.concatenate([np.linspace(-1.0, -0.9, 3000, endpoint=False), np.linspace(-0.9, 1.0, 3000)])
+    else:  # pairs of coordinates 1e-9 apart: no affordable bucket count separates them
+        base = np.linspace(-1.0, 1.0, 40)
+        g = np.sort(np.concatenate([base, base[:-1] + 1e-9]))
+    g = g.astype(dtype)
+    g = np.unique(g)  # f32 rounding may merge neighbours
+    assert np.all(np.diff(g) > 0)
+    vals = rng.uniform(-1, 1, g.size).astype(dtype)
+    nobs = 50_003
+    lo, hi = float(g[0]), float(g[-1])
+    x = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), nobs).astype(dtype)
+    k = min(g.size, 300)
+    x[:k] = g[:k]
+    x[k:k + 4] = [g[-1], np.nextafter(g[-1], np.inf, dtype=dtype), np.nextafter(g[0], -np.inf, dtype=dtype), 0.0]
+    x[k + 4:k + 9] = [np.nan, np.inf, -np.inf, 1e30, -1e30]
+    mids = ((g[:-1].astype(np.float64) + g[1:]) / 2).astype(dtype)[:1000]
+    x[1000:1000 + mids.size] = mids
+    want = np.zeros(nobs, dtype=dtype)
+    lib = _lib.load()
+    prev = lib.interpn_hip_set_fma(int(fma))
+    try:
+        oracle.linear_rectilinear([g], vals, [x], want, fma=fma)
+        it = interpn_amd.Interpolator.rectilinear("linear", [g], vals, dtype=dtype)
+        got = it.eval_host([x], np.zeros(nobs, dtype=dtype))
+        name = it.kernel_name()
+        it.close()
+    finally:
+        lib.interpn_hip_set_fma(prev)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    if axis == "dense_pairs" and dtype == np.float64:
+        assert name.startswith("interpn::k_linear_rectilinear<"), name
+    elif axis != "dense_pairs":
+        assert name.startswith("interpn::k_linear1_records<"), name
