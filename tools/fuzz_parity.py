@@ -11,7 +11,8 @@ from oracle import pyoracle
 from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
-         "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT")
+         "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
+         "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -101,6 +102,11 @@ def run(budget: float, seed: int, max_cases: int = 0):
             # (k_generic.hip::generic_vec_ok; elsewhere the option falls back to the one-tree form)
             if rng.random() < 0.5: env["INTERPN_HIP_GENERIC_VEC"] = str(int(rng.integers(0, 2)))
             if rng.random() < 0.1: env["INTERPN_HIP_PERSISTENT"] = "1"
+            # binned evaluation of the tiled multicubic kernels (device entry point, N = 2..4), dealt or not
+            if method == "cubic" and rng.random() < 0.5: env["INTERPN_HIP_BINNED"] = "1"
+            if rng.random() < 0.3: env["INTERPN_HIP_DEAL"] = "0"
+            # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
+            if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
             for k in KNOBS:
                 os.environ.pop(k, None)
             os.environ.update(env)
