@@ -21,6 +21,7 @@ namespace interpn {
 template <typename T, int N>
 struct CubicBrickArgs {
   const T* bricks;
+  unsigned table_bytes;  // < 4 GiB
   const T* obs[N];
   T* out;
   unsigned long long* first_bad;
@@ -44,11 +45,32 @@ struct CubicBrickArgs {
   size_t eighth;
 };
 
-#ifdef INTERPN_DEBUG_OFFSETS
-__device__ unsigned g_debug_limit;
-#endif
-
 constexpr int kCubRow = 18;  // elements per LDS row (16 used; 18 keeps 16-B alignment and spreads banks)
+
+// Table reads go through a raw buffer descriptor: the per-lane part of the address is a 32-bit
+// BYTE offset computed once per point (toff), the plane part (delta) is wave-uniform and rides in
+// the instruction's scalar offset, so a gather costs no address arithmetic on the vector unit (the
+// flat form spent one 64-bit add per load: 256 of ~2500 VALU instructions of a 4-D point).  The
+// descriptor's range check (num_records = table bytes) makes an out-of-range offset read 0 instead
+// of faulting.  Tables are kept below 4 GiB (interpn_abi.hip::maybe_build_cubic_tiles).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ T table_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 8) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    T v;
+    __builtin_memcpy(&v, &raw, 8);
+    return v;
+  } else {
+    const unsigned raw = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    T v;
+    __builtin_memcpy(&v, &raw, 4);
+    return v;
+  }
+}
 
 template <int S>
 __device__ __forceinline__ void tile_coord(int i0, int e, int* b, int* o) {
@@ -72,20 +94,12 @@ __device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typena
 
 // Gather one (i, j) footprint plane at table offset `delta` for all lanes, reduce dims 0 and 1.
 template <typename T, bool RECT, bool FMA>
-__device__ __forceinline__ T gather_plane(const T* __restrict__ bricks, const unsigned* toff, unsigned delta, T __attribute__((may_alias))* lds_data,
+__device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta, T __attribute__((may_alias))* lds_data,
                                           unsigned group, unsigned me, const typename CubicDimSel<T, RECT>::type* dim,
                                           unsigned interior) {
   T val[16];
-#ifdef INTERPN_DEBUG_OFFSETS
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (toff[r] + delta >= g_debug_limit) printf("OOB lane %u group %u me %u r %d toff %u delta %u limit %u\n", threadIdx.x, group, me, r, toff[r], delta, g_debug_limit);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) val[r] = (toff[r] + delta < g_debug_limit) ? bricks[toff[r] + delta] : (T)0;
-#else
-#pragma unroll
-  for (int r = 0; r < 16; ++r) val[r] = bricks[toff[r] + delta];
-#endif
+  for (int r = 0; r < 16; ++r) val[r] = table_load<T>(bricks, toff[r], delta);  // byte offsets
 #pragma unroll
   for (int r = 0; r < 16; ++r) lds_data[(group * 16 + r) * kCubRow + me] = val[r];
   wave_sync();
@@ -117,20 +131,20 @@ __device__ __forceinline__ T gather_plane(const T* __restrict__ bricks, const un
 // Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
 template <typename T, int D, bool RECT, bool FMA>
 struct PlaneReduce {
-  __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
+  __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned* plane_stride, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
                                           const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
     T s[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-      s[o] = PlaneReduce<T, D - 1, RECT, FMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D], plane_stride, lds_data,
+      s[o] = PlaneReduce<T, D - 1, RECT, FMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D] * (unsigned)sizeof(T), plane_stride, lds_data,
                                                    group, me, dim, interior);
     return cubic_node_sel<RECT, FMA, T>(s[0], s[1], s[2], s[3], dim[D]);
   }
 };
 template <typename T, bool RECT, bool FMA>
 struct PlaneReduce<T, 1, RECT, FMA> {
-  __device__ __forceinline__ static T run(const T* __restrict__ bricks, const unsigned* toff, unsigned delta,
+  __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
                                           const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
     return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
@@ -156,6 +170,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
   // The offset matrix of a group lives inside the SAME bytes as its data matrix (both regions are
   // private to the group's wave): index it with the data matrix' group stride.
   const unsigned goff = group * (unsigned)(16 * kCubRow * sizeof(T) / 4);
+  const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.bricks, a.table_bytes);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   const size_t per_xcd = (size_t)(gridDim.x >> 3) * kBlock;  // points one XCD's workgroups cover per iteration
   const size_t niter = a.eighth ? (a.eighth + per_xcd - 1) / per_xcd : (a.npts + nthreads - 1) / nthreads;
@@ -201,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     }
     if (!RECT && !ok && live) atomicMin(a.first_bad, (unsigned long long)(a.index_base + dst));
     // Offsets of my point's 16 footprint elements (plane base included) -> LDS, transposed.
-    unsigned pbase = 0;
+    unsigned pbase = 0;  // element offsets here, bytes in LDS
 #pragma unroll
     for (int d = 2; d < N; ++d) pbase += (unsigned)loc[d] * a.plane_stride[d];
 #pragma unroll
@@ -209,7 +224,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
       int bi, oi, bj, oj;
       tile_coord<SI>(loc[0], e >> 2, &bi, &oi);
       tile_coord<SJ>(loc[1], e & 3, &bj, &oj);
-      lds_off[goff + e * kCubRow + me] = pbase + ((unsigned)(bi * (int)a.nbj + bj) * 16u) + (unsigned)(oi * 4 + oj);
+      lds_off[goff + e * kCubRow + me] = (pbase + ((unsigned)(bi * (int)a.nbj + bj) * 16u) + (unsigned)(oi * 4 + oj)) * (unsigned)sizeof(T);
     }
     wave_sync();
     unsigned toff[16];
@@ -223,7 +238,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
       for (int d = 0; d < 2; ++d)
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
-    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(a.bricks, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
+    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
     if (live) stream_store(a.out + dst, res);
   }
 }

@@ -442,14 +442,14 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
   int best = -1;
   double best_cost = 0;
-  const size_t esz = g.dtype == kF64 ? 8 : 4;
   for (int c = 0; c < 5; ++c) {
     const int si = cand[c][0], sj = cand[c][1];
     if (env && strlen(env) == 2 && !(env[0] - '0' == si && env[1] - '0' == sj)) continue;
     unsigned nb[2];
     size_t bytes;
     cubic_tile_geometry(g, si, sj, nb, &bytes);
-    if (bytes / esz >= 0xFFFFFFFFull || bytes > free_b / 2 || bytes > ((size_t)4 << 30)) continue;
+    // byte offsets into the table are 32-bit in the kernel (buffer loads, cubic_brick.h)
+    if (bytes >= 0xFFFFF000ull || bytes > free_b / 2) continue;
     const double e_i = si == 4 ? 1.75 : (si == 2 ? 1.5 : 1.0);
     const double e_j = sj == 4 ? 1.75 : (sj == 2 ? 1.5 : 1.0);
     double planes = 1;

@@ -47,6 +47,12 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
                            hipStream_t stream, const unsigned* scatter, size_t index_base) {
   CubicBrickArgs<T, N> a;
   a.bricks = static_cast<const T*>(g.bricks);
+  {
+    unsigned nb[2];
+    size_t bytes = 0;
+    cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+    a.table_bytes = (unsigned)bytes;  // < 4 GiB by construction (maybe_build_cubic_tiles)
+  }
   a.out = out;
   a.first_bad = first_bad;
   a.npts = npts;
