@@ -1275,7 +1275,12 @@ int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
   st = eval_device_binned(h, obs, out, npoints, static_cast<hipStream_t>(stream));
-  if (st > 0) return st;
+  if (st > 0) {
+    // part of the sequence may be in flight on `stream` without a mark behind it
+    std::lock_guard<std::mutex> lk(h->marks_mu);
+    h->sync_device_at_destroy = true;
+    return st;
+  }
   if (st < 0) HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
   mark_stream(h, static_cast<hipStream_t>(stream));
   return INTERPN_HIP_OK;
