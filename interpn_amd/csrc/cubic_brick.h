@@ -47,6 +47,14 @@ struct CubicBrickArgs {
 
 constexpr int kCubRow = 18;  // elements per LDS row (16 used; 18 keeps 16-B alignment and spreads banks)
 
+// Which instantiations gather by LDS-DMA (gather_plane_dma), and the LDS bytes a workgroup's
+// gathers need (rectilinear axes are staged behind them).
+template <typename T, int SI, int SJ> constexpr bool cubic_dma() { return sizeof(T) == 8 && SI == 1 && SJ == 1; }
+template <typename T, int SI, int SJ> constexpr size_t cubic_lds_region() {
+  if (cubic_dma<T, SI, SJ>()) return (size_t)(kBlock / 64) * 8192;  // one 8-KiB tile image per wave
+  return (size_t)kBlock * kCubRow * (sizeof(T) > 4 ? sizeof(T) : 4);
+}
+
 // Table reads go through a raw buffer descriptor: the per-lane part of the address is a 32-bit
 // BYTE offset computed once per point (toff), the plane part (delta) is wave-uniform and rides in
 // the instruction's scalar offset, so a gather costs no address arithmetic on the vector unit (the
@@ -128,8 +136,61 @@ __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const u
   }
 }
 
+// f64, fully overlapped tiles (steps 1,1: a footprint is exactly ONE 128-byte tile): the plane's 64
+// tiles of a wave go from the table straight into LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`),
+// eight 1-KiB instructions instead of sixteen 8-byte gathers per lane plus sixteen ds_write: no
+// VGPR staging, no store traffic through the vector unit.  A DMA instruction writes lane L's 16
+// bytes at base + 16 L, so in instruction q lane L fetches the 16-byte piece that belongs at slot
+// 64 q + L of the wave's 8-KiB image, which is laid out point-major (point p = owner lane p, 8
+// slots each) with a point's pieces rotated by p >> 1: piece c sits in slot (c + (p >> 1)) & 7.
+// The rotation makes the readers conflict-free: the 16 lanes a ds_read_b128 services together
+// then hit 16 different 16-byte bank groups.  `dma_off[q]` = byte offset of that piece in the
+// table without the plane part (computed once per point from the owners' tile offsets with
+// ds_bpermute); the plane part `delta` is the instruction's scalar offset.
+template <typename T, bool RECT, bool FMA>
+__device__ __forceinline__ T gather_plane_dma(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, unsigned delta,
+                                              unsigned lds_wave /* LDS byte address of the wave's image, wave-uniform */, unsigned wl,
+                                              const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+  static_assert(sizeof(T) == 8, "LDS-DMA gather: f64 tiles");
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(bricks, (lds_byte*)(size_t)(lds_wave + (unsigned)q * 1024u), 16, dma_off[q], delta, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_sync();
+  typedef T T2 __attribute__((ext_vector_type(2), may_alias));
+  typedef __attribute__((address_space(3))) const T2 lds_T2;
+  T v[16];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned slot = wl * 8u + (((unsigned)c + (wl >> 1)) & 7u);
+    const T2 w = *(lds_T2*)(size_t)(lds_wave + slot * 16u);
+    v[2 * c] = w.x;
+    v[2 * c + 1] = w.y;
+  }
+  wave_sync();  // every lane has its tile before the next plane's DMA overwrites the image
+  T w4[4];
+  if constexpr (!RECT) {
+    if (interior & 1u) {
+#pragma unroll
+      for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_regular_node_interior<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0].tt);
+    } else {
+#pragma unroll
+      for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_regular_node<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
+    }
+    if (interior & 2u) return cubic_regular_node_interior<FMA, T>(w4[0], w4[1], w4[2], w4[3], dim[1].tt);
+    return cubic_regular_node<FMA, T>(w4[0], w4[1], w4[2], w4[3], dim[1]);
+  } else {
+#pragma unroll
+    for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
+    return cubic_node_sel<RECT, FMA, T>(w4[0], w4[1], w4[2], w4[3], dim[1]);
+  }
+}
+
 // Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
-template <typename T, int D, bool RECT, bool FMA>
+// DMA: the LDS-DMA gather (gather_plane_dma); `toff` then holds its 8 offsets, `me` the LDS byte
+// address of the wave's 8-KiB image (wave-uniform) and `group` the lane index inside the wave.
+template <typename T, int D, bool RECT, bool FMA, bool DMA>
 struct PlaneReduce {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned* plane_stride, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
@@ -137,17 +198,20 @@ struct PlaneReduce {
     T s[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-      s[o] = PlaneReduce<T, D - 1, RECT, FMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D] * (unsigned)sizeof(T), plane_stride, lds_data,
-                                                   group, me, dim, interior);
+      s[o] = PlaneReduce<T, D - 1, RECT, FMA, DMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D] * (unsigned)sizeof(T), plane_stride,
+                                                        lds_data, group, me, dim, interior);
     return cubic_node_sel<RECT, FMA, T>(s[0], s[1], s[2], s[3], dim[D]);
   }
 };
-template <typename T, bool RECT, bool FMA>
-struct PlaneReduce<T, 1, RECT, FMA> {
+template <typename T, bool RECT, bool FMA, bool DMA>
+struct PlaneReduce<T, 1, RECT, FMA, DMA> {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
                                           const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
-    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
+    if constexpr (DMA)
+      return gather_plane_dma<T, RECT, FMA>(bricks, toff, delta, me, group, dim, interior);
+    else
+      return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
   }
 };
 
@@ -159,8 +223,8 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
   typedef T __attribute__((may_alias)) lds_T;
   lds_T* lds_data = reinterpret_cast<lds_T*>(smem_raw);
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw);
-  constexpr size_t kRegion = (size_t)kBlock * kCubRow * sizeof(T) > (size_t)kBlock * kCubRow * 4
-                                 ? (size_t)kBlock * kCubRow * sizeof(T) : (size_t)kBlock * kCubRow * 4;
+  constexpr bool DMA = cubic_dma<T, SI, SJ>();
+  constexpr size_t kRegion = cubic_lds_region<T, SI, SJ>();
   unsigned char* lds_axes = smem_raw + kRegion;
   if (RECT && a.ax.use_lds) stage_axes<T, N>(a.ax, lds_axes);
   const unsigned char* axis_base = (RECT && a.ax.use_lds) ? lds_axes : a.ax.image;
@@ -171,6 +235,9 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
   // private to the group's wave): index it with the data matrix' group stride.
   const unsigned goff = group * (unsigned)(16 * kCubRow * sizeof(T) / 4);
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.bricks, a.table_bytes);
+  // LDS byte address of this wave's tile image (LDS-DMA gather), in a scalar register
+  const unsigned lds_wave = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + (lane >> 6) * 8192u));
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   const size_t per_xcd = (size_t)(gridDim.x >> 3) * kBlock;  // points one XCD's workgroups cover per iteration
   const size_t niter = a.eighth ? (a.eighth + per_xcd - 1) / per_xcd : (a.npts + nthreads - 1) / nthreads;
@@ -219,18 +286,31 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     unsigned pbase = 0;  // element offsets here, bytes in LDS
 #pragma unroll
     for (int d = 2; d < N; ++d) pbase += (unsigned)loc[d] * a.plane_stride[d];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int bi, oi, bj, oj;
-      tile_coord<SI>(loc[0], e >> 2, &bi, &oi);
-      tile_coord<SJ>(loc[1], e & 3, &bj, &oj);
-      lds_off[goff + e * kCubRow + me] = (pbase + ((unsigned)(bi * (int)a.nbj + bj) * 16u) + (unsigned)(oi * 4 + oj)) * (unsigned)sizeof(T);
-    }
-    wave_sync();
     unsigned toff[16];
+    if constexpr (DMA) {
+      // my point's tile (steps 1,1: tile index = cell) as a byte offset; instruction q of a plane's
+      // DMA has me fetch piece c of point p (gather_plane_dma)
+      const unsigned wl = lane & 63u;
+      const unsigned tb = (pbase + (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
-    wave_sync();
+      for (int q = 0; q < 8; ++q) {
+        const unsigned p = (unsigned)q * 8u + (wl >> 3);
+        const unsigned c = ((wl & 7u) - (p >> 1)) & 7u;
+        toff[q] = (unsigned)__shfl((int)tb, (int)p) + c * 16u;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int bi, oi, bj, oj;
+        tile_coord<SI>(loc[0], e >> 2, &bi, &oi);
+        tile_coord<SJ>(loc[1], e & 3, &bj, &oj);
+        lds_off[goff + e * kCubRow + me] = (pbase + ((unsigned)(bi * (int)a.nbj + bj) * 16u) + (unsigned)(oi * 4 + oj)) * (unsigned)sizeof(T);
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) toff[r] = lds_off[goff + me * kCubRow + r];
+      wave_sync();
+    }
     // bit d set: every lane of this wave is interior along dim d (d = 0, 1; regular grids)
     unsigned interior = 0;
     if constexpr (!RECT) {
@@ -238,7 +318,11 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
       for (int d = 0; d < 2; ++d)
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
-    const T res = PlaneReduce<T, N - 1, RECT, FMA>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
+    T res;
+    if constexpr (DMA)
+      res = PlaneReduce<T, N - 1, RECT, FMA, true>::run(rsrc, toff, 0u, a.plane_stride, lds_data, lane & 63u, lds_wave, dim, interior);
+    else
+      res = PlaneReduce<T, N - 1, RECT, FMA, false>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
     if (live) stream_store(a.out + dst, res);
   }
 }

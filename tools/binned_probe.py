@@ -27,7 +27,7 @@ def timed(it, o, res, reps):
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
 
-cases = [("cubic", "regular", 32, 4), ("cubic", "rectilinear", 32, 4), ("cubic", "regular", 48, 4), ("cubic", "regular", 64, 3)]
+cases = [("cubic", "regular", 32, 4), ("cubic", "rectilinear", 32, 4), ("cubic", "regular", 64, 3), ("cubic", "rectilinear", 64, 3), ("cubic", "regular", 512, 2)]
 only = sys.argv[1:]
 for method, kind, n, N in cases:
     g = np.linspace(-1, 1, n)
