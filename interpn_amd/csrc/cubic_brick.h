@@ -146,21 +146,24 @@ __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const u
 // The rotation makes the readers conflict-free: the 16 lanes a ds_read_b128 services together
 // then hit 16 different 16-byte bank groups.  `dma_off[q]` = byte offset of that piece in the
 // table without the plane part (computed once per point from the owners' tile offsets with
-// ds_bpermute); the plane part `delta` is the instruction's scalar offset.
-template <typename T, bool RECT, bool FMA>
-__device__ __forceinline__ T gather_plane_dma(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, unsigned delta,
-                                              unsigned lds_wave /* LDS byte address of the wave's image, wave-uniform */, unsigned wl,
-                                              const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+// ds_bpermute); the plane part `delta` is the instruction's scalar offset; `lds_wave` = LDS byte
+// address of the wave's image (wave-uniform, in a scalar register).
+template <typename T>
+__device__ __forceinline__ void dma_issue_plane(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, unsigned delta, unsigned lds_wave) {
   static_assert(sizeof(T) == 8, "LDS-DMA gather: f64 tiles");
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
 #pragma unroll
   for (int q = 0; q < 8; ++q)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(bricks, (lds_byte*)(size_t)(lds_wave + (unsigned)q * 1024u), 16, dma_off[q], delta, 0, 0);
+}
+
+// Wait for the plane in flight, take my tile out of the image (v[e], e = ei * 4 + ej).
+template <typename T>
+__device__ __forceinline__ void dma_take_tile(unsigned lds_wave, unsigned wl, T (&v)[16]) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
   typedef T T2 __attribute__((ext_vector_type(2), may_alias));
   typedef __attribute__((address_space(3))) const T2 lds_T2;
-  T v[16];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const unsigned slot = wl * 8u + (((unsigned)c + (wl >> 1)) & 7u);
@@ -168,7 +171,15 @@ __device__ __forceinline__ T gather_plane_dma(__amdgpu_buffer_rsrc_t bricks, con
     v[2 * c] = w.x;
     v[2 * c + 1] = w.y;
   }
-  wave_sync();  // every lane has its tile before the next plane's DMA overwrites the image
+  // every lane must HAVE its tile (reads returned, not merely issued) before the next plane's
+  // DMA — which the caller issues next, ahead of this plane's arithmetic — overwrites the image
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wave_sync();
+}
+
+// dims 0 and 1 of one tile
+template <typename T, bool RECT, bool FMA>
+__device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
   T w4[4];
   if constexpr (!RECT) {
     if (interior & 1u) {
@@ -187,9 +198,52 @@ __device__ __forceinline__ T gather_plane_dma(__amdgpu_buffer_rsrc_t bricks, con
   }
 }
 
+// All 4^(N-2) planes of a point, software-pipelined: the DMA of plane k+1 is issued as soon as
+// every lane has taken its tile of plane k out of the image, i.e. BEFORE plane k's nodes are
+// evaluated, so the table latency of the next plane hides behind the arithmetic of this one
+// with one 8-KiB image per wave and no extra registers (the tile is in registers anyway).
+// Plane order and reduction tree are the reference's (dim 2 inside dim 3;
+// src/multicubic/regular.rs:368-421).
+template <typename T, int N, bool RECT, bool FMA>
+__device__ __forceinline__ T reduce_planes_dma(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, const unsigned* plane_stride,
+                                               unsigned lds_wave, unsigned wl,
+                                               const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+  static_assert(N >= 2 && N <= 4, "tiled multicubic: N = 2..4");
+  constexpr int NP = N == 2 ? 1 : (N == 3 ? 4 : 16);
+  auto delta_of = [&](int k) -> unsigned {  // byte offset of plane k: dim 2 index = k & 3, dim 3 index = k >> 2
+    unsigned d = 0;
+    if constexpr (N >= 3) d += (unsigned)(k & 3) * plane_stride[2];
+    if constexpr (N >= 4) d += (unsigned)(k >> 2) * plane_stride[3];
+    return d * (unsigned)sizeof(T);
+  };
+  dma_issue_plane<T>(bricks, dma_off, delta_of(0), lds_wave);
+  T s2[4], s3[4];
+  T res = (T)0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    T v[16];
+    dma_take_tile<T>(lds_wave, wl, v);
+    if (k + 1 < NP) dma_issue_plane<T>(bricks, dma_off, delta_of(k + 1), lds_wave);
+    const T r01 = reduce_tile<T, RECT, FMA>(v, dim, interior);
+    if constexpr (N == 2) {
+      res = r01;
+    } else {
+      s2[k & 3] = r01;
+      if ((k & 3) == 3) {
+        const T r2 = cubic_node_sel<RECT, FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+        if constexpr (N == 3) {
+          res = r2;
+        } else {
+          s3[k >> 2] = r2;
+          if (k == NP - 1) res = cubic_node_sel<RECT, FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+        }
+      }
+    }
+  }
+  return res;
+}
+
 // Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
-// DMA: the LDS-DMA gather (gather_plane_dma); `toff` then holds its 8 offsets, `me` the LDS byte
-// address of the wave's 8-KiB image (wave-uniform) and `group` the lane index inside the wave.
 template <typename T, int D, bool RECT, bool FMA, bool DMA>
 struct PlaneReduce {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
@@ -208,10 +262,8 @@ struct PlaneReduce<T, 1, RECT, FMA, DMA> {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
                                           const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
-    if constexpr (DMA)
-      return gather_plane_dma<T, RECT, FMA>(bricks, toff, delta, me, group, dim, interior);
-    else
-      return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
+    static_assert(!DMA, "the LDS-DMA form runs reduce_planes_dma");
+    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
   }
 };
 
@@ -320,7 +372,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     }
     T res;
     if constexpr (DMA)
-      res = PlaneReduce<T, N - 1, RECT, FMA, true>::run(rsrc, toff, 0u, a.plane_stride, lds_data, lane & 63u, lds_wave, dim, interior);
+      res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);
     else
       res = PlaneReduce<T, N - 1, RECT, FMA, false>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
     if (live) stream_store(a.out + dst, res);
