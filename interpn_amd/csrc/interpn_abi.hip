@@ -290,6 +290,7 @@ struct interpn_hip_interp {
   void* vals_owned = nullptr;   // device copy of vals when created from host memory
   void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
   void* bricks_owned = nullptr; // bricked copy of vals (3-D multilinear f64)
+  void* bricks11_owned = nullptr;  // 4-D multicubic: fully overlapped tiles for binned evaluation when `bricks` is another layout
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
   unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
   std::mutex finish_mu;
@@ -461,6 +462,20 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
   }
   if (best < 0) return INTERPN_HIP_OK;
+  const bool forced = env && strlen(env) == 2;
+  unsigned nb11[2];
+  size_t bytes11 = 0;
+  cubic_tile_geometry(g, 1, 1, nb11, &bytes11);
+  const bool fits11 = bytes11 < 0xFFFFF000ull && bytes11 <= free_b / 2;
+  // f64 fully overlapped tiles are gathered by LDS-DMA (cubic_brick.h), which the line-rate model
+  // above does not know: measured in place on 1e7 points (tools/cubic4_layout_probe.py and the
+  // N = 2, 3 probe of the same session), (1,1) beats the model's choice whenever its table is at
+  // most 8 MiB (4-D 16^4: 1.11 vs 1.42 ms; 3-D 40^3: 0.35 vs 0.45; 2-D 256^2: 0.143 vs 0.168), for
+  // every 2-D grid (512^2: 0.19 vs 0.20) and for every rectilinear grid (VALU-bound kernels:
+  // 3-D 64^3 0.91 vs 0.94, 4-D 20^4 2.88 vs 2.96).
+  if (!forced && g.dtype == kF64 && fits11 &&
+      (bytes11 <= ((size_t)8 << 20) || g.ndims == 2 || g.kind == kRectilinear))
+    best = 4;
   size_t bytes;
   g.brick_step[0] = cand[best][0];
   g.brick_step[1] = cand[best][1];
@@ -471,6 +486,26 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   HIP_TRY(build_cubic_tiles(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   g.bricks = h->bricks_owned;
+  // 4-D grids in the band where an L2-friendly layout wins for small batches (20^4 .. 26^4 in f64)
+  // also keep the fully overlapped table: large batches are evaluated binned on it
+  // (eval_device_binned; 24^4 at 1e7 points: 1.38 against 1.79 ms, at 1e6: 0.154 against 0.204).
+  g.bricks11 = nullptr;
+  if (!forced && g.ndims == 4 && best != 4 && fits11 && bytes11 > ((size_t)8 << 20)) {
+    if (pool_alloc(h->device, &h->bricks11_owned, bytes11) == hipSuccess) {
+      GridDesc t = g;
+      t.brick_step[0] = t.brick_step[1] = 1;
+      t.brick_nb[0] = nb11[0];
+      t.brick_nb[1] = nb11[1];
+      HIP_TRY(build_cubic_tiles(t, h->bricks11_owned, nullptr));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      g.bricks11 = h->bricks11_owned;
+      g.bricks11_nb[0] = nb11[0];
+      g.bricks11_nb[1] = nb11[1];
+    } else {
+      (void)hipGetLastError();
+      h->bricks11_owned = nullptr;
+    }
+  }
   return INTERPN_HIP_OK;
 }
 
@@ -1065,6 +1100,7 @@ int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip
   g = src->desc;  // scalars, axis-image offsets, options; every device pointer is replaced below
   g.vals = nullptr;
   g.bricks = nullptr;
+  g.bricks11 = nullptr;
   g.brick_cell = 0;
   g.rec1_buckets = 0;
   g.axis_image = nullptr;
@@ -1190,6 +1226,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
   pool_return_pinned_word(h->device, h->finish_word);
   pool_free(h->device, h->grids_owned);
   pool_free(h->device, h->bricks_owned);
+  pool_free(h->device, h->bricks11_owned);
   pool_free(h->device, h->vals_owned);
   delete h;
 }
@@ -1209,12 +1246,30 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   g.last_binned = 0;
   if (g.cfg.binned == 0 || g.method != kCubic || !g.bricks || g.cfg.force_generic) return -1;
   if (g.ndims < 2 || g.ndims > 4) return -1;
+  // The table the sorted points are evaluated on: the handle's own when it is the fully
+  // overlapped one (or the evaluation is forced), else the second, fully overlapped table 4-D
+  // handles keep for this purpose (maybe_build_cubic_tiles).
+  const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
+  const bool second = !main11 && g.bricks11 != nullptr;
   if (g.cfg.binned < 0) {
     if (g.ndims != 4 || npoints < ((size_t)3 << 18)) return -1;
-    unsigned nb[2];
-    size_t table = 0;
-    cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &table);
-    if (table <= ((size_t)8 << 20)) return -1;  // an L2-sized table is gathered at the hit rate anyway
+    if (!main11 && !second) return -1;
+    if (main11) {
+      unsigned nb[2];
+      size_t table = 0;
+      cubic_tile_geometry(g, 1, 1, nb, &table);
+      if (table <= ((size_t)8 << 20)) return -1;  // an L2-sized table is gathered at the hit rate anyway
+    }
+  }
+  GridDesc second_desc;
+  const GridDesc* use = &g;
+  if (second) {
+    second_desc = g;
+    second_desc.bricks = g.bricks11;
+    second_desc.brick_step[0] = second_desc.brick_step[1] = 1;
+    second_desc.brick_nb[0] = g.bricks11_nb[0];
+    second_desc.brick_nb[1] = g.bricks11_nb[1];
+    use = &second_desc;
   }
   BinPlan plan;
   if (!make_bin_plan(g, &plan)) return -1;
@@ -1249,12 +1304,13 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     HIP_TRY(bin_points(g, plan, src, count, h->bin_scratch, sorted, &index, stream));
     char* dst = static_cast<char*>(out) + begin * elem;
     if (g.dtype == kF64)
-      HIP_TRY(launch_cubic_brick<double>(g, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
+      HIP_TRY(launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
                                          h->first_bad, stream, index, begin));
     else
-      HIP_TRY(launch_cubic_brick<float>(g, reinterpret_cast<const float* const*>(sorted), reinterpret_cast<float*>(dst), count,
+      HIP_TRY(launch_cubic_brick<float>(*use, reinterpret_cast<const float* const*>(sorted), reinterpret_cast<float*>(dst), count,
                                         h->first_bad, stream, index, begin));
   }
+  g.tag = use->tag;
   HIP_TRY(hipEventRecord(h->bin_event, stream));
   h->bin_event_recorded = true;
   g.last_binned = 1;

@@ -90,6 +90,10 @@ struct GridDesc {
   double rec1_scale = 0.0;
   int brick_step[2] = {2, 2};
   unsigned brick_nb[4] = {0, 0, 0, 0};
+  // 4-D multicubic whose `bricks` is not the fully overlapped layout: a second, fully overlapped
+  // tile table that large batches are evaluated on after sorting (binned evaluation); else null.
+  const void* bricks11 = nullptr;
+  unsigned bricks11_nb[2] = {0, 0};
   int brick_cell = 0;
   // check_bounds limits per dimension, in the element type's arithmetic
   // (multilinear/regular.rs:160-166: starts + steps*(dims-1), min/max; rectilinear.rs:121-123).

@@ -1350,3 +1350,36 @@ def test_linear_1d_rectilinear_records(oracle, monkeypatch, dtype, fma, axis):
         assert name.startswith("interpn::k_linear_rectilinear<"), name
     elif axis != "dense_pairs":
         assert name.startswith("interpn::k_linear1_records<"), name
+
+
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
+    """4-D multicubic grids whose in-place layout is not the fully overlapped one (20^4: an
+    L2-friendly layout serves small batches) also keep the fully overlapped tile table; batches of
+    786 432 points and more are counting-sorted and evaluated on it (LDS-DMA gather), smaller ones
+    run in place on the first table — both must give the oracle's bits.
+    multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    axis = [20, 20, 20, 20]
+    case = synthetic_case("cubic", kind, 4, axis, 800_003, 9700, np.float64, linearize=True, extrap=0.1, specials=True)
+    want = run_oracle(oracle, case, True)
+    it = _make_interp(interpn_amd, case)
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    got = it.eval_tensors(obs).cpu().numpy()
+    it.finish()
+    assert np.array_equal(got, want)
+    _, si, sj = it.table_layout()
+    if kind == "regular":
+        assert (si, sj) != (1, 1)                       # the in-place table is another layout ...
+        assert it.get_option("last_binned") == 1        # ... and this batch ran sorted on the second one
+        assert it.kernel_name().endswith(", 1, 1>"), it.kernel_name()
+    small = [o[:100_000] for o in obs]
+    got_small = it.eval_tensors(small).cpu().numpy()
+    it.finish()
+    assert it.get_option("last_binned") == 0
+    assert np.array_equal(got_small, want[:100_000])
+    it.close()
