@@ -49,10 +49,16 @@ constexpr int kCubRow = 18;  // elements per LDS row (16 used; 18 keeps 16-B ali
 
 // Which instantiations gather by LDS-DMA (gather_plane_dma), and the LDS bytes a workgroup's
 // gathers need (rectilinear axes are staged behind them).
-template <typename T, int SI, int SJ> constexpr bool cubic_dma() { return sizeof(T) == 8 && SI == 1 && SJ == 1; }
+template <typename T, int SI, int SJ> constexpr bool cubic_dma() { return SI == 1 && SJ == 1; }
+// A tile is 16 elements = sizeof(T) 16-byte pieces; a wave's image holds its 64 tiles.
+template <typename T> constexpr unsigned cubic_dma_image() { return 64u * (unsigned)sizeof(T) * 16u; }
 template <typename T, int SI, int SJ> constexpr size_t cubic_lds_region() {
-  if (cubic_dma<T, SI, SJ>()) return (size_t)(kBlock / 64) * 8192;  // one 8-KiB tile image per wave
+  if (cubic_dma<T, SI, SJ>()) return (size_t)(kBlock / 64) * cubic_dma_image<T>();  // one tile image per wave (8 KiB f64, 4 KiB f32)
   return (size_t)kBlock * kCubRow * (sizeof(T) > 4 ? sizeof(T) : 4);
+}
+// rotation of a point's pieces inside its slots (conflict-free ds_read_b128, see gather comment)
+template <typename T> __device__ __forceinline__ unsigned cubic_dma_rot(unsigned p) {
+  return sizeof(T) == 8 ? ((p >> 1) & 7u) : ((p >> 2) & 3u);
 }
 
 // Table reads go through a raw buffer descriptor: the per-lane part of the address is a 32-bit
@@ -136,24 +142,24 @@ __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const u
   }
 }
 
-// f64, fully overlapped tiles (steps 1,1: a footprint is exactly ONE 128-byte tile): the plane's 64
-// tiles of a wave go from the table straight into LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`),
-// eight 1-KiB instructions instead of sixteen 8-byte gathers per lane plus sixteen ds_write: no
-// VGPR staging, no store traffic through the vector unit.  A DMA instruction writes lane L's 16
-// bytes at base + 16 L, so in instruction q lane L fetches the 16-byte piece that belongs at slot
-// 64 q + L of the wave's 8-KiB image, which is laid out point-major (point p = owner lane p, 8
-// slots each) with a point's pieces rotated by p >> 1: piece c sits in slot (c + (p >> 1)) & 7.
-// The rotation makes the readers conflict-free: the 16 lanes a ds_read_b128 services together
-// then hit 16 different 16-byte bank groups.  `dma_off[q]` = byte offset of that piece in the
-// table without the plane part (computed once per point from the owners' tile offsets with
-// ds_bpermute); the plane part `delta` is the instruction's scalar offset; `lds_wave` = LDS byte
-// address of the wave's image (wave-uniform, in a scalar register).
+// Fully overlapped tiles (steps 1,1: a footprint is exactly ONE tile of 16 elements = PP = sizeof(T)
+// pieces of 16 bytes): the plane's 64 tiles of a wave go from the table straight into LDS by
+// LDS-DMA (`buffer_load_dwordx4 ... lds`), PP 1-KiB instructions instead of sixteen element gathers
+// per lane plus sixteen ds_write: no VGPR staging, no store traffic through the vector unit.  A
+// DMA instruction writes lane L's 16 bytes at base + 16 L, so in instruction q lane L fetches the
+// piece that belongs at slot 64 q + L of the wave's image, which is laid out point-major (point p
+// = owner lane p, PP slots each) with a point's pieces rotated: piece c sits in slot
+// (c + rot(p)) & (PP - 1), rot(p) = p >> 1 (f64) or p >> 2 (f32).  The rotation makes the readers
+// conflict-free: the 16 lanes a ds_read_b128 services together then hit 16 different 16-byte
+// bank groups.  `dma_off[q]` = byte offset of that piece in the table without the plane part
+// (computed once per point from the owners' tile offsets with ds_bpermute); the plane part
+// `delta` is the instruction's scalar offset; `lds_wave` = LDS byte address of the wave's image
+// (wave-uniform, in a scalar register).
 template <typename T>
 __device__ __forceinline__ void dma_issue_plane(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, unsigned delta, unsigned lds_wave) {
-  static_assert(sizeof(T) == 8, "LDS-DMA gather: f64 tiles");
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int q = 0; q < (int)sizeof(T); ++q)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(bricks, (lds_byte*)(size_t)(lds_wave + (unsigned)q * 1024u), 16, dma_off[q], delta, 0, 0);
 }
 
@@ -162,14 +168,17 @@ template <typename T>
 __device__ __forceinline__ void dma_take_tile(unsigned lds_wave, unsigned wl, T (&v)[16]) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
-  typedef T T2 __attribute__((ext_vector_type(2), may_alias));
-  typedef __attribute__((address_space(3))) const T2 lds_T2;
+  constexpr unsigned PP = (unsigned)sizeof(T);  // pieces per tile
+  constexpr int EP = 16 / (int)sizeof(T);      // elements per piece
+  typedef T TP __attribute__((ext_vector_type(EP), may_alias));
+  typedef __attribute__((address_space(3))) const TP lds_TP;
+  const unsigned rot = cubic_dma_rot<T>(wl);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned slot = wl * 8u + (((unsigned)c + (wl >> 1)) & 7u);
-    const T2 w = *(lds_T2*)(size_t)(lds_wave + slot * 16u);
-    v[2 * c] = w.x;
-    v[2 * c + 1] = w.y;
+  for (int c = 0; c < (int)PP; ++c) {
+    const unsigned slot = wl * PP + (((unsigned)c + rot) & (PP - 1u));
+    const TP w = *(lds_TP*)(size_t)(lds_wave + slot * 16u);
+#pragma unroll
+    for (int k = 0; k < EP; ++k) v[EP * c + k] = w[k];
   }
   // every lane must HAVE its tile (reads returned, not merely issued) before the next plane's
   // DMA — which the caller issues next, ahead of this plane's arithmetic — overwrites the image
@@ -201,7 +210,7 @@ __device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicD
 // All 4^(N-2) planes of a point, software-pipelined: the DMA of plane k+1 is issued as soon as
 // every lane has taken its tile of plane k out of the image, i.e. BEFORE plane k's nodes are
 // evaluated, so the table latency of the next plane hides behind the arithmetic of this one
-// with one 8-KiB image per wave and no extra registers (the tile is in registers anyway).
+// with one tile image per wave and no extra registers (the tile is in registers anyway).
 // Plane order and reduction tree are the reference's (dim 2 inside dim 3;
 // src/multicubic/regular.rs:368-421).
 template <typename T, int N, bool RECT, bool FMA>
@@ -289,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.bricks, a.table_bytes);
   // LDS byte address of this wave's tile image (LDS-DMA gather), in a scalar register
   const unsigned lds_wave = (unsigned)__builtin_amdgcn_readfirstlane(
-      (int)((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + (lane >> 6) * 8192u));
+      (int)((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + (lane >> 6) * cubic_dma_image<T>()));
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   const size_t per_xcd = (size_t)(gridDim.x >> 3) * kBlock;  // points one XCD's workgroups cover per iteration
   const size_t niter = a.eighth ? (a.eighth + per_xcd - 1) / per_xcd : (a.npts + nthreads - 1) / nthreads;
@@ -342,12 +351,13 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     if constexpr (DMA) {
       // my point's tile (steps 1,1: tile index = cell) as a byte offset; instruction q of a plane's
       // DMA has me fetch piece c of point p (gather_plane_dma)
+      constexpr unsigned PP = (unsigned)sizeof(T);  // 16-byte pieces per tile; 64 / PP points per DMA instruction
       const unsigned wl = lane & 63u;
       const unsigned tb = (pbase + (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const unsigned p = (unsigned)q * 8u + (wl >> 3);
-        const unsigned c = ((wl & 7u) - (p >> 1)) & 7u;
+      for (int q = 0; q < (int)PP; ++q) {
+        const unsigned p = ((unsigned)q * 64u + wl) / PP;
+        const unsigned c = ((wl & (PP - 1u)) - cubic_dma_rot<T>(p)) & (PP - 1u);
         toff[q] = (unsigned)__shfl((int)tb, (int)p) + c * 16u;
       }
     } else {

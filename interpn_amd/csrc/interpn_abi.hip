@@ -486,11 +486,12 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   HIP_TRY(build_cubic_tiles(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   g.bricks = h->bricks_owned;
-  // 4-D grids in the band where an L2-friendly layout wins for small batches (20^4 .. 26^4 in f64)
-  // also keep the fully overlapped table: large batches are evaluated binned on it
-  // (eval_device_binned; 24^4 at 1e7 points: 1.38 against 1.79 ms, at 1e6: 0.154 against 0.204).
+  // 4-D grids in the band where an L2-friendly layout wins for small batches (20^4 .. 26^4 in f64,
+  // 20^4 .. 30^4 in f32) also keep the fully overlapped table: large batches are evaluated binned
+  // on it (eval_device_binned; f64 24^4 at 1e7 points: 1.38 against 1.79 ms, at 1e6: 0.154 against
+  // 0.204; f32 28^4: 0.96 against 1.46 ms).
   g.bricks11 = nullptr;
-  if (!forced && g.ndims == 4 && best != 4 && fits11 && bytes11 > ((size_t)8 << 20)) {
+  if (!forced && g.ndims == 4 && best != 4 && fits11) {
     if (pool_alloc(h->device, &h->bricks11_owned, bytes11) == hipSuccess) {
       GridDesc t = g;
       t.brick_step[0] = t.brick_step[1] = 1;

@@ -73,8 +73,8 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
     a.plane_stride[d] = acc;
     acc *= (unsigned)g.n[d];
   }
-  const bool dma = sizeof(T) == 8 && g.brick_step[0] == 1 && g.brick_step[1] == 1;  // cubic_brick.h::cubic_dma
-  size_t lds = dma ? (size_t)(kBlock / 64) * 8192 : (size_t)kBlock * kCubRow * (sizeof(T) > 4 ? sizeof(T) : 4);
+  const bool dma = g.brick_step[0] == 1 && g.brick_step[1] == 1;  // cubic_brick.h::cubic_dma
+  size_t lds = dma ? (size_t)(kBlock / 64) * cubic_dma_image<T>() : (size_t)kBlock * kCubRow * (sizeof(T) > 4 ? sizeof(T) : 4);
   a.ax.use_lds = 0;
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
