@@ -6,12 +6,19 @@
 // (DESIGN.md section 4).  Here the handle keeps a copy of the grid in which the FIRST TWO dimensions
 // (i, j) — the ones the reference reduces first — are cut into 4 x 4 tiles (128 B in f64), stepped
 // 4, 2 or 1 (overlapping tiles = duplicated rows/columns) so that a 4 x 4 footprint spans 3.06,
-// 2.25 ... 1 tiles; the remaining dimensions index whole tiled planes.  The 16 lanes of a group
-// fetch the 16 elements of ONE point's (i, j) footprint per load instruction (elements on one
-// line become one L2 request), 16 instructions cover the group's 16 points, the 16 x 16 element
-// matrix is transposed through LDS, and every lane reduces its own footprint: dim 0, then dim 1,
-// then the plane dimensions in order — the reference's tree (src/multicubic/regular.rs:368-421),
-// so results are bit-identical to the C-order kernels.
+// 2.25 ... 1 tiles; the remaining dimensions index whole tiled planes.  Two gathers:
+//   * fully overlapped tiles (steps 1,1; a footprint = exactly one tile): the 64 tiles a wave needs
+//     from a plane go from the table straight into LDS by LDS-DMA, in an image laid out so that
+//     every lane then reads its own tile back without bank conflicts; the planes of a point are
+//     software-pipelined (gather_plane / reduce_planes_dma below).  This is the form the large-grid
+//     and the binned (sorted-points) evaluations run: cfg4 1.04 ms per 1e7 points on sorted points.
+//   * other steps: the 16 lanes of a group fetch the 16 elements of ONE point's (i, j) footprint
+//     per load instruction (elements on one line become one L2 request), 16 instructions cover the
+//     group's 16 points, the 16 x 16 element matrix is transposed through LDS.
+// Either way every lane reduces its own footprint: dim 0, then dim 1, then the plane dimensions in
+// order — the reference's tree (src/multicubic/regular.rs:368-421) — so results are bit-identical
+// to the C-order kernels.  Table reads are raw buffer loads (32-bit byte offset per lane, plane
+// offset in the scalar operand): no vector address arithmetic, range-checked.
 #pragma once
 #include "rect_args.h"
 
