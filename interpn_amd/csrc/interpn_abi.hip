@@ -1238,7 +1238,7 @@ namespace {
 // Returns -1 when the path does not apply or cannot be taken right now (the caller then launches
 // the kernel on the points as they are), otherwise a status.  Chosen automatically for 4-D grids
 // whose tile table is far beyond the L2 and batches large enough to pay for the three sorting
-// launches (cfg4: 2.8 -> 1.85 ms per 1e7 points; from about 8e5 points on; 3-D grids lose: 4 lines
+// launches (cfg4: 2.8 -> 1.85 ms per 1e7 points; from about 5e5 points on; 3-D grids lose: 4 lines
 // per point are cheaper than sorting them); `binned` = 1 forces it for N = 2..4 (tests),
 // 0 turns it off.  Not taken while the stream is being captured into a graph (it may have to
 // allocate) or while another thread is inside it with the same handle.
@@ -1253,7 +1253,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
   const bool second = !main11 && g.bricks11 != nullptr;
   if (g.cfg.binned < 0) {
-    if (g.ndims != 4 || npoints < ((size_t)3 << 18)) return -1;
+    if (g.ndims != 4 || npoints < ((size_t)1 << 19)) return -1;
     if (!main11 && !second) return -1;
     if (main11) {
       unsigned nb[2];

@@ -79,9 +79,12 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
-  const unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  unsigned blocks = grid_blocks(npts, 1, g.cfg);
   a.eighth = 0;
-  if (scatter && g.cfg.deal && blocks >= 64 && blocks % 8 == 0) a.eighth = ((npts + 7) / 8 + kBlock - 1) / kBlock * kBlock;
+  if (scatter && g.cfg.deal && blocks >= 64) {
+    blocks &= ~7u;  // eight equal XCD shares; the grid-stride loop covers what the rounding drops
+    a.eighth = ((npts + 7) / 8 + kBlock - 1) / kBlock * kBlock;
+  }
   if (g.kind == kRegular)
     return g.fma ? launch_steps<T, N, false, true>(g, a, lds, blocks, stream)
                  : launch_steps<T, N, false, false>(g, a, lds, blocks, stream);

@@ -1356,7 +1356,7 @@ def test_linear_1d_rectilinear_records(oracle, monkeypatch, dtype, fma, axis):
 def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
     """4-D multicubic grids whose in-place layout is not the fully overlapped one (20^4: an
     L2-friendly layout serves small batches) also keep the fully overlapped tile table; batches of
-    786 432 points and more are counting-sorted and evaluated on it (LDS-DMA gather), smaller ones
+    524 288 points and more are counting-sorted and evaluated on it (LDS-DMA gather), smaller ones
     run in place on the first table — both must give the oracle's bits.
     multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
     import torch
