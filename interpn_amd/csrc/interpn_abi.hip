@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -934,6 +935,25 @@ hipError_t launch_any(const GridDesc& g, const void* const* obs, void* out, size
 // (8 dims x 8 B x 4 Mi = 256 MiB worst case) while each kernel launch still fills the chip.
 constexpr size_t kHostChunkPoints = (size_t)4 << 20;
 
+// Completion of an 8-byte device-to-pinned-host copy, by watching the landing word instead of
+// calling hipStreamSynchronize: the caller stores kWordPending into *word, enqueues the copy on
+// `s`, then calls this.  The copy is ordered behind everything enqueued on `s` before it, so once
+// the word has changed that work is complete (and its results visible: a kernel's stores are
+// released at its end, before the copy starts).  Spinning on a pinned, host-coherent word costs a
+// few microseconds less per call than the runtime's wait (small calls: 24 -> ~15 us); after
+// 200 us without an answer the runtime's wait takes over.
+constexpr unsigned long long kWordPending = 0xFFFFFFFFFFFFFFFEull;  // neither "no failure" (~0) nor an index
+hipError_t wait_status_word(hipStream_t s, const unsigned long long* word) {
+  const volatile unsigned long long* w = word;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    if (*w != kWordPending) return hipSuccess;
+    __builtin_ia32_pause();
+    if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+  }
+  return hipStreamSynchronize(s);
+}
+
 int ensure_lane(interpn_hip_interp* h, int which, size_t points) {
   interpn_hip_interp::HostLane& l = h->lane[which];
   if (l.points >= points && l.obs) return INTERPN_HIP_OK;
@@ -1351,9 +1371,10 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   // The status word lands in pinned memory: a plain DMA behind the kernel, no staging copy.
   std::lock_guard<std::mutex> lk(h->finish_mu);
   if (!h->finish_word) HIP_TRY(pool_take_pinned_word(h->device, &h->finish_word));
+  *(volatile unsigned long long*)h->finish_word = kWordPending;
   HIP_TRY(hipMemcpyAsync(h->finish_word, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  const unsigned long long word = *h->finish_word;
+  HIP_TRY(wait_status_word(s, h->finish_word));
+  const unsigned long long word = *(volatile unsigned long long*)h->finish_word;
   if (word == kNoBadIndexHost) return INTERPN_HIP_OK;
   HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(word), s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1479,9 +1500,10 @@ static int eval_host_small(interpn_hip_interp* h, const void* const* obs, void* 
   char* host_out = (char*)h->small_host + (size_t)8 * stride;
   void* dev_out = (char*)h->small_dev + (size_t)8 * stride;
   HIP_TRY(launch_any(h->desc, dev_obs, dev_out, nout, l.flag_dev, l.stream));
+  *(volatile unsigned long long*)l.flag_host = kWordPending;
   HIP_TRY(hipMemcpyAsync(l.flag_host, l.flag_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream));
-  HIP_TRY(hipStreamSynchronize(l.stream));
-  const unsigned long long bad = *l.flag_host;
+  HIP_TRY(wait_status_word(l.stream, l.flag_host));
+  const unsigned long long bad = *(volatile unsigned long long*)l.flag_host;
   size_t good = nout;
   if (bad != kNoBadIndexHost) {
     HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));
