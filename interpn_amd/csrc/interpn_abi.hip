@@ -938,10 +938,11 @@ constexpr size_t kHostChunkPoints = (size_t)4 << 20;
 // Completion of an 8-byte device-to-pinned-host copy, by watching the landing word instead of
 // calling hipStreamSynchronize: the caller stores kWordPending into *word, enqueues the copy on
 // `s`, then calls this.  The copy is ordered behind everything enqueued on `s` before it, so once
-// the word has changed that work is complete (and its results visible: a kernel's stores are
-// released at its end, before the copy starts).  Spinning on a pinned, host-coherent word costs a
-// few microseconds less per call than the runtime's wait (small calls: 24 -> ~15 us); after
-// 200 us without an answer the runtime's wait takes over.
+// the word has changed that work is complete ON THE DEVICE: results in device memory may be used
+// by anything enqueued afterwards.  It says nothing about data a kernel wrote into HOST memory
+// (the zero-copy small-batch path keeps the runtime's wait for that reason).  Spinning on a
+// pinned, host-coherent word costs a few microseconds less per call than the runtime's wait;
+// after 200 us without an answer the runtime's wait takes over.
 constexpr unsigned long long kWordPending = 0xFFFFFFFFFFFFFFFEull;  // neither "no failure" (~0) nor an index
 hipError_t wait_status_word(hipStream_t s, const unsigned long long* word) {
   const volatile unsigned long long* w = word;
@@ -1293,7 +1294,13 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     use = &second_desc;
   }
   BinPlan plan;
-  if (!make_bin_plan(g, &plan)) return -1;
+  {
+    unsigned nbt[2];
+    size_t tbytes = 0;  // of the table the sorted points will be evaluated on
+    if (second || main11) cubic_tile_geometry(g, 1, 1, nbt, &tbytes);
+    else cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nbt, &tbytes);
+    if (!make_bin_plan(g, tbytes, &plan)) return -1;
+  }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return -1; }
   if (cs != hipStreamCaptureStatusNone) return -1;
@@ -1500,10 +1507,13 @@ static int eval_host_small(interpn_hip_interp* h, const void* const* obs, void* 
   char* host_out = (char*)h->small_host + (size_t)8 * stride;
   void* dev_out = (char*)h->small_dev + (size_t)8 * stride;
   HIP_TRY(launch_any(h->desc, dev_obs, dev_out, nout, l.flag_dev, l.stream));
-  *(volatile unsigned long long*)l.flag_host = kWordPending;
   HIP_TRY(hipMemcpyAsync(l.flag_host, l.flag_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream));
-  HIP_TRY(wait_status_word(l.stream, l.flag_host));
-  const unsigned long long bad = *(volatile unsigned long long*)l.flag_host;
+  // The runtime's wait, not wait_status_word: here the RESULTS are written by the kernel straight
+  // into pinned host memory, and the status word landing (a copy-engine write) does not order
+  // those shader writes for the CPU — watching the word alone returned stale results once in
+  // 37 739 fuzz cases.
+  HIP_TRY(hipStreamSynchronize(l.stream));
+  const unsigned long long bad = *l.flag_host;
   size_t good = nout;
   if (bad != kNoBadIndexHost) {
     HIP_TRY(hipMemsetAsync(l.flag_dev, 0xFF, sizeof(unsigned long long), l.stream));

@@ -193,9 +193,9 @@ struct BinPlan {
   double start[2] = {0, 0};
   double scale[2] = {0, 0};  // cell ~ floor((x - start) * scale) - 1
 };
-constexpr int kMaxBins = 256;  // a key fits one byte; 841 exact tile positions (cfg4) evaluated no faster than 225 bins
+constexpr int kMaxBins = 1024;  // one bin per thread of the scatter kernel's scan; 16-bit keys
 constexpr size_t kBinSlicePoints = (size_t)1 << 25;  // points sorted and evaluated per slice (bounds the scratch)
-bool make_bin_plan(const GridDesc& g, BinPlan* plan);
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan);
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points);
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
 // original indices (within the slice).

@@ -94,19 +94,19 @@ struct ScatterArgs {
 // Scatter with the chunk sorted in LDS first, so that consecutive lanes write consecutive
 // positions of a bin's run.  1024 threads per workgroup and all of a thread's loads issued before
 // the first is used: with 256 threads and one load in flight per lane the kernel was bound by
-// memory latency (0.57..0.73 ms per 1e7 4-D points).  kMaxBins <= 256 keeps a key in one byte.
+// memory latency (0.57..0.73 ms per 1e7 4-D points).
 constexpr int kScatThreads = 1024;
 constexpr int kScatIters = (int)(kBinChunk / kScatThreads);
 
 template <typename T, int N>
 __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<T, N> a) {
-  static_assert(kMaxBins <= 256 && kBinChunk <= 65536, "keys are bytes, local indices 16-bit");
+  static_assert(kMaxBins <= kScatThreads && kMaxBins <= 65536 && kBinChunk <= 65536, "one bin per thread in the scan; keys and local indices are 16-bit");
   __shared__ unsigned fill[kMaxBins];
   __shared__ unsigned lstart[kMaxBins];   // first local position of a bin inside this chunk
   __shared__ unsigned base[kMaxBins];     // first global position of this chunk's run in a bin
-  __shared__ unsigned char keys[kBinChunk];        // key of local point l
+  __shared__ unsigned short keys[kBinChunk];       // key of local point l
   __shared__ unsigned short sorted_src[kBinChunk]; // local point at sorted position j
-  __shared__ unsigned char sorted_key[kBinChunk];
+  __shared__ unsigned short sorted_key[kBinChunk];
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
   if (tid < kMaxBins) fill[tid] = 0;
@@ -126,13 +126,13 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
       const unsigned l = (unsigned)it * kScatThreads + tid;
       if (l < count) {
         const int key = bin_key<T>(a.p, x0[it], x1[it]);
-        keys[l] = (unsigned char)key;
+        keys[l] = (unsigned short)key;
         atomicAdd(&fill[key], 1u);
       }
     }
   }
   __syncthreads();
-  // exclusive scan of the (<= 256) bin counts: one bin per thread of the first 256, Hillis-Steele
+  // exclusive scan of the bin counts: one bin per thread, Hillis-Steele
   const unsigned mine = tid < kMaxBins ? fill[tid] : 0u;
   if (tid < kMaxBins) lstart[tid] = mine;
   __syncthreads();
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
       const unsigned key = keys[l];
       const unsigned lpos = lstart[key] + atomicAdd(&fill[key], 1u);
       sorted_src[lpos] = (unsigned short)l;
-      sorted_key[lpos] = (unsigned char)key;
+      sorted_key[lpos] = (unsigned short)key;
     }
   }
   __syncthreads();
@@ -220,7 +220,7 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
 
 }  // namespace
 
-bool make_bin_plan(const GridDesc& g, BinPlan* plan) {
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan) {
   if (g.method != kCubic || g.ndims < 2) return false;
   BinPlan p;
   for (int d = 0; d < 2; ++d) {
@@ -237,8 +237,13 @@ bool make_bin_plan(const GridDesc& g, BinPlan* plan) {
     }
     if (!(p.scale[d] > 0) || !(p.scale[d] < 1e300)) return false;
   }
+  // Bins sized so that one bin's share of the table is about half a MiB (the workgroups an XCD has
+  // in flight then share an L2-sized piece of it): 32^4 f64 (113 MiB) -> 225 bins, 48^4 (597 MiB)
+  // -> 529; never fewer than 64 (balance across the XCDs), never more than kMaxBins.
+  long long target = (long long)(table_bytes >> 19);
+  target = target < 64 ? 64 : (target > kMaxBins ? kMaxBins : target);
   auto bins = [&](int d) { return ((p.ncell[d] - 1) >> p.shift[d]) + 1; };
-  while ((long long)bins(0) * bins(1) > kMaxBins) {
+  while ((long long)bins(0) * bins(1) > target) {
     if (bins(0) >= bins(1)) ++p.shift[0];
     else ++p.shift[1];
   }
