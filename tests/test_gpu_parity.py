@@ -1352,8 +1352,9 @@ def test_linear_1d_rectilinear_records(oracle, monkeypatch, dtype, fma, axis):
         assert name.startswith("interpn::k_linear1_records<"), name
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
-def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
+def test_cubic_4d_second_table_for_binned_batches(oracle, kind, dtype):
     """4-D multicubic grids whose in-place layout is not the fully overlapped one (20^4: an
     L2-friendly layout serves small batches) also keep the fully overlapped tile table; batches of
     524 288 points and more are counting-sorted and evaluated on it (LDS-DMA gather), smaller ones
@@ -1364,8 +1365,8 @@ def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
     import interpn_amd
 
     dev = torch.device("cuda:0")
-    axis = [20, 20, 20, 20]
-    case = synthetic_case("cubic", kind, 4, axis, 800_003, 9700, np.float64, linearize=True, extrap=0.1, specials=True)
+    axis = [20, 20, 20, 20] if dtype == np.float64 else [24, 24, 24, 24]
+    case = synthetic_case("cubic", kind, 4, axis, 800_003, 9700, dtype, linearize=True, extrap=0.1, specials=True)
     want = run_oracle(oracle, case, True)
     it = _make_interp(interpn_amd, case)
     obs = [torch.from_numpy(o).to(dev) for o in case.obs]
@@ -1373,7 +1374,7 @@ def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
     it.finish()
     assert np.array_equal(got, want)
     _, si, sj = it.table_layout()
-    if kind == "regular":
+    if kind == "regular" or dtype == np.float32:
         assert (si, sj) != (1, 1)                       # the in-place table is another layout ...
         assert it.get_option("last_binned") == 1        # ... and this batch ran sorted on the second one
         assert it.kernel_name().endswith(", 1, 1>"), it.kernel_name()
@@ -1382,4 +1383,44 @@ def test_cubic_4d_second_table_for_binned_batches(oracle, kind):
     it.finish()
     assert it.get_option("last_binned") == 0
     assert np.array_equal(got_small, want[:100_000])
+    it.close()
+
+
+def test_binned_evaluation_across_slices(oracle, monkeypatch):
+    """Binned evaluation sorts and evaluates at most 2^25 points at a time (bounded scratch): a
+    batch of 2^25 + 12 345 points spans two slices — the second one a ragged handful — and must
+    equal the in-place evaluation bit for bit; 2e5 sampled points are checked against the oracle,
+    and a NaN planted in the SECOND slice is reported with its batch-wide index."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    P = (1 << 25) + 12_345
+    case = synthetic_case("cubic", "regular", 4, [6, 5, 7, 6], 200_000, 9800, np.float32, linearize=False, extrap=0.1, specials=False)
+    it = _make_interp(interpn_amd, case)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    obs = [torch.rand(P, dtype=torch.float32, device=dev, generator=gen) * 2.2 - 1.1 for _ in range(4)]
+    it.set_option("binned", 0)
+    ref = it.eval_tensors(obs)
+    it.finish()
+    it.set_option("binned", 1)
+    out = it.eval_tensors(obs)
+    it.finish()
+    assert it.get_option("last_binned") == 1
+    assert bool(torch.equal(out, ref))
+    idx = torch.randint(0, P, (200_000,), device=dev, generator=gen)
+    idx[:1000] = torch.arange(P - 1000, P, device=dev)  # the tail slice
+    sub = [o[idx].cpu().numpy() for o in obs]
+    want = np.zeros(200_000, dtype=np.float32)
+    oracle.cubic_regular(case.dims, case.starts, case.steps, case.vals, False, sub, want)
+    assert np.array_equal(out[idx].cpu().numpy(), want)
+    bad_at = (1 << 25) + 777
+    obs[1][bad_at] = float("nan")
+    it.eval_tensors(obs, out)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as err:
+        it.finish()
+    assert err.value.first_bad_index == bad_at
     it.close()
