@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--no-ablate", action="store_true", help="skip the stream-only / gather-only ablation (N = 1)")
     ap.add_argument("--no-cfg5", action="store_true", help="N > 1: skip the second block on the 128^3 grid (BASELINE configs[4])")
     ap.add_argument("--sustain-seconds", type=float, default=0.5)
+    ap.add_argument("--spinup-seconds", type=float, default=0.15,
+                    help="untimed launches in front of the W warm-up steps, until the GPU clocks have ramped (0 = none)")
     # Test aids for a 1-GPU box: run the multi-rank control flow with every rank on cuda:0 over
     # gloo (RCCL refuses two ranks on one device).  The driver never passes these.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -481,6 +483,11 @@ def worker(args):
                 dist.broadcast(stage, src=0)
                 vals_dev.copy_(stage)
         it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
+        # Clock spin-up (untimed, every rank): the first ~25 launches after an idle period run 2-6 %
+        # slow while the GPU's clocks ramp (rocprofv3 kernel trace: 1.305, 1.292, 1.274 ... 1.226 ms),
+        # longer than the driver's W warm-up steps cover; the W steps and the K timed steps follow.
+        if args.spinup_seconds > 0:
+            time_launches(torch, it, obs, out, seconds=args.spinup_seconds)
         for _ in range(args.warmup):
             it.eval_tensors(obs, out)
             it.finish()
@@ -588,6 +595,7 @@ def worker(args):
                             f"({WORKLOADS[workload][1]}" + (f", {P * world:.0e} obs over {world} GPUs)" if world > 1 else ")"),
                 "points_per_gpu": P,
                 "grid": [n] * NDIMS,
+                "spinup_seconds": args.spinup_seconds,
                 "sharding": "obs sharded contiguously per rank; grid replicated by one RCCL broadcast; no collective in the loop",
                 "value_per_gpu": round(value / world, 1),
                 "backend": args.backend if world > 1 else None,
