@@ -360,6 +360,47 @@ static void nearest_regular_hat() {
   for (double x : obs) EXPECT(y[nearest_regular_index(x, 0.0, 1.0, y.size())] == interpolator.interp_one({x}).unwrap());
 }
 
+// src/nearest/rectilinear.rs:287-312 test_interp_extrap_2d_small
+static void nearest_rectilinear_2d_small() {
+  const std::size_t nx = 3, ny = 2;
+  const std::vector<double> x = linspace(-1.0, 1.0, nx), y = {0.5, 0.6};
+  const Table xy = meshgrid<double>({&x, &y});
+  std::vector<double> z(nx * ny);
+  for (std::size_t i = 0; i < nx * ny; ++i) z[i] = xy[i][0] + xy[i][1];
+  const std::vector<double> xobs = linspace(-10.0, 10.0, 5), yobs = linspace(-10.0, 10.0, 5);
+  const Table xyobs = meshgrid<double>({&xobs, &yobs});
+  auto interpolator = NearestRectilinear<double, 2>::new_({Slice<double>(x), Slice<double>(y)}, z).unwrap();
+  for (const auto& p : xyobs) {
+    const double zii = interpolator.interp_one({p[0], p[1]}).unwrap();
+    const double expected = x[nearest_rectilinear_index(p[0], x)] + y[nearest_rectilinear_index(p[1], y)];
+    EXPECT(std::fabs(expected - zii) < 1e-12);
+  }
+}
+
+// The struct form of the multicubic interpolators (multicubic/regular.rs:239-313,
+// rectilinear.rs:193-253): `new` + `interp` give what the dispatch function gives.
+static void multicubic_structs() {
+  const Table xs = test_axes(3, 5, nullptr);
+  const std::vector<double> u = field(meshgrid(refs(xs)), [](double x) { return x * x; });
+  const Table gridobs = meshgrid(refs(obs_axes(3, -7.0, 7.0, 7)));
+  const Table t = transpose(gridobs, 3);
+  std::vector<double> a(gridobs.size()), b(gridobs.size()), c(gridobs.size());
+  const std::vector<std::size_t> dims(3, 5);
+  std::vector<double> starts, steps;
+  for (const auto& x : xs) {
+    starts.push_back(x[0]);
+    steps.push_back(x[1] - x[0]);
+  }
+  multicubic::regular::interpn<double>(dims, starts, steps, u, true, slices(t), a).unwrap();
+  auto reg = MulticubicRegular<double, 3>::new_({5, 5, 5}, {starts[0], starts[1], starts[2]}, {steps[0], steps[1], steps[2]}, u, true).unwrap();
+  reg.interp({Slice<double>(t[0]), Slice<double>(t[1]), Slice<double>(t[2])}, b).unwrap();
+  EXPECT(a == b);
+  auto rect = MulticubicRectilinear<double, 3>::new_({Slice<double>(xs[0]), Slice<double>(xs[1]), Slice<double>(xs[2])}, u, true).unwrap();
+  rect.interp({Slice<double>(t[0]), Slice<double>(t[1]), Slice<double>(t[2])}, c).unwrap();
+  for (std::size_t i = 0; i < a.size(); ++i) EXPECT(std::fabs(a[i] - c[i]) < 1e-10);  // regular and rectilinear forms of one grid
+  EXPECT(std::fabs(reg.interp_one({gridobs[10][0], gridobs[10][1], gridobs[10][2]}).unwrap() - a[10]) == 0.0);
+}
+
 // src/nearest/rectilinear.rs:319-371 test_interp_extrap_1d_to_6d
 static void nearest_rectilinear_extrap() {
   Rng rng{0x6};
@@ -522,6 +563,8 @@ int main() {
   run("multicubic::rectilinear test_interp_1d_to_3d_sine", multicubic_rectilinear_sine);
   run("nearest::regular test_interp_extrap_1d_to_6d", nearest_regular_extrap);
   run("nearest::regular test_interp_hat_func", nearest_regular_hat);
+  run("nearest::rectilinear test_interp_extrap_2d_small", nearest_rectilinear_2d_small);
+  run("multicubic structs: new + interp + interp_one", multicubic_structs);
   run("nearest::rectilinear test_interp_extrap_1d_to_6d", nearest_rectilinear_extrap);
   run("nearest::rectilinear test_interp_hat_func", nearest_rectilinear_hat);
   run("lib.rs doctests (constant field)", lib_doctests);

@@ -50,4 +50,4 @@ def test_reference_rust_tests_through_the_cpp_mirror(tmp_path):
     res = subprocess.run([build(tmp_path)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ALL PASSED" in res.stdout and "FAIL" not in res.stdout
-    assert res.stdout.count("PASS ") == 18
+    assert res.stdout.count("PASS ") == 20
