@@ -245,6 +245,67 @@ def config_row(torch, interpn_amd, name, spec, obs, out, device, seconds, check_
     return row
 
 
+def cfg1_row(torch, interpn_amd, device):
+    """BASELINE configs[0]: 2-D multilinear::regular, 4x4 f64 grid, 1e3 obs — the reference's own
+    CPU-runnable plumbing case (src/multilinear/regular.rs:51-117, N = 2 arm).  Nothing here is
+    bandwidth: the row reports call latency of the host entry points (numpy in, numpy out), of the
+    device entry point, the single-thread CPU port on the same inputs, and a bitwise check of all
+    1e3 points through every one of them."""
+    from oracle import pyoracle
+
+    rng = np.random.default_rng(11)
+    n, P = 4, 1000
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n, n], np.full(2, -1.0), np.full(2, g[1] - g[0])
+    vals = rng.uniform(-1.0, 1.0, n * n)
+    obs = [rng.uniform(-1.05, 1.05, P) for _ in range(2)]  # ~5 % extrapolated
+    want = np.zeros(P)
+    pyoracle.linear_regular(dims, starts, steps, vals, obs, want)
+    t_cpu = float("inf")
+    tmp = np.zeros(P)
+    for _ in range(200):
+        t0 = time.perf_counter()
+        pyoracle.linear_regular(dims, starts, steps, vals, obs, tmp)
+        t_cpu = min(t_cpu, time.perf_counter() - t0)
+
+    def best_of(fn, reps=300):
+        best = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    got_oneshot = np.zeros(P)
+    one = lambda: interpn_amd.raw.interpn_linear_regular_f64(dims, starts, steps, vals, obs, got_oneshot)
+    one()
+    t_oneshot = best_of(one)
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals, False, device, np.float64)
+    got_handle = np.zeros(P)
+    t_handle = best_of(lambda: it.eval_host(obs, got_handle))
+    dev = torch.device("cuda", device)
+    obs_dev = [torch.from_numpy(o).to(dev) for o in obs]
+    out_dev = torch.empty(P, dtype=torch.float64, device=dev)
+
+    def dev_call():
+        it.eval_tensors(obs_dev, out_dev)
+        it.finish()
+
+    dev_call()
+    t_dev = best_of(dev_call)
+    ms = time_launches(torch, it, obs_dev, out_dev, launches=200)
+    row = {"config": "cfg1 2D multilinear::regular 4x4, 1e3 obs (BASELINE configs[0]: plumbing case, latency not bandwidth)",
+           "points": P, "grid": dims, "kernel": it.kernel_name(),
+           "call_us": {"one_shot_host_arrays": round(t_oneshot * 1e6, 1), "resident_handle_host_arrays": round(t_handle * 1e6, 1),
+                       "resident_handle_device_tensors_incl_status": round(t_dev * 1e6, 1),
+                       "kernel_only": round(float(np.median(ms)) * 1e3, 2)},
+           "cpu_port_us": round(t_cpu * 1e6, 2), "cpu_port_Mpoints_per_s": round(P / t_cpu / 1e6, 1),
+           "oracle_check": {"points": P, "bitwise_equal": bool(np.array_equal(got_oneshot, want) and np.array_equal(got_handle, want)
+                                                                 and np.array_equal(out_dev.cpu().numpy(), want))}}
+    it.close()
+    return row
+
+
 def cpu_baseline(spec, obs_dev, sample_points):
     """Time the CPU oracle (a port of the reference's algorithm; the Rust reference cannot be
     built here) single-threaded on a bounded sample of the same workload."""
@@ -393,6 +454,18 @@ def run_ablation(torch, spec, obs, out, it, seconds):
     return res
 
 
+def sharding_text(world, bcast):
+    """The record's description of the multi-GPU data path, generated from what this run did."""
+    head = ("obs sharded contiguously, one shard per rank" if world > 1 else
+            "single rank: the whole batch on one GPU")
+    if bcast is None:
+        return head + "; no process group, grid uploaded by the rank itself; no collective anywhere"
+    lib = "RCCL (nccl backend), device tensors" if bcast["backend"] == "nccl" else \
+          f"{bcast['backend']} backend, staged through the host"
+    return (f"{head}; grid replicated from rank 0 by one broadcast over {lib}, {bcast['ranks']} rank(s), "
+            f"{bcast['bytes']} bytes; no collective in the timed loop")
+
+
 # ---------------------------------------------------------------------------------------------
 def dry_run(args):
     """Spawn / rendezvous check without a GPU: what the launcher contract gives every rank."""
@@ -451,7 +524,7 @@ def worker(args):
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         world = dist.get_world_size()  # what the process group actually is
-    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    coll_dev = dev if (use_dist and dist.get_backend() == "nccl") else torch.device("cpu")
 
     P = args.points
     NDIMS = 3
@@ -475,13 +548,22 @@ def worker(args):
         vals_dev = torch.empty(n**NDIMS, dtype=torch.float64, device=dev)
         if rank == 0:
             vals_dev.copy_(torch.from_numpy(spec["vals"]))
+        bcast = None  # what really replicated the grid (the record reports this, not an intention)
         if use_dist:
-            if args.backend == "nccl":
+            torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            if dist.get_backend() == "nccl":
                 dist.broadcast(vals_dev, src=0)  # RCCL over xGMI, device to device
+                torch.cuda.synchronize()
+                where = "device"
             else:
                 stage = vals_dev.cpu()
                 dist.broadcast(stage, src=0)
                 vals_dev.copy_(stage)
+                where = "host"
+            bcast = {"collective": "broadcast", "backend": dist.get_backend(), "on": where, "src": 0,
+                     "ranks": dist.get_world_size(), "bytes": int(vals_dev.numel() * 8),
+                     "ms": round((time.perf_counter() - tb0) * 1e3, 3)}
         it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
         # Clock spin-up (untimed, every rank): the first ~25 launches after an idle period run 2-6 %
         # slow while the GPU's clocks ramp (rocprofv3 kernel trace: 1.305, 1.292, 1.274 ... 1.226 ms),
@@ -523,7 +605,7 @@ def worker(args):
             per_rank_ms = [float(x[0]) for x in gathered]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return {"elapsed": float(t[0]), "kernel_ms": float(t[1]), "per_rank_ms": per_rank_ms, "solo_ms": solo_ms,
-                "vals_dev": vals_dev}, it, spec
+                "vals_dev": vals_dev, "broadcast": bcast}, it, spec
 
     # The headline workload keeps ONE grid for every N (north_star: "throughput on synthetic random
     # obs over a fixed grid reported at 1/2/4/8 GPUs"): BASELINE configs[1]'s 64^3 grid, 1e8 obs per
@@ -543,7 +625,7 @@ def worker(args):
             a5 = P * bpp / (m5["kernel_ms"] * 1e-3) / 1e9
             second = {
                 "workload": f"3D multilinear::regular, 128^3 f64 grid, {P:.0e} random obs per GPU = {P * world:.0e} obs over "
-                            f"{world} GPUs (BASELINE configs[4]); grid replicated by one RCCL broadcast, obs sharded, no collective in the loop",
+                            f"{world} GPUs (BASELINE configs[4]); " + sharding_text(world, m5["broadcast"]),
                 "value": round(v5, 1), "unit": "Mpoints/s", "value_per_gpu": round(v5 / world, 1),
                 "ms_per_step": round(m5["elapsed"] / args.steps * 1e3, 4), "kernel": it5.kernel_name(),
                 "table_MiB": round(tb5 / 2**20, 2), "layout_steps": [si5, sj5],
@@ -596,9 +678,12 @@ def worker(args):
                 "points_per_gpu": P,
                 "grid": [n] * NDIMS,
                 "spinup_seconds": args.spinup_seconds,
-                "sharding": "obs sharded contiguously per rank; grid replicated by one RCCL broadcast; no collective in the loop",
+                "sharding": sharding_text(world, m["broadcast"]),
                 "value_per_gpu": round(value / world, 1),
-                "backend": args.backend if world > 1 else None,
+                "backend": dist.get_backend() if use_dist else None,
+                "process_group": {"initialised": True, "backend": dist.get_backend(), "world_size": dist.get_world_size()}
+                                 if use_dist else {"initialised": False},
+                "grid_broadcast": m["broadcast"],
                 "launched_by": "bench.py spawn" if os.environ.get("INTERPN_BENCH_SPAWNED") else
                                ("external launcher" if world > 1 else "single process"),
             },
@@ -653,6 +738,7 @@ def worker(args):
                 rows = []
                 secs = args.sustain_seconds
                 try:
+                    rows.append(cfg1_row(torch, interpn_amd, local_rank))
                     rows.append(config_row(torch, interpn_amd, "cfg2 3D multilinear::regular 64^3, 1e8 obs",
                                            build_spec("linear", "regular", 64, 3, False, 1), obs, out, local_rank, secs))
                     rows.append(config_row(torch, interpn_amd, "cfg3 3D multilinear::rectilinear non-uniform 64^3, 1e8 obs",

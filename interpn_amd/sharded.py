@@ -42,11 +42,23 @@ def broadcast_grid(vals, grids=None, src: int = 0):
     shape/dtype on every rank (on the rank's GPU for the nccl/RCCL backend).  Returns them."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    # Whenever a process group exists the collective is issued, also with a single rank: the RCCL
+    # call sequence a 1-GPU box can execute is then the one an 8-GPU node executes.
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(vals, src=src)
         for g in grids or []:
             dist.broadcast(g, src=src)
     return vals, grids
+
+
+def _collective_device(dist):
+    """Where tensors handed to the default group's collectives must live: the rank's GPU for
+    nccl (= RCCL on ROCm), the host otherwise."""
+    import torch
+
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 class ShardedInterpolator:
@@ -56,8 +68,15 @@ class ShardedInterpolator:
                  linearize_extrapolation=False, device=-1, dtype=np.float64, evaluator_factory=None):
         import torch.distributed as dist
 
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._grouped = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self._grouped else 0
+        self.world = dist.get_world_size() if self._grouped else 1
+        # Host-side assembly of `out` moves numpy shards: RCCL moves device memory only, so under
+        # the nccl backend a gloo group over the same ranks carries them (created here because
+        # new_group is itself a collective every rank must join).
+        self._host_group = None
+        if self._grouped and dist.get_backend() == "nccl":
+            self._host_group = dist.new_group(backend="gloo")
         self.method, self.kind = method, kind
         if evaluator_factory is None:
             from .handle import Interpolator
@@ -99,13 +118,12 @@ class ShardedInterpolator:
             msg = str(e)
         except Exception as e:  # noqa: BLE001 - every rank must still reach the collective below
             failure = e
-        if self.world > 1:
+        if self._grouped:
             # One MIN all-reduce of (-failed, first bad index): a rank that failed outright still
-            # takes part, so the others never hang in the collective; -1 wins the MIN.
-            t = torch.tensor([-1 if failure is not None else 0, local], dtype=torch.int64)
-            backend = dist.get_backend()
-            if backend == "nccl":
-                t = t.cuda()
+            # takes part, so the others never hang in the collective; -1 wins the MIN.  Issued
+            # with a single rank too (same call sequence at every world size).
+            t = torch.tensor([-1 if failure is not None else 0, local], dtype=torch.int64,
+                             device=_collective_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             any_failed, local = int(t[0].item()) < 0, int(t[1].item())
             if failure is None and any_failed:
@@ -124,12 +142,12 @@ class ShardedInterpolator:
         import torch.distributed as dist
 
         local = out_shard.detach().cpu() if hasattr(out_shard, "detach") else torch.from_numpy(np.asarray(out_shard))
-        if self.world == 1:
+        if not self._grouped:
             return local.numpy()
-        # Shards differ in size by one point and live on the host: ship them as objects through
-        # the process group's store (RCCL cannot move host tensors, gloo's gather wants equal sizes).
+        # Shards differ in size by one point and live on the host: ship them as objects over gloo
+        # (RCCL cannot move host memory, gloo's tensor gather wants equal sizes).
         parts = [None] * self.world if self.rank == dst else None
-        dist.gather_object(local.numpy(), parts, dst=dst)
+        dist.gather_object(local.numpy(), parts, dst=dst, group=self._host_group)
         if self.rank != dst:
             return None
         full = np.concatenate(parts)

@@ -766,6 +766,59 @@ def test_check_bounds_on_device_tensors(oracle, dtype):
             assert want[violate[0]]
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_cfg1_plumbing_case(oracle, dtype):
+    """BASELINE configs[0] as stated: 2-D multilinear::regular, 4x4 grid, 1e3 obs
+    (src/multilinear/regular.rs:51-117, the N = 2 arm) — through every entry point a caller of
+    that case can take: raw one-shot, `interpn()`, the class on host arrays, the resident handle on
+    host arrays and on device tensors.  ~5 % of the points extrapolate; exact nodes, domain ends
+    and +-0 are injected; a linear field is reproduced to 1e-12 like the reference's own test
+    (`regular.rs:438-477`); NaN aborts at the first bad point with the prefix written."""
+    import torch
+
+    import interpn_amd
+    from interpn_amd import raw
+
+    case = synthetic_case("linear", "regular", 2, [4, 4], 1000, 4242, dtype)
+    dims = [4, 4]
+    starts = np.array([g[0] for g in case.grids], dtype=dtype)
+    steps = np.array([g[1] - g[0] for g in case.grids], dtype=dtype)
+    want = run_oracle(oracle, case, True)
+    # raw one-shot
+    assert_parity(case, run_hip_raw(case), want)
+    # resident handle, host arrays and device tensors
+    it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, case.vals)
+    got = np.zeros(1000, dtype=dtype)
+    it.eval_host(case.obs, got)
+    assert_parity(case, got, want)
+    dev = torch.device("cuda:0")
+    out = it.eval_tensors([torch.from_numpy(o).to(dev) for o in case.obs])
+    it.finish()
+    assert_parity(case, out.cpu().numpy(), want)
+    # class + helper (what the reference's Python tests call)
+    cls = interpn_amd.MultilinearRegular.new(dims, starts, steps, case.vals)
+    assert_parity(case, cls.eval(case.obs), want)
+    helper = interpn_amd.interpn(obs=case.obs, grids=[np.asarray(g) for g in case.grids], vals=case.vals.reshape(4, 4),
+                                 method="linear", assume_regular=True)
+    assert_parity(case, np.asarray(helper).ravel(), want)
+    # the reference's own assertion for this arm: a field linear in the coordinates is reproduced
+    if dtype == np.float64:
+        mesh = np.stack(np.meshgrid(*case.grids, indexing="ij"), axis=-1).reshape(-1, 2)
+        lin = np.ascontiguousarray(mesh @ np.array([1.0, 1.0]))
+        got = np.zeros(1000)
+        raw.interpn_linear_regular_f64(dims, starts, steps, lin, case.obs, got)
+        assert np.max(np.abs(got - (case.obs[0] + case.obs[1]))) < 1e-12
+    # abort at the first bad point, prefix written, rest untouched (regular.rs:277-280, :418)
+    bad = [o.copy() for o in case.obs]
+    bad[1][617] = np.nan
+    got = np.full(1000, -7.0, dtype=dtype)
+    with pytest.raises(AssertionError, match="Unrepresentable coordinate value"):
+        getattr(raw, "interpn_linear_regular_" + ("f64" if dtype == np.float64 else "f32"))(
+            dims, starts, steps, case.vals, bad, got)
+    assert np.array_equal(got[:617], want[:617]) and np.all(got[617:] == -7.0)
+    it.close()
+
+
 def test_device_tensors_full_size_properties(oracle):
     """BASELINE config 2 at full size (3-D multilinear-regular, 64^3 grid, 1e8 obs) on device
     tensors: (a) a sampled subset is bit-identical to the oracle; (b) evaluating a sub-range
