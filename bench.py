@@ -565,6 +565,12 @@ def worker(args):
                      "ranks": dist.get_world_size(), "bytes": int(vals_dev.numel() * 8),
                      "ms": round((time.perf_counter() - tb0) * 1e3, 3)}
         it = make_interp(interpn_amd, spec, local_rank, vals=vals_dev)
+        # A first barrier BEFORE the untimed launches: the first collective of a process group pays
+        # RCCL's one-off set-up (tens of ms with the GPU idle, after which the clocks have dropped:
+        # profiles/r03_nccl_barrier_clock_ramp.txt shows the 30 launches behind such a barrier
+        # running 1.37 -> 1.25 ms); the barrier that brackets the timed region is then a warm one
+        # that every rank reaches within a step of the others.
+        barrier()
         # Clock spin-up (untimed, every rank): the first ~25 launches after an idle period run 2-6 %
         # slow while the GPU's clocks ramp (rocprofv3 kernel trace: 1.305, 1.292, 1.274 ... 1.226 ms),
         # longer than the driver's W warm-up steps cover; the W steps and the K timed steps follow.
@@ -573,21 +579,13 @@ def worker(args):
         for _ in range(args.warmup):
             it.eval_tensors(obs, out)
             it.finish()
-        # Same workload on ONE GPU with the others idle (rank 0 alone), so that the N-rank figure can
-        # be read against an identical single-GPU one taken in the same run.
-        solo_ms = None
-        if world > 1:
-            torch.cuda.synchronize()
-            barrier()
-            if rank == 0:
-                solo_ms = float(np.mean(time_launches(torch, it, obs, out, launches=max(20, min(args.steps, 200)),
-                                                      finish_each=True)))
-            barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         torch.cuda.synchronize()
+        tb0 = time.perf_counter()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        barrier_ms = (t0 - tb0) * 1e3  # GPU idle time in front of the first timed launch
         for k in range(args.steps):
             ev[k][0].record()
             it.eval_tensors(obs, out)
@@ -596,7 +594,17 @@ def worker(args):
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-        kernel_ms_local = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        step_ms = [a.elapsed_time(b) for a, b in ev]
+        kernel_ms_local = float(np.mean(step_ms))
+        # Same workload on ONE GPU with the others idle (rank 0 alone), so that the N-rank figure can
+        # be read against an identical single-GPU one taken in the same run.  AFTER the timed region:
+        # the ranks that idle at this barrier come back with cold clocks.
+        solo_ms = None
+        if world > 1:
+            if rank == 0:
+                solo_ms = float(np.mean(time_launches(torch, it, obs, out, launches=max(20, min(args.steps, 200)),
+                                                      finish_each=True)))
+            barrier()
         t = torch.tensor([elapsed, kernel_ms_local], dtype=torch.float64, device=coll_dev)
         per_rank_ms = [kernel_ms_local]
         if use_dist:
@@ -605,7 +613,8 @@ def worker(args):
             per_rank_ms = [float(x[0]) for x in gathered]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return {"elapsed": float(t[0]), "kernel_ms": float(t[1]), "per_rank_ms": per_rank_ms, "solo_ms": solo_ms,
-                "vals_dev": vals_dev, "broadcast": bcast}, it, spec
+                "vals_dev": vals_dev, "broadcast": bcast,
+                "step_ms": step_ms, "barrier_ms": barrier_ms}, it, spec
 
     # The headline workload keeps ONE grid for every N (north_star: "throughput on synthetic random
     # obs over a fixed grid reported at 1/2/4/8 GPUs"): BASELINE configs[1]'s 64^3 grid, 1e8 obs per
@@ -684,6 +693,7 @@ def worker(args):
                 "process_group": {"initialised": True, "backend": dist.get_backend(), "world_size": dist.get_world_size()}
                                  if use_dist else {"initialised": False},
                 "grid_broadcast": m["broadcast"],
+                "barrier_ms_before_timed_region": round(m["barrier_ms"], 3),
                 "launched_by": "bench.py spawn" if os.environ.get("INTERPN_BENCH_SPAWNED") else
                                ("external launcher" if world > 1 else "single process"),
             },
@@ -701,6 +711,9 @@ def worker(args):
                 "layout_steps": [si, sj],
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
+                "kernel_ms_min": round(float(np.min(m["step_ms"])), 4),
+                "kernel_ms_max": round(float(np.max(m["step_ms"])), 4),
+                "kernel_ms_first_steps": [round(x, 3) for x in m["step_ms"][:32]],
                 "algorithmic_bytes_per_point": bpp,
                 "measured_copy_GBps": round(copy_gbps, 1),
                 "frac_of_measured_copy": round(achieved / copy_gbps, 4),
