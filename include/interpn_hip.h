@@ -92,6 +92,12 @@ typedef enum interpn_hip_status {
 } interpn_hip_status;
 
 enum { INTERPN_HIP_LINEAR = 0, INTERPN_HIP_CUBIC = 1, INTERPN_HIP_NEAREST = 2 }; /* method */
+/* The reference's `fma` cargo feature (Cargo.toml:34-38) is a PER-INTERPOLATOR property here: OR one
+ * of these into the `method` argument of interpn_hip_create_* (neither = the process default, see
+ * interpn_hip_set_fma).  Handles of both flavours can be evaluated concurrently from different
+ * threads.  Also readable / writable as the per-handle option "fma" (not while evaluations of the
+ * same handle are being enqueued by another thread). */
+enum { INTERPN_HIP_FLAVOUR_FMA = 0x100, INTERPN_HIP_FLAVOUR_NO_FMA = 0x200 };
 enum { INTERPN_HIP_MEM_HOST = 0, INTERPN_HIP_MEM_DEVICE = 1 }; /* where a buffer lives */
 
 const char* interpn_hip_strerror(int status);
@@ -99,8 +105,10 @@ const char* interpn_hip_strerror(int status);
 const char* interpn_hip_last_hip_error(void);
 /* Library version "major.minor.patch". */
 const char* interpn_hip_version(void);
-/* Select the reference's `fma` feature flavour for interpolators created afterwards
- * (process-wide; default 1).  Returns the previous value. */
+/* DEPRECATED default-setter, kept for the one-shot entry points (whose signatures are the Rust
+ * functions' and have no place for a flavour — there it plays the role of the compile-time cargo
+ * feature): flavour of interpolators created afterwards WITHOUT an INTERPN_HIP_FLAVOUR_* flag
+ * (process-wide; default 1).  Returns the previous value.  Never changes an existing handle. */
 int interpn_hip_set_fma(int enabled);
 /* Number of visible HIP devices (0 when none; never fails). */
 int interpn_hip_device_count(void);
@@ -226,6 +234,35 @@ int interpn_hip_eval_host_sharded(interpn_hip_interp* const* handles, size_t nha
 int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out,
                             size_t npoints, void* stream);
 
+/* The same evaluation, telling the caller which path it took.
+ *   flags        INTERPN_HIP_EVAL_NO_ALLOC: never allocate (scratch that interpn_hip_reserve has
+ *                not provided is then a reason to evaluate in place, reported below).
+ *   *path_taken  INTERPN_HIP_PATH_IN_PLACE (one kernel on the points as given) or
+ *                INTERPN_HIP_PATH_BINNED (points counting-sorted first: 4 launches per slice).
+ *   *why         for IN_PLACE on a handle that could bin: the reason (INTERPN_HIP_WHY_*); else 0.
+ * Either pointer may be NULL.  The sorted path needs scratch (36 B per point of a slice for 4-D
+ * f64, slices of at most 2^25 points): one block per stream that uses the handle concurrently, at
+ * most 4; streams beyond that take turns through events.  After interpn_hip_reserve(h, n, k) no
+ * evaluation of at most n points on at most k streams allocates anything. */
+enum { INTERPN_HIP_PATH_IN_PLACE = 0, INTERPN_HIP_PATH_BINNED = 1 };
+enum { INTERPN_HIP_EVAL_NO_ALLOC = 1 };
+enum {
+  INTERPN_HIP_WHY_NONE = 0,          /* binned, or binning never applies to this handle */
+  INTERPN_HIP_WHY_SMALL_OR_OFF = 1,  /* batch below the break-even size, or option "binned" = 0 */
+  INTERPN_HIP_WHY_CAPTURE = 2,       /* `stream` is being captured into a graph */
+  INTERPN_HIP_WHY_NO_SCRATCH = 3,    /* no reserved scratch block is free / large enough and allocation was not allowed */
+  INTERPN_HIP_WHY_ALLOC_FAILED = 4   /* the scratch allocation failed */
+};
+int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out,
+                               size_t npoints, void* stream, unsigned flags, int* path_taken, int* why);
+
+/* Pre-allocate what device-pointer evaluations of up to `npoints` points on up to `nstreams`
+ * concurrent streams need (the sorted path's scratch blocks; nothing for handles that never
+ * sort).  Synchronous; may be called again with larger numbers.  Per-handle counters readable
+ * with interpn_hip_get_option: "evals_binned", "evals_in_place", "scratch_allocs",
+ * "scratch_bytes". */
+int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams);
+
 /* Wait for `stream` and report the sticky status of the device evaluations enqueued since the
  * last finish: 0, or INTERPN_HIP_ERR_UNREPRESENTABLE with the smallest failing point index
  * (relative to the evaluation it occurred in) in *first_bad_index.  Clears the sticky word. */
@@ -236,8 +273,10 @@ int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu);
 
 /* Per-handle tuning / testing options by name (the list is in the header comment above:
  * "blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic", "generic_runtime",
- * "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal"; read-only:
- * "last_binned" = 1 if the most recent device-pointer evaluation sorted its points first).  Their defaults are latched from the
+ * "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal", "bin_slice_log2" (points
+ * per sorted slice, 16..27, default 25: bounds a scratch block), "fma"; read-only: "last_binned" = 1
+ * if the most recent device-pointer evaluation sorted its points first, and the counters listed
+ * at interpn_hip_reserve).  Their defaults are latched from the
  * INTERPN_HIP_* environment variables when the handle is created.  INTERPN_HIP_ERR_INVALID_ARGUMENT
  * for an unknown name or a value out of range.  Not synchronised against evaluations running
  * concurrently on the same handle. */

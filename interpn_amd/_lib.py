@@ -24,6 +24,11 @@ ERR_INVALID_ARGUMENT = 32
 LINEAR, CUBIC, NEAREST = 0, 1, 2
 METHODS = {"linear": LINEAR, "cubic": CUBIC, "nearest": NEAREST}
 MEM_HOST, MEM_DEVICE = 0, 1
+FLAVOUR_FMA, FLAVOUR_NO_FMA = 0x100, 0x200  # OR-ed into `method` of interpn_hip_create_*
+PATH_IN_PLACE, PATH_BINNED = 0, 1
+EVAL_NO_ALLOC = 1
+WHY = {0: "", 1: "batch below the break-even size or option binned = 0", 2: "stream under graph capture",
+       3: "no reserved scratch block free and allocation not allowed", 4: "scratch allocation failed"}
 
 _lib = None
 
@@ -113,6 +118,9 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_eval_host_sharded.argtypes = [POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_size_t),
                                                   c_size_t, c_void_p, c_size_t, POINTER(c_uint64)]
     lib.interpn_hip_eval_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p]
+    lib.interpn_hip_eval_device_ex.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p,
+                                               ctypes.c_uint, POINTER(c_int), POINTER(c_int)]
+    lib.interpn_hip_reserve.argtypes = [c_void_p, c_size_t, c_int]
     lib.interpn_hip_check_bounds_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_size_t, ctypes.c_double,
                                                     POINTER(ctypes.c_uint8), c_size_t, c_void_p]
     lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]

@@ -71,14 +71,24 @@ template <typename T> __device__ __forceinline__ unsigned cubic_dma_rot(unsigned
 // Table reads go through a raw buffer descriptor: the per-lane part of the address is a 32-bit
 // BYTE offset computed once per point (toff), the plane part (delta) is wave-uniform and rides in
 // the instruction's scalar offset, so a gather costs no address arithmetic on the vector unit (the
-// flat form spent one 64-bit add per load: 256 of ~2500 VALU instructions of a 4-D point).  The
-// descriptor's range check (num_records = table bytes) makes an out-of-range offset read 0 instead
-// of faulting.  Tables are kept below 4 GiB (interpn_abi.hip::maybe_build_cubic_tiles).
+// flat form spent one 64-bit add per load: 256 of ~2500 VALU instructions of a 4-D point).
+// Bounds: on gfx9 raw buffers the descriptor's range check (num_records = table bytes) covers the
+// per-lane offset (voffset + instruction offset) ONLY; the wave-uniform plane offset passed as
+// soffset is added after the check.  An out-of-range `voff` therefore reads 0, but safety of
+// `voff + soff` rests on the offsets being right by construction (both are products of clamped
+// cell indices and the tile geometry the table was built with; dead lanes carry the offsets of a
+// valid point).  Builds with -DINTERPN_HIP_DEBUG_BOUNDS fold soff into the checked voff, so that a
+// layout bug reads zeros (and fails the parity tests) instead of a neighbouring allocation.
+// Tables are kept below 4 GiB (interpn_abi.hip::maybe_build_cubic_tiles).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 template <typename T>
 __device__ __forceinline__ T table_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef INTERPN_HIP_DEBUG_BOUNDS
+  voff += soff;
+  soff = 0;
+#endif
   if constexpr (sizeof(T) == 8) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);

@@ -322,11 +322,26 @@ struct interpn_hip_interp {
   // Binned evaluation (interpn_host.h): scratch for one slice of sorted points, shared by every
   // evaluation through this handle.  `bin_event` is recorded behind the last use; the next user
   // makes its stream wait for it, so two streams never work in the scratch at the same time.
+  // Up to kMaxBinSlots blocks, one per stream that evaluates concurrently: an evaluation takes
+  // the block its stream used last (stream order alone makes the reuse safe), else an idle one,
+  // else makes a new one (unless told not to allocate), else waits — on the device, through the
+  // block's event — for the least recently used one.  `bin_mu` guards the slot list and the
+  // per-handle report fields (desc.last_binned, desc.tag of a binned launch); the launches
+  // themselves are enqueued outside it.
+  static constexpr size_t kMaxBinSlots = 4;
+  struct BinSlot {
+    void* scratch = nullptr;
+    size_t bytes = 0;
+    hipEvent_t event = nullptr;
+    bool recorded = false;       // `event` has been recorded at least once
+    bool busy = false;           // a host thread is enqueueing into this block right now
+    hipStream_t last_stream = nullptr;
+    unsigned long long stamp = 0;  // use counter value of the last use (LRU)
+  };
   std::mutex bin_mu;
-  void* bin_scratch = nullptr;
-  size_t bin_scratch_bytes = 0;
-  hipEvent_t bin_event = nullptr;
-  bool bin_event_recorded = false;
+  std::vector<BinSlot> bin_slots;
+  unsigned long long bin_uses = 0;
+  std::atomic<long long> evals_binned{0}, evals_in_place{0}, scratch_allocs{0};
 };
 
 namespace {
@@ -660,6 +675,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"axis_lds_kb", &c.axis_lds_kb, -1, 60},
       {"binned", &c.binned, -1, 1},
       {"deal", &c.deal, 0, 1},
+      {"bin_slice_log2", &c.bin_slice_log2, 16, 27},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -687,7 +703,8 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 // The environment is read here, once per handle, and nowhere on the launch path.
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
-                                      "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal"};
+                                      "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
+                                      "bin_slice_log2"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -728,6 +745,9 @@ int create_regular(int method, const size_t* dims, size_t ndims, const T* starts
                    interpn_hip_interp** handle) {
   if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   *handle = nullptr;
+  const int flavour = method & (INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA);
+  if (flavour == (INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  method &= ~(INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA);
   if (method != kLinear && method != kCubic && method != kNearest) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   int st = validate_regular<T>(method, dims, ndims, starts, nstarts, steps, nsteps, nvals);
@@ -747,7 +767,7 @@ int create_regular(int method, const size_t* dims, size_t ndims, const T* starts
   g.dtype = sizeof(T) == 8 ? kF64 : kF32;
   g.ndims = (int)ndims;
   g.linearize = linearize ? 1 : 0;
-  g.fma = g_fma.load();
+  g.fma = flavour == INTERPN_HIP_FLAVOUR_FMA ? 1 : (flavour == INTERPN_HIP_FLAVOUR_NO_FMA ? 0 : g_fma.load());
   for (size_t i = 0; i < ndims; ++i) {
     g.n[i] = (int)dims[i];
     g.start[i] = (double)starts[i];
@@ -774,6 +794,9 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
                        size_t nvals, int vals_mem, int linearize, int device, interpn_hip_interp** handle) {
   if (!handle) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   *handle = nullptr;
+  const int flavour = method & (INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA);
+  if (flavour == (INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  method &= ~(INTERPN_HIP_FLAVOUR_FMA | INTERPN_HIP_FLAVOUR_NO_FMA);
   if (method != kLinear && method != kCubic && method != kNearest) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if (vals_mem != INTERPN_HIP_MEM_HOST && vals_mem != INTERPN_HIP_MEM_DEVICE) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   int st = validate_rectilinear<T>(method, grids, grid_lens, ngrids, nvals);
@@ -793,7 +816,7 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
   g.dtype = sizeof(T) == 8 ? kF64 : kF32;
   g.ndims = (int)ngrids;
   g.linearize = linearize ? 1 : 0;
-  g.fma = g_fma.load();
+  g.fma = flavour == INTERPN_HIP_FLAVOUR_FMA ? 1 : (flavour == INTERPN_HIP_FLAVOUR_NO_FMA ? 0 : g_fma.load());
   size_t total = 0;
   for (size_t i = 0; i < ngrids; ++i) {
     g.n[i] = (int)grid_lens[i];
@@ -949,7 +972,9 @@ hipError_t wait_status_word(hipStream_t s, const unsigned long long* word) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spin = 0;; ++spin) {
     if (*w != kWordPending) return hipSuccess;
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#endif
     if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
   }
   return hipStreamSynchronize(s);
@@ -1165,6 +1190,11 @@ int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
 
 int interpn_hip_set_option(interpn_hip_interp* h, const char* name, long long value) {
   if (!h || !name) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (!strcmp(name, "fma")) {  // the flavour is read at every launch; tables do not depend on it
+    if (value != 0 && value != 1) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+    h->desc.fma = (int)value;
+    return INTERPN_HIP_OK;
+  }
   return option_access(h->desc.cfg, name, &value, true) ? INTERPN_HIP_OK : INTERPN_HIP_ERR_INVALID_ARGUMENT;
 }
 
@@ -1172,6 +1202,18 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
   if (!h || !name || !value) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if (!strcmp(name, "last_binned")) {  // read-only: did the most recent device-pointer evaluation sort its points first?
     *value = h->desc.last_binned;
+    return INTERPN_HIP_OK;
+  }
+  if (!strcmp(name, "fma")) { *value = h->desc.fma; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "evals_binned")) { *value = h->evals_binned.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "scratch_bytes")) {
+    interpn_hip_interp* hm = const_cast<interpn_hip_interp*>(h);
+    std::lock_guard<std::mutex> lk(hm->bin_mu);
+    long long tot = 0;
+    for (const auto& sl : hm->bin_slots) tot += (long long)sl.bytes;
+    *value = tot;
     return INTERPN_HIP_OK;
   }
   LaunchConfig c = h->desc.cfg;
@@ -1242,8 +1284,10 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
     pool_free(h->device, l.out);
   }
   pool_return_small(h->device, h->small_host);
-  if (h->bin_event) (void)hipEventDestroy(h->bin_event);  // its stream was waited for above (marks)
-  pool_free(h->device, h->bin_scratch);
+  for (auto& sl : h->bin_slots) {  // their streams were waited for above (marks)
+    if (sl.event) (void)hipEventDestroy(sl.event);
+    pool_free(h->device, sl.scratch);
+  }
   pool_free(h->device, h->first_bad);
   pool_return_pinned_word(h->device, h->finish_word);
   pool_free(h->device, h->grids_owned);
@@ -1263,26 +1307,112 @@ namespace {
 // per point are cheaper than sorting them); `binned` = 1 forces it for N = 2..4 (tests),
 // 0 turns it off.  Not taken while the stream is being captured into a graph (it may have to
 // allocate) or while another thread is inside it with the same handle.
-int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out, size_t npoints, hipStream_t stream) {
-  GridDesc& g = h->desc;
-  g.last_binned = 0;
-  if (g.cfg.binned == 0 || g.method != kCubic || !g.bricks || g.cfg.force_generic) return -1;
-  if (g.ndims < 2 || g.ndims > 4) return -1;
+// Slice length of the sorted path (bounds one scratch block): option "bin_slice_log2".
+size_t bin_slice_points(const GridDesc& g) {
+  const int lg = g.cfg.bin_slice_log2 >= 16 && g.cfg.bin_slice_log2 <= 27 ? g.cfg.bin_slice_log2 : 25;
+  const size_t s = (size_t)1 << lg;
+  return s < kBinSlicePoints ? s : kBinSlicePoints;
+}
+
+// Does the sorted path apply to this handle at all / to a batch of `npoints`?  (No HIP calls.)
+// Returns 0 = never for this handle, 1 = not for this batch (too small / switched off), 2 = yes.
+int binned_applies(const GridDesc& g, size_t npoints) {
+  if (g.method != kCubic || !g.bricks || g.ndims < 2 || g.ndims > 4) return 0;
+  if (g.cfg.binned == 0 || g.cfg.force_generic) return 1;
+  const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
+  const bool second = !main11 && g.bricks11 != nullptr;
+  if (g.cfg.binned < 0) {
+    if (g.ndims != 4) return 0;
+    if (!main11 && !second) return 0;
+    if (main11) {
+      unsigned nb[2];
+      size_t table = 0;
+      cubic_tile_geometry(g, 1, 1, nb, &table);
+      if (table <= ((size_t)8 << 20)) return 0;  // an L2-sized table is gathered at the hit rate anyway
+    }
+    if (npoints < ((size_t)1 << 19)) return 1;
+  }
+  return 2;
+}
+
+// Take a scratch block of at least `need` bytes for an evaluation on `stream` (see BinSlot).
+// On success the block is marked busy and, where another stream used it last, `stream` has been
+// made to wait for that use.  `*why` says why not otherwise.
+interpn_hip_interp::BinSlot* take_bin_slot(interpn_hip_interp* h, size_t need, hipStream_t stream, bool may_alloc, int* why) {
+  using Slot = interpn_hip_interp::BinSlot;
+  std::lock_guard<std::mutex> lk(h->bin_mu);
+  Slot* pick = nullptr;
+  bool wait = false;
+  for (auto& sl : h->bin_slots)  // 1. the block this stream used last: stream order is enough
+    if (!sl.busy && sl.bytes >= need && sl.recorded && sl.last_stream == stream) { pick = &sl; break; }
+  if (!pick)
+    for (auto& sl : h->bin_slots) {  // 2. an idle block
+      if (sl.busy || sl.bytes < need) continue;
+      if (!sl.recorded) { pick = &sl; break; }
+      const hipError_t q = hipEventQuery(sl.event);
+      if (q == hipSuccess) { pick = &sl; break; }
+      if (q != hipErrorNotReady) (void)hipGetLastError();
+    }
+  if (!pick && may_alloc && h->bin_slots.size() < interpn_hip_interp::kMaxBinSlots) {  // 3. a new block
+    Slot sl;
+    if (hipEventCreateWithFlags(&sl.event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_ALLOC_FAILED; return nullptr; }
+    if (pool_alloc(h->device, &sl.scratch, need) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipEventDestroy(sl.event);
+      *why = INTERPN_HIP_WHY_ALLOC_FAILED;
+      return nullptr;
+    }
+    sl.bytes = need;
+    h->scratch_allocs.fetch_add(1);
+    h->bin_slots.push_back(sl);
+    pick = &h->bin_slots.back();
+  }
+  if (!pick) {  // 4. the least recently used block that is large enough: wait for it on the device
+    for (auto& sl : h->bin_slots)
+      if (!sl.busy && sl.bytes >= need && (!pick || sl.stamp < pick->stamp)) pick = &sl;
+    wait = pick != nullptr;
+  }
+  if (!pick && may_alloc) {  // 5. grow the least recently used block that nobody is enqueueing into
+    for (auto& sl : h->bin_slots)
+      if (!sl.busy && (!pick || sl.stamp < pick->stamp)) pick = &sl;
+    if (pick) {
+      if (pick->recorded && hipEventSynchronize(pick->event) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_ALLOC_FAILED; return nullptr; }
+      pool_free(h->device, pick->scratch);
+      pick->scratch = nullptr;
+      pick->bytes = 0;
+      pick->recorded = false;
+      if (pool_alloc(h->device, &pick->scratch, need) != hipSuccess) { (void)hipGetLastError(); pick->scratch = nullptr; *why = INTERPN_HIP_WHY_ALLOC_FAILED; return nullptr; }
+      pick->bytes = need;
+      h->scratch_allocs.fetch_add(1);
+    }
+  }
+  if (!pick) { *why = INTERPN_HIP_WHY_NO_SCRATCH; return nullptr; }
+  if (wait && pick->recorded && pick->last_stream != stream &&
+      hipStreamWaitEvent(stream, pick->event, 0) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_NO_SCRATCH; return nullptr; }
+  if (!wait && pick->recorded && pick->last_stream != stream) (void)hipStreamWaitEvent(stream, pick->event, 0);  // complete already: free
+  pick->busy = true;
+  pick->stamp = ++h->bin_uses;
+  return pick;
+}
+
+// Binned evaluation of the tiled multicubic kernels on device-resident points (interpn_host.h).
+// Returns -1 when the path does not apply or cannot be taken right now (`*why` says which; the
+// caller then launches the kernel on the points as they are), otherwise a status.  Chosen
+// automatically for 4-D grids whose tile table is far beyond the L2 and batches large enough to
+// pay for the sorting launches (cfg4: 2.8 -> 1.4 ms per 1e7 points; from about 5e5 points on;
+// 3-D grids lose: 4 lines per point are cheaper than sorting them); `binned` = 1 forces it for
+// N = 2..4 (tests), 0 turns it off.  Not taken while the stream is being captured into a graph.
+int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out, size_t npoints, hipStream_t stream,
+                       unsigned flags, int* why) {
+  const GridDesc& g = h->desc;
+  *why = INTERPN_HIP_WHY_NONE;
+  const int applies = binned_applies(g, npoints);
+  if (applies < 2) { *why = applies ? INTERPN_HIP_WHY_SMALL_OR_OFF : INTERPN_HIP_WHY_NONE; return -1; }
   // The table the sorted points are evaluated on: the handle's own when it is the fully
   // overlapped one (or the evaluation is forced), else the second, fully overlapped table 4-D
   // handles keep for this purpose (maybe_build_cubic_tiles).
   const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
   const bool second = !main11 && g.bricks11 != nullptr;
-  if (g.cfg.binned < 0) {
-    if (g.ndims != 4 || npoints < ((size_t)1 << 19)) return -1;
-    if (!main11 && !second) return -1;
-    if (main11) {
-      unsigned nb[2];
-      size_t table = 0;
-      cubic_tile_geometry(g, 1, 1, nb, &table);
-      if (table <= ((size_t)8 << 20)) return -1;  // an L2-sized table is gathered at the hit rate anyway
-    }
-  }
   GridDesc second_desc;
   const GridDesc* use = &g;
   if (second) {
@@ -1299,57 +1429,67 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     size_t tbytes = 0;  // of the table the sorted points will be evaluated on
     if (second || main11) cubic_tile_geometry(g, 1, 1, nbt, &tbytes);
     else cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nbt, &tbytes);
-    if (!make_bin_plan(g, tbytes, &plan)) return -1;
+    if (!make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return -1; }
-  if (cs != hipStreamCaptureStatusNone) return -1;
-  std::unique_lock<std::mutex> lk(h->bin_mu, std::try_to_lock);
-  if (!lk.owns_lock()) return -1;
-  const size_t slice = npoints < kBinSlicePoints ? npoints : kBinSlicePoints;
-  const size_t need = bin_scratch_bytes(g, slice);
-  if (need > h->bin_scratch_bytes) {
-    if (h->bin_event_recorded && hipEventSynchronize(h->bin_event) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    pool_free(h->device, h->bin_scratch);
-    h->bin_scratch = nullptr;
-    h->bin_scratch_bytes = 0;
-    if (pool_alloc(h->device, &h->bin_scratch, need) != hipSuccess) { (void)hipGetLastError(); h->bin_scratch = nullptr; return -1; }
-    h->bin_scratch_bytes = need;
-  }
-  if (!h->bin_event && hipEventCreateWithFlags(&h->bin_event, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    h->bin_event = nullptr;
-    return -1;
-  }
-  if (h->bin_event_recorded) HIP_TRY(hipStreamWaitEvent(stream, h->bin_event, 0));
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
+  if (cs != hipStreamCaptureStatusNone) { *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
+  const size_t slice_max = bin_slice_points(g);
+  const size_t slice = npoints < slice_max ? npoints : slice_max;
+  interpn_hip_interp::BinSlot* slot =
+      take_bin_slot(h, bin_scratch_bytes(g, slice), stream, !(flags & INTERPN_HIP_EVAL_NO_ALLOC), why);
+  if (!slot) return -1;
   const size_t elem = g.dtype == kF64 ? 8 : 4;
-  for (size_t begin = 0; begin < npoints; begin += slice) {
+  hipError_t err = hipSuccess;
+  for (size_t begin = 0; begin < npoints && err == hipSuccess; begin += slice) {
     const size_t count = npoints - begin < slice ? npoints - begin : slice;
     const void* src[8];
     const void* sorted[8];
     for (int d = 0; d < g.ndims; ++d) src[d] = static_cast<const char*>(obs[d]) + begin * elem;
     const unsigned* index = nullptr;
-    HIP_TRY(bin_points(g, plan, src, count, h->bin_scratch, sorted, &index, stream));
+    err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream);
+    if (err != hipSuccess) break;
     char* dst = static_cast<char*>(out) + begin * elem;
     if (g.dtype == kF64)
-      HIP_TRY(launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
-                                         h->first_bad, stream, index, begin));
+      err = launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
+                                       h->first_bad, stream, index, begin);
     else
-      HIP_TRY(launch_cubic_brick<float>(*use, reinterpret_cast<const float* const*>(sorted), reinterpret_cast<float*>(dst), count,
-                                        h->first_bad, stream, index, begin));
+      err = launch_cubic_brick<float>(*use, reinterpret_cast<const float* const*>(sorted), reinterpret_cast<float*>(dst), count,
+                                      h->first_bad, stream, index, begin);
   }
-  g.tag = use->tag;
-  HIP_TRY(hipEventRecord(h->bin_event, stream));
-  h->bin_event_recorded = true;
-  g.last_binned = 1;
+  // Whatever was enqueued — also a sequence cut short by a failure — is followed by the block's
+  // event, so that the next user of the block on another stream waits for it.
+  {
+    std::lock_guard<std::mutex> lk(h->bin_mu);
+    if (hipEventRecord(slot->event, stream) == hipSuccess) {
+      slot->recorded = true;
+    } else {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(stream);  // no event behind the work: make it complete before anyone reuses the block
+      slot->recorded = false;
+    }
+    slot->last_stream = stream;
+    slot->busy = false;
+    if (err == hipSuccess) {
+      h->desc.tag = use->tag;
+      h->desc.last_binned = 1;
+    }
+  }
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return hip_fail(err);
+  }
   return INTERPN_HIP_OK;
 }
 
 }  // namespace
 
-int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t npoints,
-                            void* stream) {
+int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t npoints,
+                               void* stream, unsigned flags, int* path_taken, int* why_out) {
+  if (path_taken) *path_taken = INTERPN_HIP_PATH_IN_PLACE;
+  if (why_out) *why_out = INTERPN_HIP_WHY_NONE;
   if (!h || (!obs && nobs)) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (flags & ~(unsigned)INTERPN_HIP_EVAL_NO_ALLOC) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   int st = validate_obs(h->desc, nullptr, nobs, npoints);
   if (st) return st;
   if (npoints == 0) return INTERPN_HIP_OK;
@@ -1358,16 +1498,76 @@ int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_
     if (!obs[i]) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
-  st = eval_device_binned(h, obs, out, npoints, static_cast<hipStream_t>(stream));
+  int why = INTERPN_HIP_WHY_NONE;
+  st = eval_device_binned(h, obs, out, npoints, static_cast<hipStream_t>(stream), flags, &why);
+  if (why_out) *why_out = why;
   if (st > 0) {
     // part of the sequence may be in flight on `stream` without a mark behind it
     std::lock_guard<std::mutex> lk(h->marks_mu);
     h->sync_device_at_destroy = true;
     return st;
   }
-  if (st < 0) HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
+  if (st < 0) {
+    HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
+    if (binned_applies(h->desc, npoints)) {  // handles that can sort: keep the report field honest
+      std::lock_guard<std::mutex> lk(h->bin_mu);
+      h->desc.last_binned = 0;
+    } else {
+      h->desc.last_binned = 0;
+    }
+    h->evals_in_place.fetch_add(1);
+  } else {
+    if (path_taken) *path_taken = INTERPN_HIP_PATH_BINNED;
+    h->evals_binned.fetch_add(1);
+  }
   mark_stream(h, static_cast<hipStream_t>(stream));
   return INTERPN_HIP_OK;
+}
+
+int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t npoints,
+                            void* stream) {
+  return interpn_hip_eval_device_ex(h, obs, nobs, out, npoints, stream, 0u, nullptr, nullptr);
+}
+
+int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {
+  if (!h || nstreams < 0) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if ((size_t)nstreams > interpn_hip_interp::kMaxBinSlots) nstreams = (int)interpn_hip_interp::kMaxBinSlots;
+  const GridDesc& g = h->desc;
+  if (npoints == 0 || nstreams == 0 || binned_applies(g, npoints) < 2) return INTERPN_HIP_OK;  // nothing to provide
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  const size_t slice_max = bin_slice_points(g);
+  const size_t need = bin_scratch_bytes(g, npoints < slice_max ? npoints : slice_max);
+  std::lock_guard<std::mutex> lk(h->bin_mu);
+  int have = 0;
+  for (auto& sl : h->bin_slots)
+    if (sl.bytes >= need) ++have;
+  // grow blocks that are too small first (idle ones only), then add new ones
+  for (auto& sl : h->bin_slots) {
+    if (have >= nstreams) break;
+    if (sl.bytes >= need || sl.busy) continue;
+    if (sl.recorded) HIP_TRY(hipEventSynchronize(sl.event));
+    pool_free(h->device, sl.scratch);
+    sl.scratch = nullptr;
+    sl.bytes = 0;
+    sl.recorded = false;
+    hipError_t e = pool_alloc(h->device, &sl.scratch, need);
+    if (e != hipSuccess) { (void)hipGetLastError(); sl.scratch = nullptr; return INTERPN_HIP_ERR_OUT_OF_MEMORY; }
+    sl.bytes = need;
+    h->scratch_allocs.fetch_add(1);
+    ++have;
+  }
+  while (have < nstreams && h->bin_slots.size() < interpn_hip_interp::kMaxBinSlots) {
+    interpn_hip_interp::BinSlot sl;
+    HIP_TRY(hipEventCreateWithFlags(&sl.event, hipEventDisableTiming));
+    hipError_t e = pool_alloc(h->device, &sl.scratch, need);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(sl.event); return INTERPN_HIP_ERR_OUT_OF_MEMORY; }
+    sl.bytes = need;
+    h->scratch_allocs.fetch_add(1);
+    h->bin_slots.push_back(sl);
+    ++have;
+  }
+  return have >= nstreams ? INTERPN_HIP_OK : INTERPN_HIP_ERR_OUT_OF_MEMORY;
 }
 
 int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_index) {
@@ -1385,7 +1585,12 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   if (word == kNoBadIndexHost) return INTERPN_HIP_OK;
   HIP_TRY(hipMemsetAsync(h->first_bad, 0xFF, sizeof(word), s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (first_bad_index) *first_bad_index = (uint64_t)word;
+  // Read the index only now: the spin above may have seen the word while the copy engine was
+  // half-way through it (anything that is neither "pending" nor "clean" ends the spin); behind
+  // the synchronisation the 8 bytes are complete.
+  const unsigned long long settled = *(volatile unsigned long long*)h->finish_word;
+  if (settled == kNoBadIndexHost) return INTERPN_HIP_OK;  // cannot happen for a monotone MIN word; harmless
+  if (first_bad_index) *first_bad_index = (uint64_t)settled;
   return INTERPN_HIP_ERR_UNREPRESENTABLE;
 }
 

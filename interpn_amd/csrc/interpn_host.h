@@ -30,6 +30,7 @@ struct LaunchConfig {
   long long host_chunk = 0;  // points per chunk of the host-pointer pipeline (0 = default)
   int deal = 1;            // binned evaluation: deal the sorted points out to the XCDs (cubic_brick.h `eighth`)
   int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
+  int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
 };
 
 // What the most recent launch through a handle ran: the kernel template and its arguments in

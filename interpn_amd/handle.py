@@ -24,7 +24,11 @@ class Interpolator:
         self.dtype = np.dtype(dtype)
         self._ndims = ndims
         self._keepalive = keepalive  # e.g. a torch tensor whose storage the handle borrows
-        self._last_stream = None     # stream of the most recent eval_tensors (finish() waits on it)
+        # Streams that evaluations were enqueued on since the last finish(): raw handle -> the
+        # object that owns it (a torch Stream kept alive here; None for a caller-supplied integer).
+        self._pending_streams = {}
+        self.last_path = None        # "in_place" | "binned": what the most recent device evaluation did
+        self.last_path_reason = ""   # why a handle that can sort its points did not
 
     # -- construction ---------------------------------------------------------------------
     @staticmethod
@@ -44,9 +48,18 @@ class Interpolator:
             return c_void_p(vals.data_ptr()), vals.numel(), mem, vals
         raise TypeError("argument 'vals': expected a numpy array or a torch tensor")
 
+    @staticmethod
+    def _method_arg(method: str, fma) -> int:
+        """`method` of interpn_hip_create_*: the method plus the per-interpolator flavour of the
+        reference's `fma` cargo feature (None = the process default, on)."""
+        m = _lib.METHODS[method]
+        if fma is None:
+            return m
+        return m | (_lib.FLAVOUR_FMA if fma else _lib.FLAVOUR_NO_FMA)
+
     @classmethod
     def regular(cls, method: str, dims, starts, steps, vals, linearize_extrapolation: bool = False,
-                device: int = -1, dtype=None) -> "Interpolator":
+                device: int = -1, dtype=None, fma=None) -> "Interpolator":
         dtype = np.dtype(dtype or starts.dtype)
         sfx = "f64" if dtype == np.float64 else "f32"
         ct = c_double if dtype == np.float64 else c_float
@@ -57,7 +70,7 @@ class Interpolator:
         vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
         h = c_void_p()
         st = getattr(lib, f"interpn_hip_create_regular_{sfx}")(
-            _lib.METHODS[method], d, nd, starts.ctypes.data_as(POINTER(ct)),
+            cls._method_arg(method, fma), d, nd, starts.ctypes.data_as(POINTER(ct)),
             starts.size, steps.ctypes.data_as(POINTER(ct)), steps.size, vptr, nvals, mem,
             int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
         _lib.raise_for_status(st)
@@ -65,7 +78,7 @@ class Interpolator:
 
     @classmethod
     def rectilinear(cls, method: str, grids, vals, linearize_extrapolation: bool = False, device: int = -1,
-                    dtype=None) -> "Interpolator":
+                    dtype=None, fma=None) -> "Interpolator":
         dtype = np.dtype(dtype or grids[0].dtype)
         sfx = "f64" if dtype == np.float64 else "f32"
         lib = _lib.load()
@@ -73,7 +86,7 @@ class Interpolator:
         vptr, nvals, mem, keep = cls._vals_arg(vals, dtype)
         h = c_void_p()
         st = getattr(lib, f"interpn_hip_create_rectilinear_{sfx}")(
-            _lib.METHODS[method], gptr, glen, ng, vptr, nvals, mem,
+            cls._method_arg(method, fma), gptr, glen, ng, vptr, nvals, mem,
             int(bool(linearize_extrapolation)), int(device), ctypes.byref(h))
         _lib.raise_for_status(st)
         return cls(h.value, dtype, ng, keep if mem == _lib.MEM_DEVICE else None)
@@ -139,20 +152,34 @@ class Interpolator:
         _lib.raise_for_status(st)
         return out
 
-    def eval_device_ptrs(self, obs_ptrs, out_ptr: int, npoints: int, stream: int = 0) -> None:
-        """Enqueue one evaluation on device buffers given as raw addresses (asynchronous)."""
+    def reserve(self, npoints: int, nstreams: int = 1) -> None:
+        """Pre-allocate what device evaluations of up to `npoints` points on up to `nstreams`
+        concurrent streams need (`interpn_hip_reserve`); afterwards such evaluations allocate
+        nothing, also with `no_alloc=True`."""
+        _lib.raise_for_status(_lib.load().interpn_hip_reserve(self._h, int(npoints), int(nstreams)))
+
+    def eval_device_ptrs(self, obs_ptrs, out_ptr: int, npoints: int, stream: int = 0, no_alloc: bool = False) -> str:
+        """Enqueue one evaluation on device buffers given as raw addresses (asynchronous).
+        Returns the path taken, "in_place" or "binned" (also kept in `.last_path`, with
+        `.last_path_reason` saying why a handle that can sort its points evaluated in place)."""
         lib = _lib.load()
         n = len(obs_ptrs)
         vp = (c_void_p * max(n, 1))()
         for i, p in enumerate(obs_ptrs):
             vp[i] = c_void_p(int(p))
-        st = lib.interpn_hip_eval_device(self._h, vp, n, c_void_p(int(out_ptr)), int(npoints),
-                                         c_void_p(int(stream)))
+        path, why = ctypes.c_int(0), ctypes.c_int(0)
+        st = lib.interpn_hip_eval_device_ex(self._h, vp, n, c_void_p(int(out_ptr)), int(npoints), c_void_p(int(stream)),
+                                            _lib.EVAL_NO_ALLOC if no_alloc else 0, ctypes.byref(path), ctypes.byref(why))
         _lib.raise_for_status(st)
+        self.last_path = "binned" if path.value == _lib.PATH_BINNED else "in_place"
+        self.last_path_reason = _lib.WHY.get(why.value, str(why.value))
+        self._pending_streams.setdefault(int(stream), None)
+        return self.last_path
 
-    def eval_tensors(self, obs, out=None, stream=None):
-        """Evaluate on torch CUDA tensors (asynchronous on torch's current stream unless given).
-        Call `finish()` to synchronise and surface "Unrepresentable coordinate value"."""
+    def eval_tensors(self, obs, out=None, stream=None, no_alloc: bool = False):
+        """Evaluate on torch CUDA tensors (asynchronous on torch's current stream unless given: a
+        torch Stream or a raw hipStream_t integer).  Call `finish()` to synchronise and surface
+        "Unrepresentable coordinate value"."""
         import torch
 
         want = torch.float64 if self.dtype == np.float64 else torch.float32
@@ -173,9 +200,11 @@ class Interpolator:
             raise AssertionError("Dimension mismatch")
         else:
             self._check_same_device("out", out)
-        s = stream if stream is not None else torch.cuda.current_stream(self.device()).cuda_stream
-        self.eval_device_ptrs([t.data_ptr() for t in obs], out.data_ptr(), n, s)
-        self._last_stream = s
+        owner = torch.cuda.current_stream(self.device()) if stream is None else stream
+        raw = owner.cuda_stream if hasattr(owner, "cuda_stream") else int(owner)
+        self.eval_device_ptrs([t.data_ptr() for t in obs], out.data_ptr(), n, raw, no_alloc)
+        # keep the Stream OBJECT: a raw handle whose torch Stream was collected would dangle
+        self._pending_streams[raw] = owner if hasattr(owner, "cuda_stream") else None
         return out
 
     def check_bounds_tensors(self, obs, atol: float, stream=None) -> np.ndarray:
@@ -206,27 +235,38 @@ class Interpolator:
         return np.array([bool(flags[i]) for i in range(len(obs))])
 
     def finish(self, stream=None) -> None:
-        """Wait for the stream; raise AssertionError("Unrepresentable coordinate value") if any
-        device evaluation since the last finish hit a NaN/inf/out-of-range coordinate.  `stream`
-        defaults to the one the most recent `eval_tensors` was enqueued on (else torch's current
-        stream of the handle's device)."""
+        """Wait for the evaluations enqueued since the last finish and raise
+        AssertionError("Unrepresentable coordinate value") if any of them hit a NaN/inf/out-of-range
+        coordinate.  Without `stream`, EVERY stream used since the last finish is waited for (the
+        status word is sticky per handle, not per stream); with `stream` (a torch Stream or a raw
+        integer) only that one."""
         lib = _lib.load()
-        if stream is None and self._last_stream is not None:
-            stream = self._last_stream
-        if stream is None:
+        if stream is not None:
+            raws = [stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)]
+        else:
+            raws = list(self._pending_streams)
+        if not raws:
             try:
                 import torch
 
-                stream = torch.cuda.current_stream(self.device()).cuda_stream if torch.cuda.is_available() else 0
+                raws = [torch.cuda.current_stream(self.device()).cuda_stream if torch.cuda.is_available() else 0]
             except ImportError:
-                stream = 0
-        bad = c_uint64(0)
-        st = lib.interpn_hip_finish(self._h, c_void_p(int(stream)), ctypes.byref(bad))
-        if st == _lib.ERR_UNREPRESENTABLE:
-            err = AssertionError(_lib.strerror(st))
-            err.first_bad_index = bad.value
+                raws = [0]
+        first_bad = None
+        status = _lib.OK
+        for raw in raws:
+            bad = c_uint64(0)
+            st = lib.interpn_hip_finish(self._h, c_void_p(int(raw)), ctypes.byref(bad))
+            self._pending_streams.pop(raw, None)
+            if st == _lib.ERR_UNREPRESENTABLE:
+                first_bad = bad.value if first_bad is None else min(first_bad, bad.value)
+            elif st != _lib.OK and status == _lib.OK:
+                status = st
+        _lib.raise_for_status(status)
+        if first_bad is not None:
+            err = AssertionError(_lib.strerror(_lib.ERR_UNREPRESENTABLE))
+            err.first_bad_index = first_bad
             raise err
-        _lib.raise_for_status(st)
 
     def close(self) -> None:
         if self._h is not None and self._h.value:

@@ -118,3 +118,84 @@ def evaluate(method, kind, grids, vals, obs, linearize=False, starts=None, steps
         x = [F(float(obs[d][k])) for d in range(len(grids))]
         out.append(_eval(method, fg, fv, shape, x, linearize, reg))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Tensor-product form with a condition number (round 3).  Every 1-D operator above is linear in
+# the node values, so the N-D interpolant is  sum_k  prod_d W_d[k_d](x_d) * vals[k]  with per-
+# dimension weight vectors W_d that depend on x_d only.  This second formulation (weights first,
+# one contraction) shares nothing with the dimension-by-dimension recursion of `_eval` except the
+# 1-D formulas, returns exactly the same rational, and yields the quantities a rounding-error bound
+# needs:  sum |W...| |vals|  (sensitivity to rounding in the value tree)  and  |dI/dx_d|
+# (sensitivity to the rounding of t = (x - x_i) / h, whose absolute error is ~ u (|x| + |x_i|) / h).
+
+
+def _weights_1d(method, g, x, linearize, reg):
+    n = len(g)
+    if reg is not None:
+        i = _cell_regular(x, reg[0], reg[1], n, 2)
+    else:
+        i = _cell_rect(x, g)
+    if method == "linear":
+        t = (x - g[i]) / (g[i + 1] - g[i])
+        return {i: 1 - t, i + 1: t}
+    need = sorted({k for k in (i - 1, i, i + 1, i + 2) if 0 <= k < n})
+    w = {}
+    for k in need:
+        unit = {j: (F(1) if j == k else F(0)) for j in need}
+        w[k] = _cubic1d(x, g, unit, i, linearize)
+    return w
+
+
+def _contract(ws, vals, shape, absolute):
+    nd = len(ws)
+
+    def rec(d, base):
+        tot = F(0)
+        for k, w in ws[d].items():
+            idx = base * shape[d] + k
+            sub = (abs(vals[idx]) if absolute else vals[idx]) if d == nd - 1 else rec(d + 1, idx)
+            tot += (abs(w) if absolute else w) * sub
+        return tot
+
+    return rec(0, 0)
+
+
+def evaluate_with_condition(method, kind, grids, vals, obs, linearize=False, starts=None, steps=None):
+    """Per observation point: (exact value, bound scale), both Fractions.
+
+    `bound scale` = sum_k |prod_d W_d[k_d]| |vals[k]|  +  sum_d (|x_d| + max|g_d|) * |dI/dx_d|,
+    the derivative taken as an exact central difference over 2^-24 of the local cell width.  A
+    floating-point evaluation with unit round-off u that performs the reference's operations in
+    any order differs from the exact value by a modest multiple of u * scale."""
+    nd = len(grids)
+    shape = [len(g) for g in grids]
+    fv = [F(float(v)) for v in vals]
+    if kind == "regular":
+        reg = [(F(float(starts[d])), F(float(steps[d]))) for d in range(nd)]
+        fg = [[reg[d][0] + k * reg[d][1] for k in range(shape[d])] for d in range(nd)]
+    else:
+        reg = [None] * nd
+        fg = [[F(float(v)) for v in g] for g in grids]
+    gmax = [max(abs(fg[d][0]), abs(fg[d][-1])) for d in range(nd)]
+    out = []
+    for p in range(len(obs[0])):
+        x = [F(float(obs[d][p])) for d in range(nd)]
+        if any(not math.isfinite(float(obs[d][p])) for d in range(nd)):
+            out.append((None, None))
+            continue
+        ws = [_weights_1d(method, fg[d], x[d], linearize, reg[d]) for d in range(nd)]
+        val = _contract(ws, fv, shape, False)
+        scale = _contract(ws, fv, shape, True)
+        for d in range(nd):
+            i0 = min(ws[d])
+            h = fg[d][i0 + 1] - fg[d][i0]
+            delta = h / (1 << 24)
+            wp = list(ws)
+            wm = list(ws)
+            wp[d] = _weights_1d(method, fg[d], x[d] + delta, linearize, reg[d])
+            wm[d] = _weights_1d(method, fg[d], x[d] - delta, linearize, reg[d])
+            deriv = abs(_contract(wp, fv, shape, False) - _contract(wm, fv, shape, False)) / (2 * delta)
+            scale += (abs(x[d]) + gmax[d]) * deriv
+        out.append((val, scale))
+    return out

@@ -8,8 +8,12 @@ outputs of the reference itself.  They freeze
       (re-created by tests/kat.py, each citing the reference test it mirrors), and
   (b) outputs of the pinned CPU oracle (oracle/interpn_oracle.cpp, both `fma` flavours) on small
       seeded random workloads with extrapolation and special points,
-so that the oracle cannot drift silently and the GPU path can be checked on a box where only the
-committed data travels.  Run from the repository root:  python tests/golden/make_golden.py
+  (c) for every workload of (b): the EXACT value of the interpolant at each point
+      (oracle/exact_rational.py: `fractions.Fraction`, tensor-product form — no rounding, and no
+      code shared with the C++ oracle) rounded once to f64, and the rounding-error scale
+      sum|w||v| + sum_d (|x_d| + max|g_d|) |dI/dx_d| the tests multiply by 4 u,
+so that the oracle cannot drift silently and the GPU path can be checked — against the oracle AND
+against something that is not the oracle — on a box where only the committed data travels.  Run from the repository root:  python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -19,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from oracle import pyoracle  # noqa: E402
+from oracle import exact_rational, pyoracle  # noqa: E402
 from tests import kat  # noqa: E402
 from tests.helpers import run_oracle, synthetic_case  # noqa: E402
 
@@ -67,9 +71,13 @@ def main():
                     continue
                 c = synthetic_case(m, k, n, axis, 500, 7000 + n, dtype, linearize=lin, extrap=0.25)
                 c.name = f"{m}_{k}_N{n}_{'f64' if dtype == np.float64 else 'f32'}_lin{int(lin)}"
-                for key, v in pack(c, {"oracle_fma1": run_oracle(pyoracle, c, True),
-                                       "oracle_fma0": run_oracle(pyoracle, c, False)}).items():
+                ex = exact_rational.evaluate_with_condition(m, k, c.grids, c.vals, c.obs, lin, c.starts, c.steps)
+                extra = {"oracle_fma1": run_oracle(pyoracle, c, True), "oracle_fma0": run_oracle(pyoracle, c, False),
+                         "exact": np.array([float(v) for v, _ in ex]),  # float(Fraction) rounds correctly, once
+                         "exact_scale": np.array([float(sc) for _, sc in ex])}
+                for key, v in pack(c, extra).items():
                     blob[f"{c.name}/{key}"] = v
+                print(c.name, flush=True)
     np.savez_compressed(os.path.join(OUT, "random_cases.npz"), **blob)
     for f in ("kat_cases.npz", "random_cases.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -1477,3 +1477,173 @@ def test_binned_evaluation_across_slices(oracle, monkeypatch):
         it.finish()
     assert err.value.first_bad_index == bad_at
     it.close()
+
+
+def test_fma_flavour_is_a_per_handle_property(oracle):
+    """The reference's `fma` cargo feature (Cargo.toml:34-38) is chosen per interpolator
+    (INTERPN_HIP_FLAVOUR_* in `method`), not through process-global state: two handles of
+    different flavour, evaluated concurrently from two threads on their own streams, each give
+    their own flavour's bits; the process default (`interpn_hip_set_fma`) is never touched and
+    flipping it does not change an existing handle; option "fma" reads and switches a handle."""
+    import threading
+
+    import torch
+
+    import interpn_amd
+    from interpn_amd import _lib
+
+    dev = torch.device("cuda:0")
+    results = {}
+    for method, kind, axis in (("linear", "regular", [17, 9, 32]), ("cubic", "rectilinear", [9, 6, 16])):
+        case = synthetic_case(method, kind, 3, axis, 300_007, 777, np.float64, extrap=0.2)
+        want = {True: run_oracle(oracle, case, True), False: run_oracle(oracle, case, False)}
+        assert not np.array_equal(want[True], want[False])  # the flavours differ on this workload
+        mk = (lambda f: interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals, False, 0,
+                                                         np.float64, fma=f)) if kind == "regular" else \
+             (lambda f: interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals, False, 0, np.float64, fma=f))
+        its = {True: mk(True), False: mk(False)}
+        assert its[True].get_option("fma") == 1 and its[False].get_option("fma") == 0
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        errors = []
+
+        def work(flag):
+            try:
+                s = torch.cuda.Stream()
+                for _ in range(25):
+                    with torch.cuda.stream(s):
+                        out = its[flag].eval_tensors(obs)
+                    its[flag].finish()
+                    if not np.array_equal(out.cpu().numpy(), want[flag]):
+                        errors.append((method, flag))
+                        return
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=work, args=(f,)) for f in (True, False)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors
+        # the deprecated process default does not reach existing handles ...
+        lib = _lib.load()
+        prev = lib.interpn_hip_set_fma(0)
+        try:
+            out = its[True].eval_tensors(obs)
+            its[True].finish()
+            assert np.array_equal(out.cpu().numpy(), want[True])
+            # ... only handles created afterwards without a flavour flag
+            d = mk(None)
+            assert d.get_option("fma") == 0
+            d.close()
+        finally:
+            lib.interpn_hip_set_fma(prev)
+        # option "fma" switches a handle between launches
+        its[True].set_option("fma", 0)
+        out = its[True].eval_tensors(obs)
+        its[True].finish()
+        assert np.array_equal(out.cpu().numpy(), want[False])
+        for it in its.values():
+            it.close()
+        results[method] = True
+    # both flags at once is an error
+    import ctypes
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    d, st, sp, v = (ctypes.c_size_t * 1)(4), (ctypes.c_double * 1)(0.0), (ctypes.c_double * 1)(1.0), (ctypes.c_double * 4)(0, 1, 2, 3)
+    rc = lib.interpn_hip_create_regular_f64(_lib.FLAVOUR_FMA | _lib.FLAVOUR_NO_FMA, d, 1, st, 1, sp, 1, v, 4, 0, 0, 0, ctypes.byref(h))
+    assert rc == _lib.ERR_INVALID_ARGUMENT and not h.value
+    assert results == {"linear": True, "cubic": True}
+
+
+def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monkeypatch):
+    """`interpn_hip_eval_device_ex` says which path an evaluation took and why; after
+    `interpn_hip_reserve(h, n, k)` evaluations of at most n points on at most k streams allocate
+    nothing (also with INTERPN_HIP_EVAL_NO_ALLOC, which never allocates); two threads on two
+    streams use two scratch blocks concurrently instead of one falling back to the in-place
+    kernel; under graph capture the call evaluates in place and says so."""
+    import threading
+
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    P = 300_000
+    case = synthetic_case("cubic", "regular", 4, [6, 7, 5, 6], P, 9400, np.float64, extrap=0.2, specials=False)
+    want = run_oracle(oracle, case, True)
+    it = _make_interp(interpn_amd, case)
+    it.set_option("binned", 1)
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    # nothing reserved, allocation forbidden: in place, and the reason is reported
+    out = it.eval_tensors(obs, no_alloc=True)
+    it.finish()
+    assert it.last_path == "in_place" and "scratch" in it.last_path_reason
+    assert it.get_option("scratch_allocs") == 0 and it.get_option("scratch_bytes") == 0
+    assert np.array_equal(out.cpu().numpy(), want)
+    it.reserve(P, 2)
+    assert it.get_option("scratch_allocs") == 2
+    bytes2 = it.get_option("scratch_bytes")
+    assert bytes2 >= 2 * P * (4 * 8 + 4)
+    out = it.eval_tensors(obs, no_alloc=True)
+    it.finish()
+    assert it.last_path == "binned" and it.last_path_reason == ""
+    assert np.array_equal(out.cpu().numpy(), want)
+    # two threads, two streams, one handle: both sorted, no allocation, right answers
+    errors = []
+
+    def work():
+        try:
+            s = torch.cuda.Stream()
+            for _ in range(10):
+                with torch.cuda.stream(s):
+                    o = it.eval_tensors(obs, no_alloc=True)
+                s.synchronize()
+                if not np.array_equal(o.cpu().numpy(), want):
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    before = it.get_option("evals_binned")
+    ts = [threading.Thread(target=work) for _ in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    it.finish()
+    assert not errors, errors
+    assert it.get_option("evals_binned") == before + 20  # none of them fell back
+    assert it.get_option("scratch_allocs") == 2 and it.get_option("scratch_bytes") == bytes2
+    # a larger batch than reserved: allocation allowed -> grows; forbidden -> in place
+    big = [torch.cat([o, o]) for o in obs]
+    o2 = it.eval_tensors(big, no_alloc=True)
+    it.finish()
+    assert it.last_path == "in_place"
+    assert np.array_equal(o2[:P].cpu().numpy(), want)
+    o2 = it.eval_tensors(big)
+    it.finish()
+    assert it.last_path == "binned" and it.get_option("scratch_allocs") == 3
+    assert np.array_equal(o2[P:].cpu().numpy(), want)
+    # small batches of a handle in automatic mode, and captures, say why
+    it.set_option("binned", 0)
+    it.eval_tensors(obs)
+    it.finish()
+    assert it.last_path == "in_place" and "binned = 0" in it.last_path_reason
+    it.set_option("binned", 1)
+    res = torch.zeros(P, dtype=torch.float64, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        it.eval_tensors(obs, res)
+    assert it.last_path == "in_place" and "capture" in it.last_path_reason
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), want)
+    it.finish()
+    it.close()
+    # a handle that never sorts: nothing to reserve, path always in place, no reason
+    lin = synthetic_case("linear", "regular", 3, [9, 8, 7], 1000, 1, np.float64)
+    it = _make_interp(interpn_amd, lin)
+    it.reserve(10**8, 4)
+    assert it.get_option("scratch_bytes") == 0
+    it.eval_tensors([torch.from_numpy(o).to(dev) for o in lin.obs])
+    it.finish()
+    assert it.last_path == "in_place" and it.last_path_reason == ""
+    it.close()
