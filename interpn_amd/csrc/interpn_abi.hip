@@ -676,6 +676,9 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"binned", &c.binned, -1, 1},
       {"deal", &c.deal, 0, 1},
       {"bin_slice_log2", &c.bin_slice_log2, 16, 27},
+      {"column", &c.column, -1, 1},
+      {"unpermute", &c.unpermute, 0, 1},
+      {"column_part", &c.column_part, 0, 1 << 20},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -704,7 +707,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2"};
+                                      "bin_slice_log2", "column", "unpermute", "column_part"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -1424,12 +1427,17 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     use = &second_desc;
   }
   BinPlan plan;
+  // Column evaluation (cubic_column.h): 4-D regular grids whose (k, l) column of tiles fits the LDS
+  // and whose (i, j) cells fit one bin each — cfg4.  The sorted points of a cell are then
+  // evaluated out of LDS instead of 16 L2 lines per point.
+  bool column = g.cfg.column != 0 && (second || main11) && cubic_column_applies(*use);
   {
     unsigned nbt[2];
     size_t tbytes = 0;  // of the table the sorted points will be evaluated on
     if (second || main11) cubic_tile_geometry(g, 1, 1, nbt, &tbytes);
     else cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nbt, &tbytes);
-    if (!make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
+    if (column && !make_bin_plan(g, tbytes, &plan, /*exact_cells=*/true)) column = false;
+    if (!column && !make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
@@ -1447,9 +1455,27 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     const void* sorted[8];
     for (int d = 0; d < g.ndims; ++d) src[d] = static_cast<const char*>(obs[d]) + begin * elem;
     const unsigned* index = nullptr;
+    char* dst = static_cast<char*>(out) + begin * elem;
+    if (column) {
+      // parts of about count / (6 per CU) points: the dispatcher hands them to the CUs as they free up
+      size_t q = count / ((size_t)g.cfg.num_cus * 6) + 1;
+      q = (q + 1023) / 1024 * 1024;
+      q = q < 2048 ? 2048 : (q > 16384 ? 16384 : q);
+      if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part;
+      const size_t max_parts = count / q + (size_t)plan.nbins + 1;
+      BinExtras extras;
+      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q);
+      if (err != hipSuccess) break;
+      if (g.dtype == kF64)
+        err = launch_cubic_column<double>(*use, plan, reinterpret_cast<const double* const*>(sorted), index, extras, g.cfg.unpermute != 0,
+                                          reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
+      else
+        err = launch_cubic_column<float>(*use, plan, reinterpret_cast<const float* const*>(sorted), index, extras, g.cfg.unpermute != 0,
+                                         reinterpret_cast<float*>(dst), count, max_parts, h->first_bad, begin, stream);
+      continue;
+    }
     err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream);
     if (err != hipSuccess) break;
-    char* dst = static_cast<char*>(out) + begin * elem;
     if (g.dtype == kF64)
       err = launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
                                        h->first_bad, stream, index, begin);

@@ -30,6 +30,9 @@ struct LaunchConfig {
   long long host_chunk = 0;  // points per chunk of the host-pointer pipeline (0 = default)
   int deal = 1;            // binned evaluation: deal the sorted points out to the XCDs (cubic_brick.h `eighth`)
   int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
+  int column = -1;         // binned 4-D multicubic on regular grids: evaluate sorted points out of an LDS-resident table column (-1/1 where it applies, 0 never)
+  int unpermute = 0;       // column evaluation: 1 = results written in sorted order + an un-permutation pass, 0 = scattered 8-byte stores (measured faster: 1.39 vs 1.44 ms, profiles/r03_cfg4_column_v1.txt)
+  int column_part = 0;     // column evaluation: points per workgroup (0 = automatic)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
 };
 
@@ -189,6 +192,7 @@ struct BinPlan {
   int nbins = 0;      // <= kMaxBins
   int nb1 = 0;        // bins along dim 1
   int mult = 1;       // bins are visited in the order key * mult mod nbins (k_bin_points.hip::bin_key)
+  int inv_mult = 1;   // its inverse mod nbins
   int ncell[2] = {0, 0};   // footprint origins per dim: n - 3
   int shift[2] = {0, 0};   // bin = cell >> shift
   double start[2] = {0, 0};
@@ -196,12 +200,33 @@ struct BinPlan {
 };
 constexpr int kMaxBins = 1024;  // one bin per thread of the scatter kernel's scan; 16-bit keys
 constexpr size_t kBinSlicePoints = (size_t)1 << 25;  // points sorted and evaluated per slice (bounds the scratch)
-bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan);
+// `exact_cells`: one bin per (i, j) cell of dims 0, 1 (what the column evaluation needs); false when
+// they do not fit kMaxBins.
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool exact_cells = false);
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points);
+// What the column evaluation (cubic_column.h) needs from the sort besides the sorted points.
+struct BinExtras {
+  const unsigned* rank = nullptr;         // rank[i] = sorted position of point i of the slice
+  void* res_sorted = nullptr;             // room for the slice's results in sorted order
+  const unsigned* bin_end = nullptr;      // end of every bin in sorted order
+  const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
+};
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
-// original indices (within the slice).
+// original indices (within the slice).  `extras` (4-D only): also the items above, with bins cut
+// into parts of at most `part_points` points.
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
-                      const void** binned_obs, const unsigned** index, hipStream_t stream);
+                      const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras = nullptr,
+                      unsigned part_points = 0);
+
+// Column evaluation of sorted 4-D multicubic points on a regular grid (cubic_column.h): does it
+// apply to this grid (LDS capacity, one bin per cell), and the launch.  `res_sorted` non-null:
+// results are written in sorted order and un-permuted into `out` by a second kernel; null: every
+// result goes straight to out[index[k]].
+bool cubic_column_applies(const GridDesc& g);
+template <typename T>
+hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const T* const* sorted_obs, const unsigned* index,
+                               const BinExtras& extras, bool unpermute, T* out, size_t npts, size_t max_parts,
+                               unsigned long long* first_bad, size_t index_base, hipStream_t stream);
 
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>

@@ -17,7 +17,8 @@ namespace {
 constexpr int kHistIters = 32;                             // histogram: 256-lane rows per workgroup
 constexpr size_t kHistChunk = (size_t)kBlock * kHistIters;
 constexpr size_t kBinChunk = 4096;                         // scatter: points per workgroup (sorted in LDS)
-constexpr size_t kCounterBytes = (size_t)2 * kMaxBins * sizeof(unsigned);
+// totals[kMaxBins] | cursor[kMaxBins] | part_prefix[kMaxBins + 1] (+ padding)
+constexpr size_t kCounterBytes = (size_t)4 * kMaxBins * sizeof(unsigned);
 
 struct BinParams {
   double start[2];
@@ -65,20 +66,32 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
     if (hist[b]) atomicAdd(&totals[b], hist[b]);
 }
 
-// cursor[b] = sum of totals[0..b); one workgroup of 1024 threads (kMaxBins <= 1024).
-__global__ void __launch_bounds__(1024) k_bin_scan(const unsigned* __restrict__ totals, unsigned* __restrict__ cursor, int nbins) {
+// cursor[b] = sum of totals[0..b); one workgroup of 1024 threads (kMaxBins <= 1024).  Also the
+// work list of the column kernel (cubic_column.h): a bin of c points is cut into
+// ceil(c / part_points) parts, part_prefix[b] = parts in front of bin b, part_prefix[nbins] = all.
+__global__ void __launch_bounds__(1024) k_bin_scan(const unsigned* __restrict__ totals, unsigned* __restrict__ cursor, int nbins,
+                                                   unsigned* __restrict__ part_prefix, unsigned part_points) {
   __shared__ unsigned s[1024];
+  __shared__ unsigned sp[1024];
   const int t = threadIdx.x;
   const unsigned mine = t < nbins ? totals[t] : 0u;
+  const unsigned parts = part_points ? (mine + part_points - 1u) / part_points : 0u;
   s[t] = mine;
+  sp[t] = parts;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
     const unsigned add = t >= off ? s[t - off] : 0u;
+    const unsigned addp = t >= off ? sp[t - off] : 0u;
     __syncthreads();
     s[t] += add;
+    sp[t] += addp;
     __syncthreads();
   }
-  if (t < nbins) cursor[t] = s[t] - mine;
+  if (t < nbins) {
+    cursor[t] = s[t] - mine;
+    part_prefix[t] = sp[t] - parts;
+    if (t == nbins - 1) part_prefix[nbins] = sp[t];
+  }
 }
 
 template <typename T, int N>
@@ -86,6 +99,7 @@ struct ScatterArgs {
   const T* obs[N];
   T* binned[N];
   unsigned* index;
+  unsigned* rank;  // optional: rank[i] = sorted position of point i (the inverse of `index`)
   unsigned* cursor;
   size_t npts;
   BinParams p;
@@ -107,6 +121,7 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
   __shared__ unsigned short keys[kBinChunk];       // key of local point l
   __shared__ unsigned short sorted_src[kBinChunk]; // local point at sorted position j
   __shared__ unsigned short sorted_key[kBinChunk];
+  __shared__ unsigned lpos32[kBinChunk];            // sorted position of local point l (rank output)
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
   if (tid < kMaxBins) fill[tid] = 0;
@@ -183,16 +198,32 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
 #pragma unroll
   for (int it = 0; it < kScatIters; ++it)
     if (((unsigned)it * kScatThreads + tid) < count) a.index[pos[it]] = (unsigned)src[it];
+  if (a.rank) {
+    // rank[] is indexed by ORIGINAL position: hand the sorted positions over through LDS so that
+    // consecutive lanes write consecutive words.
+#pragma unroll
+    for (int it = 0; it < kScatIters; ++it) {
+      const unsigned j = (unsigned)it * kScatThreads + tid;
+      if (j < count) lpos32[sorted_src[j]] = pos[it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kScatIters; ++it) {
+      const unsigned l = (unsigned)it * kScatThreads + tid;
+      if (l < count) a.rank[first + l] = lpos32[l];
+    }
+  }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T, int N>
 hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts, void* scratch, const void** binned_obs,
-                        const unsigned** index, hipStream_t stream) {
+                        const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream) {
   unsigned char* base = static_cast<unsigned char*>(scratch);
   unsigned* totals = reinterpret_cast<unsigned*>(base);
   unsigned* cursor = totals + kMaxBins;
+  unsigned* part_prefix = cursor + kMaxBins;
   size_t off = align_up(kCounterBytes, 256);
   unsigned* idx = reinterpret_cast<unsigned*>(base + off);
   off += align_up(npts * sizeof(unsigned), 256);
@@ -202,6 +233,16 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     a.binned[d] = reinterpret_cast<T*>(base + off);
     binned_obs[d] = a.binned[d];
     off += align_up(npts * sizeof(T), 256);
+  }
+  a.rank = nullptr;
+  if (extras) {  // column evaluation: rank (original -> sorted) and a sorted-order result array
+    a.rank = reinterpret_cast<unsigned*>(base + off);
+    off += align_up(npts * sizeof(unsigned), 256);
+    extras->rank = a.rank;
+    extras->res_sorted = base + off;
+    off += align_up(npts * sizeof(T), 256);
+    extras->bin_end = cursor;  // after the scatter every cursor stands at the end of its bin
+    extras->part_prefix = part_prefix;
   }
   a.index = idx;
   a.cursor = cursor;
@@ -213,14 +254,14 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   const unsigned blocks = (unsigned)((npts + kBinChunk - 1) / kBinChunk);
   const unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
   hipLaunchKernelGGL(k_bin_hist<T>, dim3(hblocks), dim3(kBlock), 0, stream, a.obs[0], a.obs[1], npts, p, totals);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points);
   hipLaunchKernelGGL((k_bin_scatter<T, N>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
-bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan) {
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool exact_cells) {
   if (g.method != kCubic || g.ndims < 2) return false;
   BinPlan p;
   for (int d = 0; d < 2; ++d) {
@@ -242,6 +283,10 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan) {
   // -> 529; never fewer than 64 (balance across the XCDs), never more than kMaxBins.
   long long target = (long long)(table_bytes >> 19);
   target = target < 64 ? 64 : (target > kMaxBins ? kMaxBins : target);
+  if (exact_cells) {  // one bin per (i, j) cell (column evaluation): only if they all fit
+    if ((long long)p.ncell[0] * p.ncell[1] > kMaxBins) return false;
+    target = kMaxBins;
+  }
   auto bins = [&](int d) { return ((p.ncell[d] - 1) >> p.shift[d]) + 1; };
   while ((long long)bins(0) * bins(1) > target) {
     if (bins(0) >= bins(1)) ++p.shift[0];
@@ -254,18 +299,26 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan) {
   p.mult = (int)(0.6180339887 * p.nbins);
   if (p.mult < 1) p.mult = 1;
   while (gcd(p.mult, p.nbins) != 1) ++p.mult;
+  p.inv_mult = 1;  // (b * inv_mult) % nbins undoes (key * mult) % nbins
+  for (int v = 1; v < p.nbins; ++v)
+    if ((long long)v * p.mult % p.nbins == 1) { p.inv_mult = v; break; }
   *plan = p;
   return true;
 }
 
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points) {
   const size_t elem = g.dtype == kF64 ? 8 : 4;
-  return align_up(kCounterBytes, 256) + align_up(slice_points * sizeof(unsigned), 256) +
-         (size_t)g.ndims * align_up(slice_points * elem, 256);
+  size_t b = align_up(kCounterBytes, 256) + align_up(slice_points * sizeof(unsigned), 256) +
+             (size_t)g.ndims * align_up(slice_points * elem, 256);
+  // column evaluation (4-D): rank + results in sorted order
+  if (g.ndims == 4) b += align_up(slice_points * sizeof(unsigned), 256) + align_up(slice_points * elem, 256);
+  return b;
 }
 
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
-                      const void** binned_obs, const unsigned** index, hipStream_t stream) {
+                      const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras,
+                      unsigned part_points) {
+  if (extras && g.ndims != 4) return hipErrorInvalidValue;
   if (npts == 0 || npts > kBinSlicePoints) return hipErrorInvalidValue;
   BinParams p;
   for (int d = 0; d < 2; ++d) {
@@ -277,7 +330,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.nb1 = plan.nb1;
   p.nbins = plan.nbins;
   p.mult = plan.mult;
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, stream)
+#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream)
   if (g.dtype == kF64) {
     switch (g.ndims) {
       case 2: GO(double, 2);
