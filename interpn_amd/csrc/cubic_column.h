@@ -30,32 +30,31 @@ template <typename T>
 struct CubicColumnArgs {
   const T* tiles;            // fully overlapped tile table [plane (k, l)][bi][bj][16]
   unsigned table_bytes;
-  const T* obs[4];           // the slice's points in bin order
+  const T* records;          // the slice's points in bin order, 4 coordinates each
   const unsigned* index;     // sorted position -> index within the slice
-  T* out;                    // caller's output of the slice (scattered write) ...
-  T* res_sorted;             // ... or, if non-null, results in sorted order (un-permuted by k_unpermute)
+  T* out;                    // caller's output of the slice
   unsigned long long* first_bad;
   size_t index_base;
   size_t npts;
   const unsigned* bin_end;      // end of bin b in sorted order (the scatter's cursors after the scatter)
   const unsigned* part_prefix;  // workgroups (parts) in front of bin b; [nbins] = total
   int nbins;
-  int nb1;                   // cells along dim 1
-  unsigned inv_mult;         // sorted bin b holds cell key (b * inv_mult) % nbins
-  unsigned part_points;      // a bin of c points is cut into ceil(c / part_points) equal parts
+  int nb1;                   // classes along dim 1 (n1 - 1)
+  unsigned inv_mult;         // sorted bin b holds class pair (b * inv_mult) % nbins
   T start[4];
   T step[4];
+  T rstep[4];                // ~1 / step: the local sort's class estimate (a hint; the exact class is re-derived)
   int n[4];
   int linearize;
   unsigned plane_stride[4];  // table elements per unit index of dims 2, 3
   unsigned nbj;
+  int ablate;                // timing probes only (results wrong): 1 no store, 2 points in stored order, 4 no planes, 8 no fill
 };
 
-constexpr int kColThreads = 1024;
 
 template <typename T> constexpr unsigned col_tile_bytes() { return 16u * (unsigned)sizeof(T); }
 // LDS bytes of a column of `ntiles` tiles (whole 16-tile groups)
-template <typename T> inline size_t col_lds_bytes(unsigned ntiles) { return (size_t)((ntiles + 15u) / 16u) * 16u * col_tile_bytes<T>(); }
+template <typename T> __host__ __device__ inline size_t col_lds_bytes(unsigned ntiles) { return (size_t)((ntiles + 15u) / 16u) * 16u * col_tile_bytes<T>(); }
 
 template <typename T>
 __device__ __forceinline__ unsigned col_tile_base(unsigned tile) {  // LDS byte offset of piece 0 of `tile`
@@ -100,85 +99,252 @@ __device__ __noinline__ T col_slow_point(__amdgpu_buffer_rsrc_t rsrc, unsigned t
   return cubic_regular_node<FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
 }
 
-template <typename T, bool FMA>
-__global__ void __launch_bounds__(kColThreads) k_cubic_column(const CubicColumnArgs<T> a) {
+// ---- nodes with a wave-uniform form -------------------------------------------------------------
+// Within a workgroup all points share the class of dims 0 and 1, and the local sort below puts
+// points of one (dim 2, dim 3) class pair next to each other, so almost every wave is uniform
+// along every dimension: all lanes interior (the reference's Saturation::None arm), all saturated
+// low, or all saturated high, none of them extrapolating linearly.  Each of these is the
+// reference's arm for that case without the selects of the general form (same operations, same
+// bits, multicubic/regular.rs:495-623); anything else takes the general form.
+enum : int { kFormNone = 0, kFormLow = 1, kFormHigh = 2, kFormMixed = 3 };
+
+template <bool FMA, int FORM, typename T>
+__device__ __forceinline__ T col_node(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
+  const T two = (T)2;
+  if constexpr (FORM == kFormNone) {
+    return cubic_regular_node_interior<FMA, T>(v0, v1, v2, v3, d.tt);
+  } else if constexpr (FORM == kFormLow) {   // InsideLow / OutsideLow without linearisation: regular.rs:507-527
+    const T dy = v0 - v1;
+    const T k0 = -((v2 - v0) / two);
+    const T k1 = two * dy - k0;              // == two.mul_add(dy, -k0): 2 dy is exact
+    return hermite<FMA>(d.tt, v1, dy, k0, k1);
+  } else if constexpr (FORM == kFormHigh) {  // InsideHigh / OutsideHigh without linearisation: regular.rs:563-582
+    const T dy = v3 - v2;
+    const T k0 = (v3 - v1) / two;
+    const T k1 = two * dy - k0;
+    return hermite<FMA>(d.tt, v2, dy, k0, k1);
+  } else {
+    return cubic_regular_node<FMA, T>(v0, v1, v2, v3, d);
+  }
+}
+
+template <bool FMA, typename T>
+__device__ __forceinline__ T col_node_rt(int form, T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
+  switch (form) {  // wave-uniform
+    case kFormNone: return col_node<FMA, kFormNone, T>(v0, v1, v2, v3, d);
+    case kFormLow: return col_node<FMA, kFormLow, T>(v0, v1, v2, v3, d);
+    case kFormHigh: return col_node<FMA, kFormHigh, T>(v0, v1, v2, v3, d);
+    default: return col_node<FMA, kFormMixed, T>(v0, v1, v2, v3, d);
+  }
+}
+
+// the wave's form along one dimension (every lane must call this)
+template <typename T>
+__device__ __forceinline__ int col_wave_form(const CubicDimRegular<T>& d) {
+  if (__builtin_amdgcn_ballot_w64(d.linear != 0) != 0) return kFormMixed;
+  if (__builtin_amdgcn_ballot_w64(d.sat != kSatNone) == 0) return kFormNone;
+  if (__builtin_amdgcn_ballot_w64(d.sat != kSatLow) == 0) return kFormLow;
+  if (__builtin_amdgcn_ballot_w64(d.sat != kSatHigh) == 0) return kFormHigh;
+  return kFormMixed;
+}
+
+// All 16 planes of a point out of the LDS column, dim 0 in form F0: dim 2 index = k & 3, dim 3
+// index = k >> 2 (the reference's order, multicubic/regular.rs:368-421).  The tile of the next plane
+// is requested before this plane's nodes are evaluated (PIPE: needs 32 more VGPRs).
+// ALLNONE: every dimension of the wave is interior (the common case): no form tests at all.
+template <typename T, bool FMA, int F0, bool PIPE, bool ALLNONE = false>
+__device__ __forceinline__ T col_reduce(unsigned lds_col, unsigned t0, unsigned n3, const CubicDimRegular<T>* dim, int f1, int f2, int f3) {
+  T s3[4];
+  T cur[16];
+  if constexpr (PIPE) col_take_tile<T>(lds_col, t0, cur);
+#pragma unroll 1
+  for (int k3 = 0; k3 < 4; ++k3) {
+    T s2[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      T nxt[16];
+      if constexpr (PIPE) {
+        // plane after (k2, k3): (k2 + 1, k3), or (0, k3 + 1); behind the last plane this reads one
+        // tile too many (t0 + 4: still inside the column)
+        const unsigned tn = k2 < 3 ? t0 + (unsigned)(k2 + 1) * n3 + (unsigned)k3 : t0 + (unsigned)(k3 + 1);
+        col_take_tile<T>(lds_col, tn, nxt);
+      } else {
+        col_take_tile<T>(lds_col, t0 + (unsigned)k2 * n3 + (unsigned)k3, cur);
+      }
+      T w[4];
+#pragma unroll
+      for (int ej = 0; ej < 4; ++ej) w[ej] = col_node<FMA, F0, T>(cur[ej], cur[4 + ej], cur[8 + ej], cur[12 + ej], dim[0]);
+      if constexpr (ALLNONE) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
+      else s2[k2] = col_node_rt<FMA, T>(f1, w[0], w[1], w[2], w[3], dim[1]);
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[e] = nxt[e];
+      }
+    }
+    if constexpr (ALLNONE) s3[k3] = col_node<FMA, kFormNone, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+    else s3[k3] = col_node_rt<FMA, T>(f2, s2[0], s2[1], s2[2], s2[3], dim[2]);
+  }
+  if constexpr (ALLNONE) return col_node<FMA, kFormNone, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+  else return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
+// class estimate of the local sort (a hint only): 0 = floc <= 0, c = floc, n - 2 = floc >= n - 2
+template <typename T>
+__device__ __forceinline__ unsigned col_class_hint(T x, T start, T rstep, int n) {
+  const T u = (x - start) * rstep;
+  return u >= (T)1 ? (u < (T)(n - 2) ? (unsigned)(int)u : (unsigned)(n - 2)) : 0u;
+}
+
+template <typename T, bool FMA, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<T> a) {
+  constexpr bool PIPE = THREADS <= 768;  // 168+ VGPRs per lane: room for a second tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_col[];
   __shared__ int s_bin;
   __shared__ unsigned s_begin, s_end;
+  __shared__ unsigned s_hist[1024];   // local sort: points per (dim 2, dim 3) class pair, then their first slot
   const unsigned tid = threadIdx.x;
-  // Which (bin, part) is this workgroup?  part_prefix is non-decreasing; [nbins] = number of parts.
-  if (tid == 0) {
+  // Which (bin, part) is this workgroup?  part_prefix is non-decreasing, [nbins] = number of parts:
+  // the bin b with part_prefix[b] <= w < part_prefix[b + 1] — every thread tests one bin (a
+  // single thread bisecting costs ten dependent global loads, ~10 us of the workgroup's ~100).
+  if (tid == 0) s_bin = -1;
+  __syncthreads();
+  {
     const unsigned w = blockIdx.x;
-    int bin = -1;
-    if (w < a.part_prefix[a.nbins]) {
-      int lo = 0, hi = a.nbins;  // largest b with part_prefix[b] <= w
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.part_prefix[mid] <= w) lo = mid; else hi = mid;
+    for (int b = (int)tid; b < a.nbins; b += THREADS) {
+      const unsigned p0 = a.part_prefix[b], p1 = a.part_prefix[b + 1];
+      if (p0 <= w && w < p1) {
+        const unsigned b0 = b ? a.bin_end[b - 1] : 0u;
+        const unsigned b1 = a.bin_end[b];
+        const unsigned cnt = b1 - b0;
+        const unsigned nparts = p1 - p0;
+        const unsigned j = w - p0;
+        const unsigned per = (cnt + nparts - 1) / nparts;  // equal parts (<= the scan's part_points)
+        const unsigned lo_p = b0 + j * per;
+        unsigned hi_p = lo_p + per;
+        if (hi_p > b1) hi_p = b1;
+        s_begin = lo_p < b1 ? lo_p : b1;
+        s_end = hi_p;
+        s_bin = b;
       }
-      bin = lo;
-      const unsigned b0 = bin ? a.bin_end[bin - 1] : 0u;
-      const unsigned b1 = a.bin_end[bin];
-      const unsigned count = b1 - b0;
-      const unsigned nparts = a.part_prefix[bin + 1] - a.part_prefix[bin];
-      const unsigned j = w - a.part_prefix[bin];
-      // equal parts, each a multiple of 64 points except the last
-      unsigned per = (count + nparts - 1) / nparts;
-      per = (per + 63u) & ~63u;
-      const unsigned lo_p = b0 + j * per;
-      unsigned hi_p = lo_p + per;
-      if (hi_p > b1) hi_p = b1;
-      s_begin = lo_p < b1 ? lo_p : b1;
-      s_end = hi_p;
     }
-    s_bin = bin;
   }
+  for (unsigned c = tid; c < 1024u; c += THREADS) s_hist[c] = 0;
   __syncthreads();
   const int bin = s_bin;
   if (bin < 0) return;
   const unsigned begin = s_begin, end = s_end;
   if (begin >= end) return;
+  const unsigned count = end - begin;  // <= kColumnMaxPart
   const unsigned key = (unsigned)(((unsigned long long)(unsigned)bin * a.inv_mult) % (unsigned)a.nbins);
-  const int ci = (int)(key / (unsigned)a.nb1), cj = (int)(key % (unsigned)a.nb1);
-  const unsigned ntiles = (unsigned)a.n[2] * (unsigned)a.n[3];
+  const int c0 = (int)(key / (unsigned)a.nb1), c1 = (int)(key % (unsigned)a.nb1);  // nominal classes of dims 0, 1
+  const int ci = c0 - 1 < 0 ? 0 : (c0 - 1 > a.n[0] - 4 ? a.n[0] - 4 : c0 - 1);      // their footprint cell
+  const int cj = c1 - 1 < 0 ? 0 : (c1 - 1 > a.n[1] - 4 ? a.n[1] - 4 : c1 - 1);
+  const unsigned n3 = (unsigned)a.n[3];
+  const unsigned ntiles = (unsigned)a.n[2] * n3;
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.tiles, a.table_bytes);
   const unsigned cell_off = (unsigned)(ci * (int)a.nbj + cj) * 16u * (unsigned)sizeof(T);  // my cell's tile inside a plane, bytes
   const unsigned ps2 = a.plane_stride[2] * (unsigned)sizeof(T), ps3 = a.plane_stride[3] * (unsigned)sizeof(T);
   const unsigned lds_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_col;
-  // ---- column fill: one LDS-DMA instruction = 1 KiB = RPI 256-byte rows of one 16-tile group;
-  // lane L delivers piece (row0 + (L >> 4)) of tile 16 g + (L & 15).
+  const size_t col_bytes = col_lds_bytes<T>(ntiles);
+  unsigned short* perm = reinterpret_cast<unsigned short*>(smem_col + col_bytes);  // local order: slot -> point of the part
+  typedef T RV __attribute__((ext_vector_type(4)));
+  const RV* __restrict__ recs = reinterpret_cast<const RV*>(a.records) + begin;
+
+  // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram.
+  // (Loads first, then the column fill is issued, then they are used: the fill overlaps this.)
+  constexpr int kMaxMine = (int)((kColumnMaxPart + THREADS - 1) / THREADS);
+  const bool lsort = !(a.ablate & (2 | 16));  // kernel-uniform: probes 2 / 16 take the points in stored order
+  unsigned short cls23[kMaxMine];
   {
-    constexpr unsigned PP = (unsigned)sizeof(T);  // pieces (rows) per group
-    constexpr unsigned IPG = PP / 4u;             // DMA instructions per group (4 rows each)
-    const unsigned ngroups = (ntiles + 15u) / 16u;
-    const unsigned ninstr = ngroups * IPG;
-    const unsigned wave = tid >> 6, wl = tid & 63u;
-    typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    for (unsigned q = wave; q < ninstr; q += kColThreads / 64) {
-      const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
-      const unsigned tile = g * 16u + (wl & 15u);
-      const unsigned piece = r0 + (wl >> 4);
-      unsigned src = 0xFFFFFFF0u;  // out of range: the descriptor's check turns it into zeros
-      if (tile < ntiles) {
-        const unsigned k = tile / (unsigned)a.n[3], l = tile - k * (unsigned)a.n[3];
-        src = k * ps2 + l * ps3 + cell_off + piece * 16u;
+    T x2[kMaxMine], x3[kMaxMine];
+#pragma unroll
+    for (int m = 0; m < kMaxMine; ++m) {
+      const unsigned q = (unsigned)m * THREADS + tid;
+      x2[m] = x3[m] = (T)0;
+      if (lsort) {
+        const RV r = q < count ? recs[q] : recs[0];
+        x2[m] = r[2];
+        x3[m] = r[3];
       }
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + g * (16u * col_tile_bytes<T>()) + r0 * 256u));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, src, 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- column fill: one LDS-DMA instruction = 1 KiB = four 256-byte rows of one 16-tile group;
+    // lane L delivers piece (row0 + (L >> 4)) of tile 16 g + (L & 15).
+    {
+      constexpr unsigned PP = (unsigned)sizeof(T);  // pieces (rows) per group
+      constexpr unsigned IPG = PP / 4u;             // DMA instructions per group (4 rows each)
+      const unsigned ngroups = (ntiles + 15u) / 16u;
+      const unsigned ninstr = ngroups * IPG;
+      const unsigned wave = tid >> 6, wl = tid & 63u;
+      typedef __attribute__((address_space(3))) unsigned char lds_byte;
+      for (unsigned q = wave; q < ((a.ablate & 8) ? 0u : ninstr); q += THREADS / 64) {
+        const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
+        const unsigned tile = g * 16u + (wl & 15u);
+        const unsigned piece = r0 + (wl >> 4);
+        unsigned src = 0xFFFFFFF0u;  // out of range: the descriptor's check turns it into zeros
+        if (tile < ntiles) {
+          const unsigned k = tile / n3, l = tile - k * n3;
+          src = k * ps2 + l * ps3 + cell_off + piece * 16u;
+        }
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + g * (16u * col_tile_bytes<T>()) + r0 * 256u));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, src, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < kMaxMine; ++m) {
+      const unsigned q = (unsigned)m * THREADS + tid;
+      const unsigned h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
+      const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
+      const unsigned c = h2 * (unsigned)(a.n[3] - 1) + h3;  // < (n2 - 1)(n3 - 1) <= 1024
+      cls23[m] = (unsigned short)c;
+      if (lsort && q < count) atomicAdd(&s_hist[c], 1u);
+    }
   }
   __syncthreads();
-  // ---- the part's points
-  for (unsigned p0 = begin; p0 < end; p0 += kColThreads) {
-    const unsigned p = p0 + tid;
-    const bool live = p < end;
+  // exclusive scan of the 1024 counters: CPT consecutive counters per thread, wave scan, wave totals
+  {
+    constexpr int CPT = (1024 + THREADS - 1) / THREADS;
+    unsigned mine[CPT];
+    unsigned sum = 0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) { mine[c] = tid * CPT + c < 1024u ? s_hist[tid * CPT + c] : 0u; sum += mine[c]; }
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = (unsigned)__shfl_up((int)incl, off);
+      if ((tid & 63u) >= (unsigned)off) incl += up;
+    }
+    __shared__ unsigned s_wave[THREADS / 64];
+    if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (unsigned w = 0; w < (tid >> 6); ++w) run += s_wave[w];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) { if (tid * CPT + c < 1024u) s_hist[tid * CPT + c] = run; run += mine[c]; }
+  }
+  __syncthreads();
+  // pass 2: slots
+#pragma unroll
+  for (int m = 0; m < kMaxMine; ++m) {
+    const unsigned q = (unsigned)m * THREADS + tid;
+    if (lsort && q < count) perm[atomicAdd(&s_hist[cls23[m]], 1u)] = (unsigned short)q;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the column has landed
+  __syncthreads();
+
+  // ---- the part's points in local order
+  for (unsigned j0 = 0; j0 < count; j0 += THREADS) {
+    const unsigned j = j0 + tid;
+    const bool live = j < count;
+    // dead lanes (the last row's tail) redo the part's last point: they keep their wave uniform
+    unsigned q = live ? j : count - 1;
+    if (lsort) q = perm[q];  // (never read when it was not built)
+    const RV r = recs[q];
     CubicDimRegular<T> dim[4];
     int loc[4];
     bool ok = true;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const T x = live ? stream_load(a.obs[d] + p) : a.start[d];
+      const T x = r[d];
       T floc;
       ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
       ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
@@ -198,30 +364,19 @@ __global__ void __launch_bounds__(kColThreads) k_cubic_column(const CubicColumnA
       dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
       loc[d] = l;
     }
-    // the original index is needed for a scattered store and for reporting a failing point
-    const unsigned orig = (live && (!a.res_sorted || !ok)) ? a.index[p] : 0u;
-    if (!ok && live) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
-    unsigned interior = 0;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
-    // 16 planes out of LDS: dim 2 index = k & 3, dim 3 index = k >> 2 (the reference's order)
-    const unsigned t0 = (unsigned)loc[2] * (unsigned)a.n[3] + (unsigned)loc[3];
-    T s2[4], s3[4];
-    T res = (T)0;
-    // One tile in registers at a time: with four waves per SIMD the other waves' arithmetic covers
-    // this wave's LDS latency (a second tile buffer costs 32 VGPRs, and at the 128 a 1024-thread
-    // workgroup may use, spills).
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      T cur[16];
-      col_take_tile<T>(lds_col, t0 + (unsigned)(k & 3) * (unsigned)a.n[3] + (unsigned)(k >> 2), cur);
-      const T r01 = reduce_tile<T, false, FMA>(cur, dim, interior);
-      s2[k & 3] = r01;
-      if ((k & 3) == 3) {
-        s3[k >> 2] = cubic_regular_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
-        if (k == 15) res = cubic_regular_node<FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
-      }
+    const int f0 = col_wave_form<T>(dim[0]), f1 = col_wave_form<T>(dim[1]);
+    const int f2 = col_wave_form<T>(dim[2]), f3 = col_wave_form<T>(dim[3]);
+    const unsigned t0 = (unsigned)loc[2] * n3 + (unsigned)loc[3];
+    T res = dim[0].tt + dim[1].tt + dim[2].tt + dim[3].tt;
+    if (!(a.ablate & 4)) {
+    if ((f0 | f1 | f2 | f3) == kFormNone) res = col_reduce<T, FMA, kFormNone, PIPE, true>(lds_col, t0, n3, dim, f1, f2, f3);
+    else
+    switch (f0) {  // wave-uniform
+      case kFormNone: res = col_reduce<T, FMA, kFormNone, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+      case kFormLow: res = col_reduce<T, FMA, kFormLow, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+      case kFormHigh: res = col_reduce<T, FMA, kFormHigh, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+      default: res = col_reduce<T, FMA, kFormMixed, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+    }
     }
     // not my cell (the sort's estimate and the exact cell disagree on a boundary): from the table
     if (live && (loc[0] != ci || loc[1] != cj)) {
@@ -234,20 +389,12 @@ __global__ void __launch_bounds__(kColThreads) k_cubic_column(const CubicColumnA
       for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
       res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
     }
-    if (live) {
-      if (a.res_sorted) a.res_sorted[p] = res;
-      else stream_store(a.out + orig, res);
+    if (live && (!(a.ablate & 1) || res == (T)12345.678)) {
+      const unsigned orig = a.index[begin + q];
+      if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
+      stream_store(a.out + orig, res);
     }
   }
-}
-
-// out[i] = res[rank[i]]: the un-permutation of results written in sorted order.  `rank` is read
-// coalesced, `res` in short runs (the points of one 4096-point chunk of the sort sit in one run
-// per bin), `out` is written coalesced — full lines instead of 8-byte scattered stores.
-template <typename T>
-__global__ void __launch_bounds__(kBlock) k_unpermute(const T* __restrict__ res, const unsigned* __restrict__ rank, T* __restrict__ out, size_t npts) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < npts) stream_store(out + i, res[rank[i]]);
 }
 
 }  // namespace interpn

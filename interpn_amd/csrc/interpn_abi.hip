@@ -677,8 +677,10 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"deal", &c.deal, 0, 1},
       {"bin_slice_log2", &c.bin_slice_log2, 16, 27},
       {"column", &c.column, -1, 1},
-      {"unpermute", &c.unpermute, 0, 1},
       {"column_part", &c.column_part, 0, 1 << 20},
+      {"column_threads", &c.column_threads, 512, 1024},
+      {"column_ablate", &c.column_ablate, 0, 31},
+      {"bin_scramble", &c.bin_scramble, 0, 1},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -707,7 +709,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "unpermute", "column_part"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -1432,11 +1434,19 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   // evaluated out of LDS instead of 16 L2 lines per point.
   bool column = g.cfg.column != 0 && (second || main11) && cubic_column_applies(*use);
   {
+    // automatic mode: a workgroup's rows of 768 lanes must be mostly full and its column fill
+    // amortised — from about 3000 points per (class pair) bin on (32^4: 4e6 points 0.53 against
+    // 0.63 ms, 2e6 points 0.35 against 0.30; profiles/r03_cfg4_column_sizes.txt)
+    const size_t slice_max0 = bin_slice_points(g);
+    const size_t per_slice = npoints < slice_max0 ? npoints : slice_max0;
+    if (g.cfg.column < 0 && per_slice < (size_t)3072 * (size_t)(g.n[0] - 1) * (size_t)(g.n[1] - 1)) column = false;
+  }
+  {
     unsigned nbt[2];
     size_t tbytes = 0;  // of the table the sorted points will be evaluated on
     if (second || main11) cubic_tile_geometry(g, 1, 1, nbt, &tbytes);
     else cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nbt, &tbytes);
-    if (column && !make_bin_plan(g, tbytes, &plan, /*exact_cells=*/true)) column = false;
+    if (column && !make_bin_plan(g, tbytes, &plan, /*classes=*/true)) column = false;
     if (!column && !make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1457,21 +1467,21 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     const unsigned* index = nullptr;
     char* dst = static_cast<char*>(out) + begin * elem;
     if (column) {
-      // parts of about count / (6 per CU) points: the dispatcher hands them to the CUs as they free up
-      size_t q = count / ((size_t)g.cfg.num_cus * 6) + 1;
+      // parts of about count / (3 per CU) points (the dispatcher hands them to the CUs as they free
+      // up), as large as the LDS allows: a part pays for its column fill and its local sort once, and
+      // its last 1024-lane row is the only partly filled one
+      size_t q = count / ((size_t)g.cfg.num_cus * 3) + 1;
       q = (q + 1023) / 1024 * 1024;
-      q = q < 2048 ? 2048 : (q > 16384 ? 16384 : q);
-      if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part;
+      q = q < 2048 ? 2048 : (q > kColumnMaxPart ? kColumnMaxPart : q);
+      if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part < kColumnMaxPart ? (size_t)g.cfg.column_part : kColumnMaxPart;
       const size_t max_parts = count / q + (size_t)plan.nbins + 1;
       BinExtras extras;
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q);
       if (err != hipSuccess) break;
       if (g.dtype == kF64)
-        err = launch_cubic_column<double>(*use, plan, reinterpret_cast<const double* const*>(sorted), index, extras, g.cfg.unpermute != 0,
-                                          reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
+        err = launch_cubic_column<double>(*use, plan, extras, index, reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
       else
-        err = launch_cubic_column<float>(*use, plan, reinterpret_cast<const float* const*>(sorted), index, extras, g.cfg.unpermute != 0,
-                                         reinterpret_cast<float*>(dst), count, max_parts, h->first_bad, begin, stream);
+        err = launch_cubic_column<float>(*use, plan, extras, index, reinterpret_cast<float*>(dst), count, max_parts, h->first_bad, begin, stream);
       continue;
     }
     err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream);

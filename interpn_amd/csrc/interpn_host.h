@@ -31,8 +31,10 @@ struct LaunchConfig {
   int deal = 1;            // binned evaluation: deal the sorted points out to the XCDs (cubic_brick.h `eighth`)
   int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
   int column = -1;         // binned 4-D multicubic on regular grids: evaluate sorted points out of an LDS-resident table column (-1/1 where it applies, 0 never)
-  int unpermute = 0;       // column evaluation: 1 = results written in sorted order + an un-permutation pass, 0 = scattered 8-byte stores (measured faster: 1.39 vs 1.44 ms, profiles/r03_cfg4_column_v1.txt)
   int column_part = 0;     // column evaluation: points per workgroup (0 = automatic)
+  int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
+  int column_ablate = 0;   // column evaluation, timing probes only (results wrong): 1 no store, 2 stored order, 4 no planes, 8 no fill
+  int column_threads = 768; // column evaluation: threads per workgroup (768 = three waves per SIMD with 168 VGPRs, planes software-pipelined: 1.10 ms for cfg4; 1024: 1.17; 512: 1.18)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
 };
 
@@ -193,6 +195,11 @@ struct BinPlan {
   int nb1 = 0;        // bins along dim 1
   int mult = 1;       // bins are visited in the order key * mult mod nbins (k_bin_points.hip::bin_key)
   int inv_mult = 1;   // its inverse mod nbins
+  // 1: a bin is a pair of saturation CLASSES of dims 0, 1 on a regular grid (class 0 = floc <= 0,
+  // c = floc for interior cells, n - 2 = floc >= n - 2; ncell = n - 1 classes per dim, no shift):
+  // what the column kernel sorts by, so that a whole bin shares its (i, j) footprint AND the form
+  // of its dim-0 / dim-1 nodes.  0: footprint cells, coarsened by `shift`.
+  int classes = 0;
   int ncell[2] = {0, 0};   // footprint origins per dim: n - 3
   int shift[2] = {0, 0};   // bin = cell >> shift
   double start[2] = {0, 0};
@@ -200,33 +207,31 @@ struct BinPlan {
 };
 constexpr int kMaxBins = 1024;  // one bin per thread of the scatter kernel's scan; 16-bit keys
 constexpr size_t kBinSlicePoints = (size_t)1 << 25;  // points sorted and evaluated per slice (bounds the scratch)
-// `exact_cells`: one bin per (i, j) cell of dims 0, 1 (what the column evaluation needs); false when
-// they do not fit kMaxBins.
-bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool exact_cells = false);
+// `classes`: one bin per pair of saturation classes of dims 0, 1 (what the column evaluation
+// needs; regular grids); false when they do not fit kMaxBins.
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool classes = false);
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points);
-// What the column evaluation (cubic_column.h) needs from the sort besides the sorted points.
+// What the column evaluation (cubic_column.h) gets from the sort.
 struct BinExtras {
-  const unsigned* rank = nullptr;         // rank[i] = sorted position of point i of the slice
-  void* res_sorted = nullptr;             // room for the slice's results in sorted order
+  const void* records = nullptr;          // the slice's points in bin order, one N-element record each
   const unsigned* bin_end = nullptr;      // end of every bin in sorted order
   const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
 };
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
-// original indices (within the slice).  `extras` (4-D only): also the items above, with bins cut
-// into parts of at most `part_points` points.
+// original indices (within the slice).  `extras` (4-D only): the sorted points are written as
+// records instead, and the bins are cut into parts of at most `part_points` points.
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
                       const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras = nullptr,
                       unsigned part_points = 0);
 
 // Column evaluation of sorted 4-D multicubic points on a regular grid (cubic_column.h): does it
-// apply to this grid (LDS capacity, one bin per cell), and the launch.  `res_sorted` non-null:
-// results are written in sorted order and un-permuted into `out` by a second kernel; null: every
-// result goes straight to out[index[k]].
+// apply to this grid (LDS capacity, classes fit the bins), and the launch.
 bool cubic_column_applies(const GridDesc& g);
+constexpr unsigned kColumnMaxPart = 12288;  // points per workgroup at most (16-bit local order: 24 KiB of LDS beside the column)
 template <typename T>
-hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const T* const* sorted_obs, const unsigned* index,
-                               const BinExtras& extras, bool unpermute, T* out, size_t npts, size_t max_parts,
-                               unsigned long long* first_bad, size_t index_base, hipStream_t stream);
+hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
+                               T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,
+                               hipStream_t stream);
 
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>

@@ -17,6 +17,7 @@ namespace {
 constexpr int kHistIters = 32;                             // histogram: 256-lane rows per workgroup
 constexpr size_t kHistChunk = (size_t)kBlock * kHistIters;
 constexpr size_t kBinChunk = 4096;                         // scatter: points per workgroup (sorted in LDS)
+constexpr size_t kRecChunk = 8192;                         // ... when it writes records for the column kernel (longer runs per bin)
 // totals[kMaxBins] | cursor[kMaxBins] | part_prefix[kMaxBins + 1] (+ padding)
 constexpr size_t kCounterBytes = (size_t)4 * kMaxBins * sizeof(unsigned);
 
@@ -28,6 +29,8 @@ struct BinParams {
   int nb1;
   int nbins;
   int mult;
+  int classes;  // 1: bins are saturation classes (BinPlan::classes), 0: footprint cells >> shift
+  int scramble; // testing: every 5th point is put into the NEXT bin (the key is only a locality hint: results must not change)
 };
 
 // ~ footprint origin: clamp(floor((x - start) / step) - 1, 0, n - 4); NaN -> 0.  A locality hint
@@ -37,10 +40,25 @@ __device__ __forceinline__ int bin_cell(double x, double start, double scale, in
   return u >= 1.0 ? (u < (double)ncell ? (int)u - 1 : ncell - 1) : 0;
 }
 
+// ~ class of a coordinate on a regular axis of n points (`nclass` = n - 1 classes):
+// 0 = floc <= 0 (saturated low, inside or outside), c = floc for 1 <= floc <= n - 3 (interior),
+// n - 2 = floc >= n - 2 (saturated high); floc = floor((x - start) / step).  Footprint cell =
+// clamp(class - 1, 0, n - 4).  The column kernel (cubic_column.h) re-derives the exact class.
+__device__ __forceinline__ int bin_class(double x, double start, double scale, int nclass) {
+  const double u = (x - start) * scale;
+  return u >= 1.0 ? (u < (double)(nclass - 1) ? (int)u : nclass - 1) : 0;
+}
+
 template <typename T>
 __device__ __forceinline__ int bin_key(const BinParams& p, T x0, T x1) {
-  const int c0 = bin_cell((double)x0, p.start[0], p.scale[0], p.ncell[0]) >> p.shift[0];
-  const int c1 = bin_cell((double)x1, p.start[1], p.scale[1], p.ncell[1]) >> p.shift[1];
+  int c0, c1;
+  if (p.classes) {
+    c0 = bin_class((double)x0, p.start[0], p.scale[0], p.ncell[0]);
+    c1 = bin_class((double)x1, p.start[1], p.scale[1], p.ncell[1]);
+  } else {
+    c0 = bin_cell((double)x0, p.start[0], p.scale[0], p.ncell[0]) >> p.shift[0];
+    c1 = bin_cell((double)x1, p.start[1], p.scale[1], p.ncell[1]) >> p.shift[1];
+  }
   // Bins are visited in a scrambled order (key * mult mod nbins, mult coprime with nbins): each
   // bin is its own unit of locality (a tile position's planes), so any order of bins serves the
   // caches equally, but contiguous stretches of the sorted points — what one XCD gets when they
@@ -48,6 +66,14 @@ __device__ __forceinline__ int bin_key(const BinParams& p, T x0, T x1) {
   // evaluation costs differ on rectilinear grids (saturation branches): without the scramble the
   // XCDs holding the first and last rows of cells finished 15 % late.
   return (c0 * p.nb1 + c1) * p.mult % p.nbins;
+}
+
+// the key the sort uses for point i (testing option `scramble`: see BinParams)
+template <typename T>
+__device__ __forceinline__ int bin_key_at(const BinParams& p, T x0, T x1, size_t i) {
+  int k = bin_key<T>(p, x0, x1);
+  if (p.scramble && i % 5 == 0) k = k + 1 < p.nbins ? k + 1 : 0;
+  return k;
 }
 
 template <typename T>
@@ -59,7 +85,7 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
   const size_t first = (size_t)blockIdx.x * kHistChunk;
   for (int it = 0; it < kHistIters; ++it) {
     const size_t i = first + (size_t)it * kBlock + threadIdx.x;
-    if (i < npts) atomicAdd(&hist[bin_key<T>(p, x0[i], x1[i])], 1u);
+    if (i < npts) atomicAdd(&hist[bin_key_at<T>(p, x0[i], x1[i], i)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < p.nbins; b += kBlock)
@@ -99,7 +125,7 @@ struct ScatterArgs {
   const T* obs[N];
   T* binned[N];
   unsigned* index;
-  unsigned* rank;  // optional: rank[i] = sorted position of point i (the inverse of `index`)
+  T* records;      // optional: the sorted points as N-element records (array of structures) instead of `binned`
   unsigned* cursor;
   size_t npts;
   BinParams p;
@@ -110,37 +136,37 @@ struct ScatterArgs {
 // the first is used: with 256 threads and one load in flight per lane the kernel was bound by
 // memory latency (0.57..0.73 ms per 1e7 4-D points).
 constexpr int kScatThreads = 1024;
-constexpr int kScatIters = (int)(kBinChunk / kScatThreads);
 
-template <typename T, int N>
+// CH = points per workgroup.
+template <typename T, int N, int CH>
 __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<T, N> a) {
-  static_assert(kMaxBins <= kScatThreads && kMaxBins <= 65536 && kBinChunk <= 65536, "one bin per thread in the scan; keys and local indices are 16-bit");
+  static_assert(kMaxBins <= kScatThreads && kMaxBins <= 65536 && CH <= 65536, "one bin per thread in the scan; keys and local indices are 16-bit");
+  constexpr int kIters = CH / kScatThreads;
   __shared__ unsigned fill[kMaxBins];
   __shared__ unsigned lstart[kMaxBins];   // first local position of a bin inside this chunk
   __shared__ unsigned base[kMaxBins];     // first global position of this chunk's run in a bin
-  __shared__ unsigned short keys[kBinChunk];       // key of local point l
-  __shared__ unsigned short sorted_src[kBinChunk]; // local point at sorted position j
-  __shared__ unsigned short sorted_key[kBinChunk];
-  __shared__ unsigned lpos32[kBinChunk];            // sorted position of local point l (rank output)
+  __shared__ unsigned short keys[CH];       // key of local point l
+  __shared__ unsigned short sorted_src[CH]; // local point at sorted position j
+  __shared__ unsigned short sorted_key[CH];
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
   if (tid < kMaxBins) fill[tid] = 0;
   __syncthreads();
-  const size_t first = (size_t)blockIdx.x * kBinChunk;
-  const unsigned count = (unsigned)((a.npts - first) < kBinChunk ? (a.npts - first) : kBinChunk);
+  const size_t first = (size_t)blockIdx.x * CH;
+  const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
   {
-    T x0[kScatIters], x1[kScatIters];
+    T x0[kIters], x1[kIters];
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it) {
+    for (int it = 0; it < kIters; ++it) {
       const unsigned l = (unsigned)it * kScatThreads + tid;
       x0[it] = l < count ? a.obs[0][first + l] : (T)0;
       x1[it] = l < count ? a.obs[1][first + l] : (T)0;
     }
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it) {
+    for (int it = 0; it < kIters; ++it) {
       const unsigned l = (unsigned)it * kScatThreads + tid;
       if (l < count) {
-        const int key = bin_key<T>(a.p, x0[it], x1[it]);
+        const int key = bin_key_at<T>(a.p, x0[it], x1[it], first + l);
         keys[l] = (unsigned short)key;
         atomicAdd(&fill[key], 1u);
       }
@@ -166,7 +192,7 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < kScatIters; ++it) {
+  for (int it = 0; it < kIters; ++it) {
     const unsigned l = (unsigned)it * kScatThreads + tid;
     if (l < count) {
       const unsigned key = keys[l];
@@ -176,41 +202,88 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
     }
   }
   __syncthreads();
-  unsigned pos[kScatIters];
-  size_t src[kScatIters];
+  unsigned pos[kIters];
+  size_t src[kIters];
 #pragma unroll
-  for (int it = 0; it < kScatIters; ++it) {
+  for (int it = 0; it < kIters; ++it) {
     const unsigned j = (unsigned)it * kScatThreads + tid;
     const unsigned jj = j < count ? j : 0u;
     const unsigned key = sorted_key[jj];
     src[it] = first + sorted_src[jj];
     pos[it] = base[key] + (jj - lstart[key]);
   }
+  {
 #pragma unroll
-  for (int d = 0; d < N; ++d) {
-    T v[kScatIters];
+    for (int d = 0; d < N; ++d) {
+      T v[kIters];
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it) v[it] = ((unsigned)it * kScatThreads + tid) < count ? a.obs[d][src[it]] : (T)0;
+      for (int it = 0; it < kIters; ++it) v[it] = ((unsigned)it * kScatThreads + tid) < count ? a.obs[d][src[it]] : (T)0;
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it)
-      if (((unsigned)it * kScatThreads + tid) < count) a.binned[d][pos[it]] = v[it];
+      for (int it = 0; it < kIters; ++it)
+        if (((unsigned)it * kScatThreads + tid) < count) a.binned[d][pos[it]] = v[it];
+    }
   }
 #pragma unroll
-  for (int it = 0; it < kScatIters; ++it)
+  for (int it = 0; it < kIters; ++it)
     if (((unsigned)it * kScatThreads + tid) < count) a.index[pos[it]] = (unsigned)src[it];
-  if (a.rank) {
-    // rank[] is indexed by ORIGINAL position: hand the sorted positions over through LDS so that
-    // consecutive lanes write consecutive words.
+}
+
+// Records form of the scatter (column evaluation): no sorting inside the workgroup at all.  Every
+// thread keeps its points in registers (read coalesced, all N coordinates), takes a rank inside
+// (workgroup, bin) from the LDS histogram's returning atomic, one thread per bin reserves the
+// workgroup's run in that bin with one global atomic, and every point is then stored as ONE
+// N-element record at run start + rank.  The 32-byte records of a run are written by different
+// waves of the same workgroup within microseconds of each other, so the L2 (one XCD's: a workgroup
+// lives on one XCD) merges them into whole lines before they leave.  Two barriers, no gathers.
+template <typename T, int N, int CH>
+__global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const ScatterArgs<T, N> a) {
+  static_assert(kMaxBins <= kScatThreads, "one bin per thread when the runs are reserved");
+  constexpr int kIters = CH / kScatThreads;
+  __shared__ unsigned fill[kMaxBins];
+  __shared__ unsigned base[kMaxBins];
+  const int nbins = a.p.nbins;
+  const unsigned tid = threadIdx.x;
+  if (tid < kMaxBins) fill[tid] = 0;
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * CH;
+  const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
+  T x[kIters][N];
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it) {
-      const unsigned j = (unsigned)it * kScatThreads + tid;
-      if (j < count) lpos32[sorted_src[j]] = pos[it];
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+#pragma unroll
+    for (int d = 0; d < N; ++d) x[it][d] = l < count ? stream_load(a.obs[d] + first + l) : (T)0;
+  }
+  unsigned short key[kIters], rank[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+    key[it] = 0;
+    rank[it] = 0;
+    if (l < count) {
+      const int k = bin_key_at<T>(a.p, x[it][0], x[it][1], first + l);
+      key[it] = (unsigned short)k;
+      rank[it] = (unsigned short)atomicAdd(&fill[k], 1u);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < kMaxBins) {
+    const unsigned mine = fill[tid];
+    base[tid] = (mine && (int)tid < nbins) ? atomicAdd(&a.cursor[tid], mine) : 0u;  // one run per non-empty bin
+  }
+  __syncthreads();
+  typedef T RV __attribute__((ext_vector_type(N)));
+  RV* __restrict__ recs = reinterpret_cast<RV*>(a.records);
 #pragma unroll
-    for (int it = 0; it < kScatIters; ++it) {
-      const unsigned l = (unsigned)it * kScatThreads + tid;
-      if (l < count) a.rank[first + l] = lpos32[l];
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+    if (l < count) {
+      const unsigned pos = base[key[it]] + rank[it];
+      RV r;
+#pragma unroll
+      for (int d = 0; d < N; ++d) r[d] = x[it][d];
+      recs[pos] = r;
+      a.index[pos] = (unsigned)(first + l);
     }
   }
 }
@@ -228,19 +301,16 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   unsigned* idx = reinterpret_cast<unsigned*>(base + off);
   off += align_up(npts * sizeof(unsigned), 256);
   ScatterArgs<T, N> a;
+  a.records = nullptr;
   for (int d = 0; d < N; ++d) {
     a.obs[d] = static_cast<const T*>(obs[d]);
     a.binned[d] = reinterpret_cast<T*>(base + off);
     binned_obs[d] = a.binned[d];
     off += align_up(npts * sizeof(T), 256);
   }
-  a.rank = nullptr;
-  if (extras) {  // column evaluation: rank (original -> sorted) and a sorted-order result array
-    a.rank = reinterpret_cast<unsigned*>(base + off);
-    off += align_up(npts * sizeof(unsigned), 256);
-    extras->rank = a.rank;
-    extras->res_sorted = base + off;
-    off += align_up(npts * sizeof(T), 256);
+  if (extras) {  // column evaluation: the same room holds the points as N-element records
+    a.records = a.binned[0];
+    extras->records = a.records;
     extras->bin_end = cursor;  // after the scatter every cursor stands at the end of its bin
     extras->part_prefix = part_prefix;
   }
@@ -251,21 +321,32 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   *index = idx;
   hipError_t e = hipMemsetAsync(totals, 0, kMaxBins * sizeof(unsigned), stream);
   if (e != hipSuccess) return e;
-  const unsigned blocks = (unsigned)((npts + kBinChunk - 1) / kBinChunk);
   const unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
   hipLaunchKernelGGL(k_bin_hist<T>, dim3(hblocks), dim3(kBlock), 0, stream, a.obs[0], a.obs[1], npts, p, totals);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points);
-  hipLaunchKernelGGL((k_bin_scatter<T, N>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
+  if (extras) {
+    if constexpr (N == 4) {
+      const unsigned blocks = (unsigned)((npts + kRecChunk - 1) / kRecChunk);
+      hipLaunchKernelGGL((k_bin_scatter_records<T, N, (int)kRecChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else {
+    const unsigned blocks = (unsigned)((npts + kBinChunk - 1) / kBinChunk);
+    hipLaunchKernelGGL((k_bin_scatter<T, N, (int)kBinChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
 }  // namespace
 
-bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool exact_cells) {
+bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool classes) {
   if (g.method != kCubic || g.ndims < 2) return false;
   BinPlan p;
+  p.classes = classes ? 1 : 0;
+  if (classes && g.kind != kRegular) return false;
   for (int d = 0; d < 2; ++d) {
-    p.ncell[d] = g.n[d] - 3;
+    p.ncell[d] = classes ? g.n[d] - 1 : g.n[d] - 3;
     if (p.ncell[d] < 1) return false;
     if (g.kind == kRegular) {
       p.start[d] = g.start[d];
@@ -283,7 +364,7 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool ex
   // -> 529; never fewer than 64 (balance across the XCDs), never more than kMaxBins.
   long long target = (long long)(table_bytes >> 19);
   target = target < 64 ? 64 : (target > kMaxBins ? kMaxBins : target);
-  if (exact_cells) {  // one bin per (i, j) cell (column evaluation): only if they all fit
+  if (classes) {  // one bin per pair of saturation classes (column evaluation): only if they all fit
     if ((long long)p.ncell[0] * p.ncell[1] > kMaxBins) return false;
     target = kMaxBins;
   }
@@ -310,8 +391,6 @@ size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points) {
   const size_t elem = g.dtype == kF64 ? 8 : 4;
   size_t b = align_up(kCounterBytes, 256) + align_up(slice_points * sizeof(unsigned), 256) +
              (size_t)g.ndims * align_up(slice_points * elem, 256);
-  // column evaluation (4-D): rank + results in sorted order
-  if (g.ndims == 4) b += align_up(slice_points * sizeof(unsigned), 256) + align_up(slice_points * elem, 256);
   return b;
 }
 
@@ -330,6 +409,8 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.nb1 = plan.nb1;
   p.nbins = plan.nbins;
   p.mult = plan.mult;
+  p.classes = plan.classes;
+  p.scramble = g.cfg.bin_scramble;
 #define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream)
   if (g.dtype == kF64) {
     switch (g.ndims) {

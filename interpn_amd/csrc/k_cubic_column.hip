@@ -4,7 +4,9 @@
 namespace interpn {
 
 namespace {
-constexpr size_t kColumnLdsMax = 144 * 1024;  // of the CU's 160 KiB; the kernel's static words and the runtime keep the rest
+constexpr size_t kColumnBytesMax = 128 * 1024;                 // the column itself
+constexpr size_t kColumnPermBytes = 2 * (size_t)kColumnMaxPart;  // local order of a part (16-bit)
+constexpr size_t kColumnLdsMax = kColumnBytesMax + kColumnPermBytes;  // dynamic LDS at most (+ ~4.3 KiB static: 148.3 of the CU's 160 KiB)
 
 template <typename T>
 size_t column_bytes(const GridDesc& g) { return col_lds_bytes<T>((unsigned)g.n[2] * (unsigned)g.n[3]); }
@@ -15,15 +17,16 @@ bool cubic_column_applies(const GridDesc& g) {
   // the fully overlapped tile table is what the column is filled from
   const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
   if (!main11 && !g.bricks11) return false;
-  if ((long long)(g.n[0] - 3) * (g.n[1] - 3) > kMaxBins) return false;  // one bin per (i, j) cell
+  if ((long long)(g.n[0] - 1) * (g.n[1] - 1) > kMaxBins) return false;  // one bin per class pair of dims 0, 1
+  if ((long long)(g.n[2] - 1) * (g.n[3] - 1) > 1024) return false;      // the workgroup's local sort: class pairs of dims 2, 3
   const size_t col = g.dtype == kF64 ? column_bytes<double>(g) : column_bytes<float>(g);
-  return col <= kColumnLdsMax;
+  return col <= kColumnBytesMax;
 }
 
 template <typename T>
-hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const T* const* sorted_obs, const unsigned* index,
-                               const BinExtras& extras, bool unpermute, T* out, size_t npts, size_t max_parts,
-                               unsigned long long* first_bad, size_t index_base, hipStream_t stream) {
+hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
+                               T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,
+                               hipStream_t stream) {
   CubicColumnArgs<T> a;
   a.tiles = static_cast<const T*>(g.bricks);
   {
@@ -38,14 +41,14 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const T* 
     a.plane_stride[2] = acc * (unsigned)g.n[3];
   }
   for (int d = 0; d < 4; ++d) {
-    a.obs[d] = sorted_obs[d];
     a.start[d] = (T)g.start[d];
     a.step[d] = (T)g.step[d];
+    a.rstep[d] = (T)(1.0 / g.step[d]);
     a.n[d] = g.n[d];
   }
+  a.records = static_cast<const T*>(extras.records);
   a.index = index;
   a.out = out;
-  a.res_sorted = unpermute ? static_cast<T*>(extras.res_sorted) : nullptr;
   a.first_bad = first_bad;
   a.index_base = index_base;
   a.npts = npts;
@@ -54,35 +57,31 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const T* 
   a.nbins = plan.nbins;
   a.nb1 = plan.nb1;
   a.inv_mult = (unsigned)plan.inv_mult;
-  a.part_points = 0;
   a.linearize = g.linearize;
-  const size_t lds = column_bytes<T>(g);
+  a.ablate = g.cfg.column_ablate;
+  const size_t lds = column_bytes<T>(g) + kColumnPermBytes;
   // More than 64 KiB of dynamic LDS needs the opt-in, once per kernel and device.
   auto prepare = [&](auto kernel) -> hipError_t {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColumnLdsMax);
   };
-  hipError_t e;
-  if (g.fma) {
-    e = prepare(k_cubic_column<T, true>);
-    if (e != hipSuccess) return e;
-    g.tag.set("k_cubic_column", {1}, 0b1u);
-    hipLaunchKernelGGL((k_cubic_column<T, true>), dim3((unsigned)max_parts), dim3(kColThreads), lds, stream, a);
-  } else {
-    e = prepare(k_cubic_column<T, false>);
-    if (e != hipSuccess) return e;
-    g.tag.set("k_cubic_column", {0}, 0b1u);
-    hipLaunchKernelGGL((k_cubic_column<T, false>), dim3((unsigned)max_parts), dim3(kColThreads), lds, stream, a);
-  }
-  e = hipGetLastError();
-  if (e != hipSuccess || !unpermute) return e;
-  hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((npts + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                     static_cast<const T*>(extras.res_sorted), extras.rank, out, npts);
+  hipError_t e = hipSuccess;
+  const int threads = g.cfg.column_threads == 1024 ? 1024 : (g.cfg.column_threads == 768 ? 768 : 512);
+#define GO(FMA, TH)                                                                                              \
+  do {                                                                                                           \
+    e = prepare(k_cubic_column<T, FMA, TH>);                                                                     \
+    if (e != hipSuccess) return e;                                                                               \
+    g.tag.set("k_cubic_column", {FMA, TH}, 0b01u);                                                               \
+    hipLaunchKernelGGL((k_cubic_column<T, FMA, TH>), dim3((unsigned)max_parts), dim3(TH), lds, stream, a);       \
+  } while (0)
+  if (g.fma) { if (threads == 1024) GO(true, 1024); else if (threads == 768) GO(true, 768); else GO(true, 512); }
+  else { if (threads == 1024) GO(false, 1024); else if (threads == 768) GO(false, 768); else GO(false, 512); }
+#undef GO
   return hipGetLastError();
 }
 
-template hipError_t launch_cubic_column<double>(const GridDesc&, const BinPlan&, const double* const*, const unsigned*, const BinExtras&,
-                                                bool, double*, size_t, size_t, unsigned long long*, size_t, hipStream_t);
-template hipError_t launch_cubic_column<float>(const GridDesc&, const BinPlan&, const float* const*, const unsigned*, const BinExtras&,
-                                               bool, float*, size_t, size_t, unsigned long long*, size_t, hipStream_t);
+template hipError_t launch_cubic_column<double>(const GridDesc&, const BinPlan&, const BinExtras&, const unsigned*, double*, size_t, size_t,
+                                                unsigned long long*, size_t, hipStream_t);
+template hipError_t launch_cubic_column<float>(const GridDesc&, const BinPlan&, const BinExtras&, const unsigned*, float*, size_t, size_t,
+                                               unsigned long long*, size_t, hipStream_t);
 
 }  // namespace interpn

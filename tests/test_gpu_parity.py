@@ -1648,3 +1648,84 @@ def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monke
     it.finish()
     assert it.last_path == "in_place" and it.last_path_reason == ""
     it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("axis", [[6, 7, 5, 6], [4, 4, 4, 4], [9, 5, 12, 7], [33, 32, 6, 5]], ids=str)
+def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, axis):
+    """Column evaluation (cubic_column.h): large 4-D multicubic batches on a regular grid are sorted
+    by the saturation-class pair of dims 0, 1 and a workgroup evaluates its bin's points out of an
+    LDS-resident column of table tiles (cfg4's form).  Forced here at small sizes: batches from one
+    point to several workgroup parts with ragged tails, ~30 % of the points extrapolating (every
+    node form: interior, saturated low / high, linearised, mixed waves), NaN / inf / huge
+    coordinates (first failing index = the ORIGINAL index), both `linearize_extrapolation` values,
+    part sizes down to one row, 512 / 768 / 1024-thread workgroups, and — `bin_scramble` — every
+    fifth point deliberately sorted into the wrong bin, so that the kernel's out-of-cell path (the
+    same tree from the table in global memory) is exercised: always the oracle's bits.
+    src/multicubic/regular.rs:325-623."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    want_t = torch.float64 if dtype == np.float64 else torch.float32
+    for nobs, threads, part, scramble in ((1, 768, 0, 0), (700, 768, 0, 0), (5_000, 512, 0, 1), (40_001, 1024, 2048, 0),
+                                          (40_001, 768, 1, 1), (250_013, 768, 0, 0), (250_013, 768, 3000, 1)):
+        lin = bool((nobs + threads) % 2)
+        case = synthetic_case("cubic", "regular", 4, axis, nobs, 9900 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
+                              specials=min(axis) >= 8)
+        want = run_oracle(oracle, case, True)
+        it = _make_interp(interpn_amd, case)
+        for k, v in (("binned", 1), ("column", 1), ("column_threads", threads), ("column_part", part), ("bin_scramble", scramble)):
+            it.set_option(k, v)
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)
+        out = out_full[1:1 + nobs]
+        it.eval_tensors(obs, out)
+        it.finish()
+        assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_column<"), it.kernel_name()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), (nobs, threads, part, scramble, int((got != want).sum()))
+        assert float(out_full[0]) == -5.0 and float(out_full[-1]) == -5.0  # nothing outside the batch was written
+        if nobs > 1000:
+            # failing coordinates: the smallest ORIGINAL index is reported; the prefix is right
+            bad = [o.clone() for o in obs]
+            bad[2][nobs // 2] = float("nan")
+            bad[0][nobs // 3] = float("inf")
+            bad[3][nobs - 1] = 1e300 if dtype == np.float64 else 3e38
+            res = it.eval_tensors(bad)
+            with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as err:
+                it.finish()
+            assert err.value.first_bad_index == nobs // 3
+            assert np.array_equal(res[:nobs // 3].cpu().numpy(), want[:nobs // 3])
+        it.close()
+
+
+def test_column_evaluation_is_chosen_for_large_batches_only(oracle, monkeypatch):
+    """Automatic mode: the column form needs about 3000 points per bin to pay for its column
+    fills; below that the tiled kernel runs on the sorted points (and below 2^19 points the batch
+    is not sorted at all).  Every path gives the same bits."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    case = synthetic_case("cubic", "regular", 4, [6, 7, 5, 6], 600_000, 9901, np.float64, extrap=0.1, specials=False)
+    it = _make_interp(interpn_amd, case)  # (6-1)(7-1) = 30 bins: 600 000 points = 20 000 per bin
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    it.set_option("binned", 1)
+    a = it.eval_tensors(obs)
+    it.finish()
+    assert it.kernel_name().startswith("interpn::k_cubic_column<")
+    small = [o[:50_000] for o in obs]   # 1 667 per bin: sorted, tiled kernel
+    b = it.eval_tensors(small)
+    it.finish()
+    assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_brick<")
+    it.set_option("binned", 0)
+    c = it.eval_tensors(obs)
+    it.finish()
+    assert it.last_path == "in_place"
+    assert torch.equal(a, c) and torch.equal(b, c[:50_000])
+    it.close()

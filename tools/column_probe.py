@@ -52,19 +52,17 @@ def main():
     t = timed(5)
     ref = out.clone()
     print(json.dumps({"variant": "in place", "ms": round(t[0], 4), "min": round(t[1], 4), "kernel": it.kernel_name()}), flush=True)
-    variants = [("tiled kernel on sorted points", {"binned": 1, "column": 0}),
-                ("column, scattered stores", {"binned": 1, "column": 1, "unpermute": 0}),
-                ("column, sorted stores + unpermute", {"binned": 1, "column": 1, "unpermute": 1})]
-    for q in (2048, 4096, 8192, 16384):
-        variants.append((f"column, unpermute, part {q}", {"binned": 1, "column": 1, "unpermute": 1, "column_part": q}))
+    variants = []
+    for rep in range(2):
+        variants.append(("tiled kernel on sorted points", {"binned": 1, "column": 0}))
+        variants.append(("column", {"binned": 1, "column": 1}))
     for name, opts in variants:
-        it.set_option("column_part", 0)
         for k, v in opts.items():
             it.set_option(k, v)
         out.fill_(-3.0)
         t = timed()
         same = bool(torch.equal(out, ref))
-        print(json.dumps({"variant": name, "ms": round(t[0], 4), "min": round(t[1], 4), "kernel": it.kernel_name(),
+        print(json.dumps({"points": P, "variant": name, "ms": round(t[0], 4), "min": round(t[1], 4), "kernel": it.kernel_name(),
                           "path": it.last_path, "bit_identical_to_in_place": same}), flush=True)
     it.close()
 
