@@ -236,13 +236,67 @@ def config_row(torch, interpn_amd, name, spec, obs, out, device, seconds, check_
            "oracle_check": {"points": check_points, "bitwise_equal": same}}
     if it.get_option("last_binned"):
         # 4-D multicubic: the batch is counting-sorted by table position first (3 more launches on
-        # the same stream); kernel_ms is the whole evaluation.  The same handle with the points
-        # evaluated in place, for comparison:
+        # the same stream); kernel_ms is the whole evaluation.  Its stages from HIP events recorded
+        # between the launches (option stage_timing), and the same handle with the points evaluated
+        # in place, for comparison:
+        it.set_option("stage_timing", 1)
+        stages = []
+        for _ in range(24):
+            it.eval_tensors(obs, out)
+            it.finish()
+            stages.append(it.stage_ms())
+        it.set_option("stage_timing", 0)
+        st = {k: round(float(np.median([s[k] for s in stages])), 4) for k in ("hist", "scan", "scatter", "kernel")}
         it.set_option("binned", 0)
         ms0 = time_launches(torch, it, obs, out, seconds=seconds / 2)
-        row["binned"] = {"launches_per_evaluation": 4, "unsorted_kernel_ms": round(float(np.mean(ms0)), 4)}
+        row["binned"] = {"launches_per_evaluation": 4, "stage_ms": st, "unsorted_kernel_ms": round(float(np.mean(ms0)), 4),
+                         "stage_note": "histogram (+ counter reset) | scan | scatter of the points into bin order | evaluation "
+                                       "kernel on the sorted points; HIP events on the launch stream, median of 24 evaluations"}
+        if spec["method"] == "cubic" and spec["ndims"] == 4:
+            row["bound"] = cubic4_bound(row, P, st["kernel"], float(np.mean(ms0)), spec)
     it.close()
     return row
+
+
+# FP64 vector issue peak measured on this part (tools/fp64_rate.hip -> profiles/r03_fp64_vector_rate.txt; the
+# microarchitecture guide gives none): v_add/v_mul/v_fma_f64 all issue one wave64 instruction per ~4.1 cycles per SIMD.
+FP64_WAVE_INSTR_PER_US_PER_SIMD = 566.0
+FP64_FMA_PEAK_TFLOPS = 74.1  # = 566e6 x 1024 SIMDs x 64 lanes x 2 flop
+L2_HIT_LINES_PER_S = 2.7e11  # 128 channels x 1 line per clock
+L2_MISS_LINES_PER_S = 5.5e10  # random 128-B lines from the Infinity Cache / HBM (tools/tune_sector)
+
+
+def cubic4_bound(row, P, kernel_stage_ms, unsorted_ms, spec):
+    """What bounds cfg4 ('cfg4 is not HBM-bound by construction ... report additionally
+    L2/MALL gather GB/s and FP64-VALU utilization so the number is interpretable')."""
+    gather_bytes = 8 * 4**4  # a 4^4 footprint of f64 = 16 table lines of 128 B
+    nodes = (4**4 - 1) // 3  # 85 one-dimensional reductions per point (multicubic/regular.rs:368-421)
+    node_instr = 9 + 2 + 3   # interior node: 9 add/sub, 2 mul by 0.5, 3 fma (multicubic/regular.rs:495-505, mod.rs:72-91)
+    node_flop = 9 + 2 + 2 * 3
+    t = kernel_stage_ms * 1e-3
+    issue_peak = FP64_WAVE_INSTR_PER_US_PER_SIMD * 1e6 * 1024  # wave-instructions per second, whole chip
+    column = row["kernel"].startswith("interpn::k_cubic_column")
+    return {
+        "hbm": "not the bound: 40 B of streams against 2 KiB of table values and ~1.2k f64 operations per point",
+        "gather_bytes_per_point": gather_bytes,
+        "gather_served_from": "LDS: the (k, l) column of the bin's (i, j) cell, filled once per workgroup (cubic_column.h)" if column
+                              else "L2 (sorted points share table lines; tiled kernel)",
+        "gather_GBps": round(P * gather_bytes / t / 1e9, 1),
+        "unsorted_gather_GBps": round(P * gather_bytes / (unsorted_ms * 1e-3) / 1e9, 1),
+        "l2_line_floor_ms": round(P * 16 / L2_HIT_LINES_PER_S * 1e3, 4),
+        "l2_miss_line_floor_ms": round(P * 16 / L2_MISS_LINES_PER_S * 1e3, 4),
+        "lds_floor_ms": round(P * gather_bytes / (256 * 256 * 2.35e9) * 1e3, 4),
+        "valu_f64_instr_per_point": nodes * node_instr,
+        "valu_flop_per_point": nodes * node_flop,
+        "valu_floor_ms": round(P / 64 * nodes * node_instr / issue_peak * 1e3, 4),
+        "valu_frac_of_fp64_vector_issue_peak": round(P / 64 * nodes * node_instr / t / issue_peak, 4),
+        "valu_TFLOPs": round(P * nodes * node_flop / t / 1e12, 2),
+        "valu_frac_of_fp64_vector_peak": round(P * nodes * node_flop / t / 1e12 / FP64_FMA_PEAK_TFLOPS, 4),
+        "peak_source": "measured: tools/fp64_rate.hip, profiles/r03_fp64_vector_rate.txt (566 wave-instr/us/SIMD for add, mul and fma "
+                       "alike = 74.1 TFLOP/s counting fma as 2 flop; the microarchitecture guide gives no FP64 vector peak)",
+        "counts": "node arithmetic only (85 nodes x 14 f64 instructions); cell location adds 8 IEEE divisions and ~300 further "
+                  "instructions per point; floors: 16 lines per point at the L2 hit rate / miss rate, 2 KiB per point at 256 B/clk/CU of LDS",
+    }
 
 
 def cfg1_row(torch, interpn_amd, device):

@@ -263,6 +263,12 @@ int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, si
  * "scratch_bytes". */
 int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams);
 
+/* Measurement aid (bench.py): with option "stage_timing" = 1 a sorted (binned) single-slice
+ * evaluation records HIP events between its launches; this waits for the most recent one and
+ * returns its stage durations in milliseconds: ms[0] histogram (+ counter reset), ms[1] scan,
+ * ms[2] scatter, ms[3] evaluation kernel.  n >= 4.  INVALID_ARGUMENT when no such evaluation ran. */
+int interpn_hip_stage_ms(interpn_hip_interp* h, double* ms, size_t n);
+
 /* Wait for `stream` and report the sticky status of the device evaluations enqueued since the
  * last finish: 0, or INTERPN_HIP_ERR_UNREPRESENTABLE with the smallest failing point index
  * (relative to the evaluation it occurred in) in *first_bad_index.  Clears the sticky word. */

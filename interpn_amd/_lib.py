@@ -121,6 +121,7 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_eval_device_ex.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p,
                                                ctypes.c_uint, POINTER(c_int), POINTER(c_int)]
     lib.interpn_hip_reserve.argtypes = [c_void_p, c_size_t, c_int]
+    lib.interpn_hip_stage_ms.argtypes = [c_void_p, POINTER(c_double), c_size_t]
     lib.interpn_hip_check_bounds_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_size_t, ctypes.c_double,
                                                     POINTER(ctypes.c_uint8), c_size_t, c_void_p]
     lib.interpn_hip_finish.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]

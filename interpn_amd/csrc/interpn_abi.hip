@@ -337,6 +337,8 @@ struct interpn_hip_interp {
     bool busy = false;           // a host thread is enqueueing into this block right now
     hipStream_t last_stream = nullptr;
     unsigned long long stamp = 0;  // use counter value of the last use (LRU)
+    hipEvent_t stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // option stage_timing: start | hist | scan | scatter | kernel
+    bool staged = false;           // the last use recorded them (single slice)
   };
   std::mutex bin_mu;
   std::vector<BinSlot> bin_slots;
@@ -681,6 +683,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"column_threads", &c.column_threads, 512, 1024},
       {"column_ablate", &c.column_ablate, 0, 31},
       {"bin_scramble", &c.bin_scramble, 0, 1},
+      {"stage_timing", &c.stage_timing, 0, 1},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -1291,6 +1294,8 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
   pool_return_small(h->device, h->small_host);
   for (auto& sl : h->bin_slots) {  // their streams were waited for above (marks)
     if (sl.event) (void)hipEventDestroy(sl.event);
+    for (hipEvent_t e : sl.stage)
+      if (e) (void)hipEventDestroy(e);
     pool_free(h->device, sl.scratch);
   }
   pool_free(h->device, h->first_bad);
@@ -1459,6 +1464,15 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   if (!slot) return -1;
   const size_t elem = g.dtype == kF64 ? 8 : 4;
   hipError_t err = hipSuccess;
+  // per-stage timing on request (single-slice evaluations only)
+  hipEvent_t* stage = nullptr;
+  slot->staged = false;
+  if (g.cfg.stage_timing && npoints <= slice) {
+    bool okev = true;
+    for (hipEvent_t& e : slot->stage)
+      if (!e && hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; okev = false; }
+    if (okev) stage = slot->stage;
+  }
   for (size_t begin = 0; begin < npoints && err == hipSuccess; begin += slice) {
     const size_t count = npoints - begin < slice ? npoints - begin : slice;
     const void* src[8];
@@ -1476,7 +1490,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part < kColumnMaxPart ? (size_t)g.cfg.column_part : kColumnMaxPart;
       const size_t max_parts = count / q + (size_t)plan.nbins + 1;
       BinExtras extras;
-      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q);
+      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage);
       if (err != hipSuccess) break;
       if (g.dtype == kF64)
         err = launch_cubic_column<double>(*use, plan, extras, index, reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
@@ -1484,7 +1498,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
         err = launch_cubic_column<float>(*use, plan, extras, index, reinterpret_cast<float*>(dst), count, max_parts, h->first_bad, begin, stream);
       continue;
     }
-    err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream);
+    err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, nullptr, 0, stage);
     if (err != hipSuccess) break;
     if (g.dtype == kF64)
       err = launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
@@ -1493,6 +1507,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       err = launch_cubic_brick<float>(*use, reinterpret_cast<const float* const*>(sorted), reinterpret_cast<float*>(dst), count,
                                       h->first_bad, stream, index, begin);
   }
+  if (stage && err == hipSuccess && hipEventRecord(stage[4], stream) == hipSuccess) slot->staged = true;
   // Whatever was enqueued — also a sequence cut short by a failure — is followed by the block's
   // event, so that the next user of the block on another stream waits for it.
   {
@@ -1563,6 +1578,24 @@ int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, si
 int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out, size_t npoints,
                             void* stream) {
   return interpn_hip_eval_device_ex(h, obs, nobs, out, npoints, stream, 0u, nullptr, nullptr);
+}
+
+int interpn_hip_stage_ms(interpn_hip_interp* h, double* ms, size_t n) {
+  if (!h || !ms || n < 4) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(h->device);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(h->bin_mu);
+  const interpn_hip_interp::BinSlot* best = nullptr;
+  for (const auto& sl : h->bin_slots)
+    if (sl.staged && !sl.busy && (!best || sl.stamp > best->stamp)) best = &sl;
+  if (!best) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipEventSynchronize(best->stage[4]));
+  for (int k = 0; k < 4; ++k) {
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, best->stage[k], best->stage[k + 1]));
+    ms[k] = (double)f;
+  }
+  return INTERPN_HIP_OK;
 }
 
 int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {

@@ -32,6 +32,7 @@ struct LaunchConfig {
   int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
   int column = -1;         // binned 4-D multicubic on regular grids: evaluate sorted points out of an LDS-resident table column (-1/1 where it applies, 0 never)
   int column_part = 0;     // column evaluation: points per workgroup (0 = automatic)
+  int stage_timing = 0;    // binned evaluation: record HIP events between its launches (interpn_hip_stage_ms; bench.py)
   int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
   int column_ablate = 0;   // column evaluation, timing probes only (results wrong): 1 no store, 2 stored order, 4 no planes, 8 no fill
   int column_threads = 768; // column evaluation: threads per workgroup (768 = three waves per SIMD with 168 VGPRs, planes software-pipelined: 1.10 ms for cfg4; 1024: 1.17; 512: 1.18)
@@ -218,11 +219,12 @@ struct BinExtras {
   const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
 };
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
-// original indices (within the slice).  `extras` (4-D only): the sorted points are written as
+// original indices (within the slice).  `stage` (optional, 4 events): recorded in front of the
+// histogram, behind it, behind the scan and behind the scatter.  `extras` (4-D only): the sorted points are written as
 // records instead, and the bins are cut into parts of at most `part_points` points.
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
                       const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras = nullptr,
-                      unsigned part_points = 0);
+                      unsigned part_points = 0, hipEvent_t* stage = nullptr);
 
 // Column evaluation of sorted 4-D multicubic points on a regular grid (cubic_column.h): does it
 // apply to this grid (LDS capacity, classes fit the bins), and the launch.

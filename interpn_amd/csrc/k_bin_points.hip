@@ -292,7 +292,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T, int N>
 hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts, void* scratch, const void** binned_obs,
-                        const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream) {
+                        const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream, hipEvent_t* stage) {
   unsigned char* base = static_cast<unsigned char*>(scratch);
   unsigned* totals = reinterpret_cast<unsigned*>(base);
   unsigned* cursor = totals + kMaxBins;
@@ -319,11 +319,15 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   a.npts = npts;
   a.p = p;
   *index = idx;
+  auto mark = [&](int k) { if (stage) (void)hipEventRecord(stage[k], stream); };  // per-stage timing on request (bench.py)
+  mark(0);
   hipError_t e = hipMemsetAsync(totals, 0, kMaxBins * sizeof(unsigned), stream);
   if (e != hipSuccess) return e;
   const unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
   hipLaunchKernelGGL(k_bin_hist<T>, dim3(hblocks), dim3(kBlock), 0, stream, a.obs[0], a.obs[1], npts, p, totals);
+  mark(1);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points);
+  mark(2);
   if (extras) {
     if constexpr (N == 4) {
       const unsigned blocks = (unsigned)((npts + kRecChunk - 1) / kRecChunk);
@@ -335,6 +339,7 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     const unsigned blocks = (unsigned)((npts + kBinChunk - 1) / kBinChunk);
     hipLaunchKernelGGL((k_bin_scatter<T, N, (int)kBinChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
   }
+  mark(3);
   return hipGetLastError();
 }
 
@@ -396,7 +401,7 @@ size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points) {
 
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
                       const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras,
-                      unsigned part_points) {
+                      unsigned part_points, hipEvent_t* stage) {
   if (extras && g.ndims != 4) return hipErrorInvalidValue;
   if (npts == 0 || npts > kBinSlicePoints) return hipErrorInvalidValue;
   BinParams p;
@@ -411,7 +416,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.mult = plan.mult;
   p.classes = plan.classes;
   p.scramble = g.cfg.bin_scramble;
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream)
+#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage)
   if (g.dtype == kF64) {
     switch (g.ndims) {
       case 2: GO(double, 2);

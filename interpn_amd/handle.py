@@ -158,6 +158,13 @@ class Interpolator:
         nothing, also with `no_alloc=True`."""
         _lib.raise_for_status(_lib.load().interpn_hip_reserve(self._h, int(npoints), int(nstreams)))
 
+    def stage_ms(self):
+        """Durations (ms) of the most recent sorted evaluation's stages — histogram, scan, scatter,
+        evaluation kernel — recorded when option "stage_timing" is 1 (`interpn_hip_stage_ms`)."""
+        ms = (c_double * 4)()
+        _lib.raise_for_status(_lib.load().interpn_hip_stage_ms(self._h, ms, 4))
+        return {"hist": ms[0], "scan": ms[1], "scatter": ms[2], "kernel": ms[3]}
+
     def eval_device_ptrs(self, obs_ptrs, out_ptr: int, npoints: int, stream: int = 0, no_alloc: bool = False) -> str:
         """Enqueue one evaluation on device buffers given as raw addresses (asynchronous).
         Returns the path taken, "in_place" or "binned" (also kept in `.last_path`, with
