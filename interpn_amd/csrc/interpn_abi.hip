@@ -684,6 +684,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"column_ablate", &c.column_ablate, 0, 31},
       {"bin_scramble", &c.bin_scramble, 0, 1},
       {"stage_timing", &c.stage_timing, 0, 1},
+      {"axis_records", &c.axis_records, 0, 1},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -712,7 +713,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "axis_records"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -869,6 +870,51 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       return INTERPN_HIP_ERR_UNSUPPORTED;
     }
   }
+  // Per-bucket search records (interpn_host.h: axis_rec_*; multilinear and nearest only): built on
+  // the host with the arithmetic bucket_of() uses on the device (same type, same operations, no
+  // contraction), for axes whose buckets hold at most one coordinate each.  All axes or none.
+  std::vector<std::vector<unsigned char>> recs(ngrids);
+  {
+    bool all = method != kCubic;
+    size_t rbytes = 0;
+    const size_t rsize = sizeof(T) == 8 ? 32 : 16;
+    for (size_t i = 0; i < ngrids && all; ++i) {
+      const int n = (int)grid_lens[i], M = g.axis_buckets[i];
+      if (M <= 0) { all = false; break; }
+      const T g0 = (T)g.axis_g0[i], scale = (T)g.axis_scale[i];
+      std::vector<int> first(M + 1, n);  // first[b] = tab[b]: coordinates in buckets < b
+      int prev = -1;
+      for (int k = 0; k < n && all; ++k) {
+        const T u = (grids[i][k] - g0) * scale;
+        const int b = u >= (T)(M - 1) ? (M - 1) : (u > (T)0 ? (int)u : 0);
+        if (b <= prev) all = false;  // two coordinates in one bucket (or not monotone): no records
+        for (int q = prev + 1; q <= b; ++q) first[q] = k;
+        prev = b;
+      }
+      if (!all) break;
+      recs[i].assign((size_t)M * rsize, 0);
+      for (int b = 0; b < M; ++b) {
+        const int k = first[b];
+        if (k >= n) { all = false; break; }  // cannot happen: g[n-1] lies in bucket M-1
+        T triple[3] = {k > 0 ? grids[i][k - 1] : (T)0, grids[i][k], k + 1 < n ? grids[i][k + 1] : (T)0};
+        unsigned char* r = recs[i].data() + (size_t)b * rsize;
+        memcpy(r, triple, 3 * sizeof(T));
+        const unsigned ku = (unsigned)k;
+        memcpy(r + 3 * sizeof(T), &ku, sizeof(ku));
+      }
+      rbytes += recs[i].size();
+    }
+    if (all && rbytes <= kMaxGridLdsBytesWide && bytes + rbytes < 0xFFFFFF00ull) {
+      g.axis_rec_base = (unsigned)bytes;
+      for (size_t i = 0; i < ngrids; ++i) {
+        g.axis_rec_off[i] = (unsigned)bytes;
+        bytes += recs[i].size();
+      }
+      g.axis_rec_bytes = (unsigned)(bytes - g.axis_rec_base);
+    } else {
+      for (auto& r : recs) r.clear();
+    }
+  }
   g.axis_image_bytes = (unsigned)bytes;
   hipError_t e = pool_alloc(h->device, &h->grids_owned, bytes);
   if (e == hipSuccess) e = hipMemsetAsync(h->grids_owned, 0, bytes, nullptr);
@@ -887,6 +933,8 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     if (e == hipSuccess && g.axis_ltab_off[i])
       e = build_lane_table<T>(reinterpret_cast<const T*>(gdev), g.n[i], (T)g.axis_g0[i], (T)g.axis_lscale[i],
                               reinterpret_cast<unsigned*>((char*)h->grids_owned + g.axis_ltab_off[i]), nullptr);
+    if (e == hipSuccess && g.axis_rec_bytes)
+      e = hipMemcpy((char*)h->grids_owned + g.axis_rec_off[i], recs[i].data(), recs[i].size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       interpn_hip_destroy(h);
       return hip_fail(e);

@@ -163,7 +163,14 @@ struct Axis {
   int M;  // number of buckets, 0 = no table (axis not proven sorted): std probe sequence
   T g0;
   T scale;
+  const unsigned char* rec = nullptr;  // per-bucket records (below), or null
 };
+
+// Per-bucket record of an axis whose buckets hold at most one coordinate each: with k = tab[b],
+// {gm1, g0, gp1} = {g[k-1], g[k], g[k+1]} (entries outside the axis are never selected).
+template <typename T> struct AxisRecord;
+template <> struct __attribute__((aligned(16))) AxisRecord<double> { double gm1, g0, gp1; unsigned k, pad; };
+template <> struct __attribute__((aligned(16))) AxisRecord<float> { float gm1, g0, gp1; unsigned k; };
 
 constexpr int kLaneBuckets = 255;  // buckets of a lane table (256 byte entries = 64 lanes x 4)
 
@@ -195,6 +202,21 @@ __device__ __forceinline__ int axis_partition_point(const Axis<T>& ax, T x) {
 template <typename T>
 __device__ __forceinline__ int axis_cell(const Axis<T>& ax, T x, T* x0, T* x1) {
   const int n = ax.n;
+  if (ax.rec) {
+    // One access.  k = tab[b] coordinates lie in earlier buckets, so every one of them is < x and
+    // every coordinate of a later bucket is >= x (bucket_of is monotone and is the function the
+    // table was built with); bucket b itself holds at most g[k].  Hence partition_point(g < x) =
+    // k + (g[k] < x), and cell l = clamp(that - 1, 0, n - 2) is k (brackets g[k], g[k+1]) or k - 1
+    // (brackets g[k-1], g[k]).  NaN: bucket 0, g[0] < NaN is false, l = 0 like the reference.
+    const int b = bucket_of<T>(x, ax.g0, ax.scale, ax.M);
+    const AxisRecord<T> r = reinterpret_cast<const AxisRecord<T>*>(ax.rec)[b];
+    const int k = (int)r.k;
+    const bool up = r.g0 < x;
+    const bool hi = (up && k <= n - 2) || k == 0;
+    *x0 = hi ? r.g0 : r.gm1;
+    *x1 = hi ? r.gp1 : r.g0;
+    return hi ? k : k - 1;
+  }
   int l = axis_partition_point<T>(ax, x) - 1;
   l = l > 0 ? l : 0;
   l = l < n - 2 ? l : n - 2;

@@ -32,6 +32,7 @@ struct LaunchConfig {
   int binned = -1;         // tiled multicubic, device-pointer evaluation: -1 auto, 0 never, 1 always sort the points first
   int column = -1;         // binned 4-D multicubic on regular grids: evaluate sorted points out of an LDS-resident table column (-1/1 where it applies, 0 never)
   int column_part = 0;     // column evaluation: points per workgroup (0 = automatic)
+  int axis_records = 1;    // rectilinear multilinear / nearest: search with per-bucket records where the handle has them (0: coordinates + tables as before)
   int stage_timing = 0;    // binned evaluation: record HIP events between its launches (interpn_hip_stage_ms; bench.py)
   int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
   int column_ablate = 0;   // column evaluation, timing probes only (results wrong): 1 no store, 2 stored order, 4 no planes, 8 no fill
@@ -86,6 +87,15 @@ struct GridDesc {
   unsigned axis_ltab_off[8] = {0};
   double axis_lscale[8] = {0};
   int axis_lscan[8] = {0};  // largest bucket population of the lane table (read back when it is built)
+  // Per-bucket search records (multilinear / nearest; axes too long for the lane-resident search):
+  // when no bucket of an axis' table holds more than one coordinate, one record per bucket —
+  // {g[k-1], g[k], g[k+1], k} with k = tab[b] — answers a cell query with ONE LDS access instead of
+  // the table's two words, a scan probe and the two bracketing coordinates (interpn_device.h::
+  // axis_cell).  They sit behind the coordinates and tables in the axis image and are staged
+  // INSTEAD of them.  axis_rec_bytes = 0: none (some axis is not eligible, or every axis fits a lane).
+  unsigned axis_rec_off[8] = {0};   // byte offsets inside the image
+  unsigned axis_rec_base = 0;       // first byte of the records region
+  unsigned axis_rec_bytes = 0;      // its size
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell

@@ -56,6 +56,11 @@ struct AxisArgs {
   int use_lds;
   unsigned ltab_off[N];  // lane tables (axes <= 64 coordinates), 0 = none
   T lscale[N];
+  // Per-bucket search records (GridDesc::axis_rec_*): when use_rec is set, `image` / `image_bytes`
+  // are the records region alone and rec_off[d] is axis d's offset inside it; g_off / tab_off are
+  // then not to be dereferenced.
+  int use_rec;
+  unsigned rec_off[N];
 };
 
 template <typename T, int N>
@@ -67,6 +72,7 @@ __device__ __forceinline__ Axis<T> make_axis(const AxisArgs<T, N>& a, const unsi
   ax.M = a.M[d];
   ax.g0 = a.g0[d];
   ax.scale = a.scale[d];
+  ax.rec = a.use_rec ? base + a.rec_off[d] : nullptr;
   return ax;
 }
 

@@ -217,7 +217,7 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   a.ax.use_lds = 0;
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
-  if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax, /*big_lds=*/true);
+  if (g.kind == kRectilinear) lds = fill_axis_args<T, 2>(g, a.ax, /*big_lds=*/true, /*records=*/true);
   const int axr = lane_axes_mode(g);  // both axes <= 64 coordinates: searched across lanes, no LDS image
   if (axr) lds = 0;
   // Two points per lane when every stream is aligned to 2*sizeof(T) (the handle's `ppl` option = 1

@@ -149,7 +149,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   size_t axis_lds = 0;
-  if (g.kind == kRectilinear) axis_lds = fill_axis_args<T, N>(g, a.ax);
+  if (g.kind == kRectilinear) axis_lds = fill_axis_args<T, N>(g, a.ax, false, /*records=*/true);
   // Two points per lane (vector coordinate/result accesses) for the 3-D shape when every stream is
   // aligned to 2*sizeof(T); the handle's `ppl` option = 1 forces the scalar form (tuning / testing).
   if constexpr (N == 3) {

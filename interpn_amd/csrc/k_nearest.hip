@@ -145,7 +145,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.use_lds = 0;
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
-  if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);
+  if (g.kind == kRectilinear) lds = fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);  // (per-bucket records measured slower here: 3-D 80^3 1.32 vs 1.17 ms)
   const int axr = lane_axes_mode(g);  // rectilinear axes of <= 64 coordinates: searched across lanes, no LDS image
   if (axr) lds = 0;
   // Two points per lane when every stream is aligned to 2*sizeof(T) (`ppl` option = 1: scalar form).

@@ -10,10 +10,14 @@ namespace interpn {
 // where the axes are long and the search is what the kernel spends its time on: the image may
 // then take up to 60 KiB (measured: 2-D 1000^2 rectilinear 2.22 -> 1.66 ms, 1-D 3000 1.22 ->
 // 0.64 ms per 1e8 points against the search through L1/L2).
+// `records`: the kernel searches with axis_cell (multilinear, nearest) and may be given the
+// per-bucket records instead of coordinates + tables.
 template <typename T, int N>
-inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds = false) {
+inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds = false, bool records = false) {
   ax.image = static_cast<const unsigned char*>(g.axis_image);
   ax.image_bytes = g.axis_image_bytes;
+  ax.use_rec = 0;
+  for (int d = 0; d < N; ++d) ax.rec_off[d] = 0;
   for (int d = 0; d < N; ++d) {
     ax.g_off[d] = g.axis_g_off[d];
     ax.tab_off[d] = g.axis_tab_off[d];
@@ -26,6 +30,16 @@ inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds
   }
   size_t cap = (big_lds && N <= 2) ? kMaxGridLdsBytesWide : kMaxGridLdsBytes;
   if (g.cfg.axis_lds_kb >= 0 && g.cfg.axis_lds_kb <= 60) cap = (size_t)g.cfg.axis_lds_kb * 1024;  // tuning knob
+  bool lanes = g.cfg.axis_regs != 0;  // the lane-resident search (lane_axes.h) takes axes of <= 64 coordinates
+  for (int d = 0; d < N; ++d) lanes = lanes && g.n[d] <= 64;
+  if (records && !lanes && g.cfg.axis_records != 0 && g.axis_rec_bytes && g.axis_rec_bytes <= cap) {
+    ax.use_rec = 1;
+    ax.image += g.axis_rec_base;
+    ax.image_bytes = g.axis_rec_bytes;
+    for (int d = 0; d < N; ++d) ax.rec_off[d] = g.axis_rec_off[d] - g.axis_rec_base;
+    ax.use_lds = 1;
+    return g.axis_rec_bytes;
+  }
   ax.use_lds = g.axis_image_bytes <= cap;
   return ax.use_lds ? g.axis_image_bytes : 0;
 }
@@ -42,7 +56,7 @@ inline size_t fill_rect_args(const GridDesc& g, const T* const* obs, T* out, siz
     acc *= (unsigned)g.n[d];
   }
   for (int d = 0; d < N; ++d) a.obs[d] = obs[d];
-  return fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true);
+  return fill_axis_args<T, N>(g, a.ax, /*big_lds=*/true, /*records=*/true);
 }
 
 }  // namespace interpn

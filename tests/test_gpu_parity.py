@@ -1729,3 +1729,44 @@ def test_column_evaluation_is_chosen_for_large_batches_only(oracle, monkeypatch)
     assert it.last_path == "in_place"
     assert torch.equal(a, c) and torch.equal(b, c[:50_000])
     it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("method,axis", [("linear", [300]), ("linear", [65, 130]), ("linear", [70, 9, 81]), ("linear", [7, 90, 5, 6]),
+                                         ("linear", [40, 33]), ("linear", [500, 470])], ids=str)
+def test_rectilinear_bucket_records(oracle, monkeypatch, dtype, method, axis):
+    """Axes too long for the lane-resident search are searched through per-bucket records — one LDS
+    access {g[k-1], g[k], g[k+1], k} per cell query instead of table words + scan + brackets
+    (interpn_device.h::axis_cell; multilinear/rectilinear.rs:353-370).  Jittered axes (records
+    built), with and without the records (option axis_records), forced LDS search on short axes
+    too, and a clustered axis whose buckets hold several coordinates (no records: the old search):
+    always the oracle's bits, exact nodes / domain ends / NaN included."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = len(axis)
+    for variant in ("jittered", "clustered"):
+        case = synthetic_case(method, "rectilinear", n, axis, 120_007, 9950 + sum(axis), dtype, extrap=0.1)
+        if variant == "clustered":  # 5 coordinates squeezed into one bucket's width on the longest axis
+            d = int(np.argmax(axis))
+            g = case.grids[d].astype(np.float64).copy()
+            w = (g[-1] - g[0]) / (2 * g.size)
+            g[10:15] = g[10] + np.arange(5) * w / 8
+            g[15:] = np.maximum(g[15:], g[14] + w / 4 * (1 + np.arange(g.size - 15)))
+            g = g.astype(dtype)
+            assert np.all(np.diff(g) > 0)
+            case.grids[d] = g
+        case.obs[0][5] = np.nan
+        want = run_oracle(oracle, case, True)
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for records, axis_regs in ((1, -1), (0, -1), (1, 0)):
+            it = _make_interp(interpn_amd, case)
+            it.set_option("axis_records", records)
+            it.set_option("axis_regs", axis_regs)
+            got = it.eval_tensors(obs).cpu().numpy()
+            it.finish()
+            same = (got == want) | (np.isnan(got) & np.isnan(want))
+            assert np.all(same), (variant, records, axis_regs, int((~same).sum()))
+            it.close()
