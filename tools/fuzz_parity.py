@@ -12,12 +12,13 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
-         "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL")
+         "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
+         "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
 
-def run_device(case, rng, dtype):
+def run_device(case, rng, dtype, fma=None):
     """The persistent-handle device entry point on torch tensors whose first element sits at a
     random element offset (exercises the aligned-vector and the scalar stream paths)."""
     import torch
@@ -26,10 +27,10 @@ def run_device(case, rng, dtype):
 
     if case.kind == "regular":
         it = interpn_amd.Interpolator.regular(case.method, case.dims, case.starts, case.steps, case.vals,
-                                              linearize_extrapolation=case.linearize)
+                                              linearize_extrapolation=case.linearize, fma=fma)
     else:
         it = interpn_amd.Interpolator.rectilinear(case.method, case.grids, case.vals,
-                                                  linearize_extrapolation=case.linearize)
+                                                  linearize_extrapolation=case.linearize, fma=fma)
     try:
         nobs = case.obs[0].size
         obs_t = []
@@ -105,6 +106,18 @@ def run(budget: float, seed: int, max_cases: int = 0):
             # binned evaluation of the tiled multicubic kernels (device entry point, N = 2..4), dealt or not
             if method == "cubic" and rng.random() < 0.5: env["INTERPN_HIP_BINNED"] = "1"
             if rng.random() < 0.3: env["INTERPN_HIP_DEAL"] = "0"
+            # round 3: the LDS-column evaluation of sorted 4-D multicubic points on regular grids (forced where it
+            # applies: fully overlapped tiles), its workgroup size / part size, deliberately mis-binned points, short
+            # slices; per-bucket search records on or off
+            if method == "cubic" and N == 4 and kind == "regular" and rng.random() < 0.7:
+                env["INTERPN_HIP_BINNED"] = "1"
+                env["INTERPN_HIP_BRICKS"] = "11"
+                env["INTERPN_HIP_COLUMN"] = str(int(rng.choice([-1, 1, 1, 1, 0])))
+                env["INTERPN_HIP_COLUMN_THREADS"] = str(int(rng.choice([512, 768, 1024])))
+                if rng.random() < 0.5: env["INTERPN_HIP_COLUMN_PART"] = str(int(rng.choice([1, 64, 700, 2048, 12288])))
+                if rng.random() < 0.4: env["INTERPN_HIP_BIN_SCRAMBLE"] = "1"
+                if rng.random() < 0.3: env["INTERPN_HIP_BIN_SLICE_LOG2"] = "16"
+            if kind == "rectilinear" and rng.random() < 0.3: env["INTERPN_HIP_AXIS_RECORDS"] = "0"
             # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
             if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
             for k in KNOBS:
@@ -131,10 +144,16 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 run_oracle(pyoracle, case, fma, out=want)
             except AssertionError as e:
                 err_o = str(e)
-            device_path = rng.random() < 0.3
+            device_path = rng.random() < 0.3 or "INTERPN_HIP_COLUMN" in env
+            # per-handle flavour (round 3): on the device path half of the cases pass the flavour to the handle while the
+            # process default says the opposite
+            fma_arg = None
+            if device_path and rng.random() < 0.5:
+                fma_arg = fma
+                lib.interpn_hip_set_fma(0 if fma else 1)
             try:
                 if device_path:
-                    got, err_g, first_bad = run_device(case, rng, dtype)
+                    got, err_g, first_bad = run_device(case, rng, dtype, fma_arg)
                 else:
                     run_hip_raw(case, out=got)
             except AssertionError as e:
