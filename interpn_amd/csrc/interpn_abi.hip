@@ -604,8 +604,14 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   unsigned nbc[4] = {0, 0, 0, 0};
   size_t bcell = 0;
   if (g.ndims >= 4) brick_cell_geometry(g, nbc, &bcell);
+  bool j4 = false;       // f32 2 x 4 x 4 bricks (linear_brick.h, CELL == 2)
+  unsigned nbj4[3] = {0, 0, 0};
+  size_t bj4 = 0;
+  if (g.dtype == kF32) brick_j4_geometry(g, nbj4, &bj4);
   if (env && !strcmp(env, "c4") && g.ndims >= 4) {
     cell = true;  // forced 4-D cell bricks (tests / tuning); INTERPN_HIP_BRICKS=c4 is ignored for N = 3
+  } else if (env && !strcmp(env, "j4") && g.dtype == kF32) {
+    j4 = true;    // forced (tests / tuning); ignored for f64
   } else if (env && strlen(env) == 2 && (env[0] == '1' || env[0] == '2') && (env[1] == '1' || env[1] == '2')) {
     si = env[0] - '0';
     sj = env[1] - '0';
@@ -627,10 +633,16 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     brick_geometry(g, 2, 2, nb, &b22);
     // (tools/sweep_linear_nd.py, profiles/r02_sweep_linear_nd.txt: within 6 % of the best forced
     // layout at every size, N = 4..6)
+    // f32 (round 3): the 2 x 4 x 4 bricks are the one-line-per-cell layout at 0.78x the size of the
+    // fully overlapped 2 x 2 x 8 bricks; they take its place in the rule (tools/sweep_f32.py,
+    // profiles/r03_sweep_f32_layouts.txt: never slower than (1,1); 64^3 0.73 -> 0.66 ms, 72^3
+    // 0.81 ((1,2)) -> 0.76, 128^3 1.77 -> 1.70).
+    const bool f32 = g.dtype == kF32;
+    const size_t bone = f32 ? bj4 : b11;  // the one-line-per-cell table of this element type
     if (g.ndims >= 4 && fits(bcell) && (bcell <= 6 * MiB || b22 > 3 * MiB)) {
       cell = true;
-    } else if (fits(b11)) {
-      if (b11 <= 6 * MiB || b22 > 6 * MiB) { si = 1; sj = 1; }
+    } else if (fits(bone)) {
+      if (bone <= 6 * MiB || b22 > 6 * MiB) { si = 1; sj = 1; j4 = f32; }
       else if (b12 <= 6 * MiB) { si = 1; sj = 2; }
       else { si = 2; sj = 2; }
     } else if (fits(b12)) { si = 1; sj = 2; }
@@ -638,7 +650,12 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     else return INTERPN_HIP_OK;  // stay on the C-order kernel
   }
   size_t bytes;
-  if (cell) {
+  if (j4) {
+    bytes = bj4;
+    for (int k = 0; k < 3; ++k) g.brick_nb[k] = nbj4[k];
+    g.brick_nb[3] = 0;
+    si = sj = 1;
+  } else if (cell) {
     bytes = bcell;
     for (int k = 0; k < 4; ++k) g.brick_nb[k] = nbc[k];
     si = sj = 1;
@@ -651,7 +668,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (bytes > free_b / 2) return INTERPN_HIP_OK;
   g.brick_step[0] = si;
   g.brick_step[1] = sj;
-  g.brick_cell = cell ? 1 : 0;
+  g.brick_cell = j4 ? 2 : (cell ? 1 : 0);
   hipError_t e = pool_alloc(h->device, &h->bricks_owned, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); h->bricks_owned = nullptr; g.brick_cell = 0; return INTERPN_HIP_OK; }
   HIP_TRY(build_bricks(g, h->bricks_owned, nullptr));
@@ -1309,6 +1326,7 @@ size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* st
   if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   else if (g.ndims == 1) bytes = records1_bytes(g, g.rec1_buckets);
   else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
+  else if (g.brick_cell == 2) brick_j4_geometry(g, nb, &bytes);
   else if (g.brick_cell) brick_cell_geometry(g, nb4, &bytes);
   else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
   return bytes;

@@ -166,6 +166,7 @@ hipError_t launch_generic(const GridDesc& g, const T* const* obs, T* out, size_t
 // Bricked multilinear path (k_linear_brick.hip).
 void brick_geometry(const GridDesc& g, int si, int sj, unsigned nb[3], size_t* bytes);
 void brick_cell_geometry(const GridDesc& g, unsigned nb[4], size_t* bytes);
+void brick_j4_geometry(const GridDesc& g, unsigned nb[3], size_t* bytes);  // f32 2 x 4 x 4 bricks (brick_cell == 2)
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,

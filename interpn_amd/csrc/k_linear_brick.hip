@@ -41,6 +41,17 @@ void brick_cell_geometry(const GridDesc& g, unsigned nb[4], size_t* bytes) {
   *bytes = lead * nb[3] * nb[0] * nb[1] * nb[2] * 128;
 }
 
+// f32 2 x 4 x 4 bricks (linear_brick.h, CELL == 2): nb = bricks along (i, j, k), steps (1, 3, 3).
+void brick_j4_geometry(const GridDesc& g, unsigned nb[3], size_t* bytes) {
+  const int N = g.ndims;
+  nb[0] = bricks_along(g.n[N - 3], 1);
+  nb[1] = bricks_along(g.n[N - 2], 3);
+  nb[2] = bricks_along(g.n[N - 1], 3);
+  size_t lead = 1;
+  for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
+  *bytes = lead * nb[0] * nb[1] * nb[2] * 128;
+}
+
 static hipError_t build_cell_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
   const int N = g.ndims;
   size_t lead = 1;
@@ -60,8 +71,20 @@ static hipError_t build_cell_bricks(const GridDesc& g, void* bricks, hipStream_t
 }
 
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
-  if (g.brick_cell) return build_cell_bricks(g, bricks, stream);
+  if (g.brick_cell == 1) return build_cell_bricks(g, bricks, stream);
   const int N = g.ndims;
+  if (g.brick_cell == 2) {
+    if (g.dtype != kF32) return hipErrorInvalidValue;
+    size_t lead4 = 1;
+    for (int d = 0; d < N - 3; ++d) lead4 *= (size_t)g.n[d];
+    const size_t elems4 = lead4 * g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * 32;
+    size_t blocks4 = (elems4 + kBlock - 1) / kBlock;
+    if (blocks4 > 65535) blocks4 = 65535;
+    hipLaunchKernelGGL(k_build_j4_bricks<float>, dim3((unsigned)blocks4), dim3(kBlock), 0, stream,
+                       static_cast<const float*>(g.vals), static_cast<float*>(bricks), lead4, g.n[N - 3], g.n[N - 2],
+                       g.n[N - 1], g.brick_nb[0], g.brick_nb[1], g.brick_nb[2]);
+    return hipGetLastError();
+  }
   size_t lead = 1;
   for (int d = 0; d < N - 3; ++d) lead *= (size_t)g.n[d];
   const size_t elems = lead * g.brick_nb[0] * g.brick_nb[1] * g.brick_nb[2] * (g.dtype == kF64 ? 16 : 32);
@@ -81,8 +104,15 @@ hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream) {
 template <typename T, int N, bool RECT, bool FMA, int PPL, int AXR>
 static hipError_t launch_steps(const GridDesc& g, const BrickArgs<T, N>& a, size_t lds, unsigned blocks, hipStream_t stream) {
   const int si = g.brick_step[0], sj = g.brick_step[1];
+  if constexpr (sizeof(T) == 4) {
+    if (g.brick_cell == 2) {
+      g.tag.set("k_linear_brick", {N, RECT, FMA, 1, 1, PPL, AXR, 0, 2}, 0b000000110u);
+      hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR, 0, 2>), dim3(blocks), dim3(kBlock), lds, stream, a);
+      return hipGetLastError();
+    }
+  }
   if constexpr (N >= 4) {
-    if (g.brick_cell) {
+    if (g.brick_cell == 1) {
       g.tag.set("k_linear_brick", {N, RECT, FMA, 1, 1, PPL, AXR, 0, 1}, 0b000000110u);
       hipLaunchKernelGGL((k_linear_brick<T, N, RECT, FMA, 1, 1, PPL, AXR, 0, 1>), dim3(blocks), dim3(kBlock), lds, stream, a);
       return hipGetLastError();
@@ -142,7 +172,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.lead_stride[0] = 0;
   for (int d = N - 4; d >= 0; --d) {
     a.lead_stride[d] = acc;
-    acc *= (g.brick_cell && d == N - 4) ? g.brick_nb[3] : (unsigned)g.n[d];
+    acc *= (g.brick_cell == 1 && d == N - 4) ? g.brick_nb[3] : (unsigned)g.n[d];
   }
   size_t lds = (size_t)kBlock * kPieceRow * sizeof(P) + (size_t)kBlock * 16;
   a.ax.use_lds = 0;
@@ -153,9 +183,14 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   // Two points per lane (vector coordinate/result accesses) for the 3-D shape when every stream is
   // aligned to 2*sizeof(T); the handle's `ppl` option = 1 forces the scalar form (tuning / testing).
   if constexpr (N == 3) {
-    bool aligned = (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0;
-    for (int d = 0; d < N; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
-    if (aligned && g.cfg.ppl != 1) return launch_kind<T, N, 2>(g, a, lds, axis_lds, npts, stream);
+    auto aligned_to = [&](size_t bytes) {
+      bool al = (reinterpret_cast<uintptr_t>(out) % bytes) == 0;
+      for (int d = 0; d < N; ++d) al = al && (reinterpret_cast<uintptr_t>(obs[d]) % bytes) == 0;
+      return al;
+    };
+    // (f32 with FOUR points per lane — the 16-byte stream accesses f64 gets with two — was built and
+    // measured in round 3: 64^3 0.666 against 0.661 ms, 72^3 0.790 against 0.769: no gain, not instantiated)
+    if (aligned_to(2 * sizeof(T)) && g.cfg.ppl != 1) return launch_kind<T, N, 2>(g, a, lds, axis_lds, npts, stream);
   }
   return launch_kind<T, N, 1>(g, a, lds, axis_lds, npts, stream);
 }

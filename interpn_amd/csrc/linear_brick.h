@@ -28,11 +28,16 @@ namespace interpn {
 //            128-B line, where the 3-D bricks need two (one per h plane).  16x the grid in f64
 //            (10.7x in f32).  The brick holds its two h planes as two (i,j) groups of 64 B, so the
 //            h-pair is reached with an in-brick offset of IJ elements instead of a table stride.
+// CELL == 2 (f32 only, round 3): 2(i) x 4(j) x 4(k) bricks over the last three dimensions, stepped
+//            (1, 3, 3): every cell lies inside ONE brick = one line, like the fully overlapped
+//            2 x 2 x 8 bricks, but the table is 3.56x the grid instead of 4.57x — at 64^3 3.4 MiB
+//            instead of 4.85 MiB, i.e. inside the 4 MiB L2 of an XCD.  Only f32 packs 32 values in
+//            a line; the f64 analogue of this shape IS the 2 x 2 x 4 brick.
 template <typename T, int CELL = 0> struct BrickGeom {
-  static constexpr int KW = (CELL ? 16 : 32) / (int)sizeof(T);  // elements per brick row
+  static constexpr int KW = CELL == 2 ? 4 : (CELL ? 16 : 32) / (int)sizeof(T);  // elements per brick row
   static constexpr int SK = KW - 1;                             // brick step along k
   static constexpr int IJ = 4 * KW;                             // elements of one (i,j) group: the four pieces of a gather
-  static constexpr int ELEMS = (CELL ? 2 : 1) * IJ;             // elements per brick (128 B)
+  static constexpr int ELEMS = CELL == 2 ? 32 : (CELL ? 2 : 1) * IJ;  // elements per brick (128 B)
 };
 
 template <typename T, int N>
@@ -54,6 +59,11 @@ struct BrickArgs {
 template <typename T, int SI, int SJ, int CELL = 0>
 __device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int i, int j, unsigned kpart, int di, int dj) {
   constexpr int KW = BrickGeom<T, CELL>::KW;
+  if constexpr (CELL == 2) {  // rows (oi, oj) of 4 elements, oi = 0..1, oj = 0..3; j stepped 3
+    const int bj3 = j / 3;
+    const int oj3 = j - 3 * bj3 + dj;
+    return ((unsigned)(i * (int)nbj + bj3) * nbk) * 32u + (unsigned)((di * 4 + oj3) * 4) + kpart;
+  }
   int bi, oi, bj, oj;
   if (SI == 1) { bi = i; oi = di; }
   else { bi = i >> 1; oi = (i & 1) + di; if (oi == 2) { bi += 1; oi = 0; } }
@@ -174,7 +184,8 @@ struct LeadReduce<T, 0, FMA> {
 // PPL = points per lane.  With PPL = 2 a lane owns two consecutive points, so coordinates and
 // results move as 2*sizeof(T)-byte vectors (16 B in f64): the streams then cost the L2 fewer
 // channel-cycles per line (measured -4 % at 64^3, -7 % at 32^3; tools/tune_layout ... w).  Needs all
-// obs/out pointers aligned to 2*sizeof(T); the launcher falls back to PPL = 1 otherwise.
+// obs/out pointers aligned to PPL*sizeof(T); the launcher falls back to a smaller PPL otherwise.
+// f32 takes PPL = 4 for the same 16-byte accesses (round 3, 3-D).
 // AXR != 0 (rectilinear, every axis <= 64 coordinates): the axes live in registers, one
 // coordinate per lane, and are searched with cross-lane reads instead of LDS gathers.
 //   AXR == 1: the reference's binary-search probe sequence, six lockstep steps (any axis);
@@ -205,7 +216,8 @@ __device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int 
 
 template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0, int ABL = 0, int CELL = 0>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
-  static_assert(CELL == 0 || (N >= 4 && SI == 1 && SJ == 1), "4-D cell bricks: N >= 4, fully overlapped");
+  static_assert(CELL == 0 || (CELL == 1 && N >= 4 && SI == 1 && SJ == 1) || (CELL == 2 && sizeof(T) == 4 && SI == 1 && SJ == 1),
+                "4-D cell bricks: N >= 4, fully overlapped; 2 x 4 x 4 bricks: f32");
   typedef typename LeafVec<T, 2>::type P;
   typedef BrickGeom<T, CELL> Geom;
   constexpr int L = N - 3;
@@ -258,16 +270,22 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         xin[PPL - 1][d] = v.y;
       }
       wave_sync();
-    } else if (PPL == 2) {
+    } else if (PPL >= 2) {
+      typedef T TV __attribute__((ext_vector_type(PPL)));
 #pragma unroll
       for (int d = 0; d < N; ++d) {
-        T2 v;
-        v.x = RECT ? (T)0 : a.start[d];
-        v.y = v.x;
-        if (live[PPL - 1]) v = stream_load(reinterpret_cast<const T2*>(a.obs[d] + i0));
-        else if (live[0]) v.x = stream_load(a.obs[d] + i0);
-        xin[0][d] = v.x;
-        xin[PPL - 1][d] = v.y;
+        TV v;
+#pragma unroll
+        for (int h = 0; h < PPL; ++h) v[h] = RECT ? (T)0 : a.start[d];
+        if (live[PPL - 1]) {
+          v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + i0));
+        } else {  // the batch's ragged tail: element by element
+#pragma unroll
+          for (int h = 0; h < PPL; ++h)
+            if (live[h]) v[h] = stream_load(a.obs[d] + i0 + h);
+        }
+#pragma unroll
+        for (int h = 0; h < PPL; ++h) xin[h][d] = v[h];
       }
     } else {
 #pragma unroll
@@ -338,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
         // except the h dimension of 4-D cell bricks, whose pair sits inside the brick
         unsigned ls[L > 0 ? L : 1];
 #pragma unroll
-        for (int d = 0; d < L; ++d) ls[d] = (CELL && d == L - 1) ? (unsigned)Geom::IJ : a.lead_stride[d];
+        for (int d = 0; d < L; ++d) ls[d] = (CELL == 1 && d == L - 1) ? (unsigned)Geom::IJ : a.lead_stride[d];
         c = LeadReduce<T, L, FMA>::run(a.bricks, toff, 0u, ls, t, lds_piece, quad, q);
       }
       // Trailing three dims, reference order (multilinear/regular.rs:347-403): i first, k last.
@@ -354,14 +372,17 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
     if constexpr (ABL == 2) {
       // keep the results alive without a store the memory system would see
       if (resv[0] == (T)1234567.25 && resv[PPL - 1] == (T)-7654321.5) a.out[i0] = resv[0];
-    } else if (PPL == 2) {
+    } else if (PPL >= 2) {
+      typedef T TV __attribute__((ext_vector_type(PPL)));
       if (live[PPL - 1]) {
-        T2 v;
-        v.x = resv[0];
-        v.y = resv[PPL - 1];
-        stream_store(reinterpret_cast<T2*>(a.out + i0), v);
-      } else if (live[0]) {
-        stream_store(a.out + i0, resv[0]);
+        TV v;
+#pragma unroll
+        for (int h = 0; h < PPL; ++h) v[h] = resv[h];
+        stream_store(reinterpret_cast<TV*>(a.out + i0), v);
+      } else {
+#pragma unroll
+        for (int h = 0; h < PPL; ++h)
+          if (live[h]) stream_store(a.out + i0 + h, resv[h]);
       }
     } else if (live[0]) {
       stream_store(a.out + i0, resv[0]);
@@ -389,6 +410,29 @@ __global__ void __launch_bounds__(kBlock) k_build_bricks(const T* __restrict__ v
     const int i = (int)bi * si + (int)(within / (2 * KW));
     const int j = (int)bj * sj + (int)((within / KW) & 1);
     const int k = (int)bk * (KW - 1) + (int)(within % KW);
+    T v = (T)0;
+    if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];
+    bricks[e] = v;
+  }
+}
+
+// f32 2 x 4 x 4 bricks (CELL == 2): table[lead][bi][bj][bk][oi 0..1][oj 0..3][ok 0..3], steps (1, 3, 3).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_j4_bricks(const T* __restrict__ vals, T* __restrict__ bricks, size_t nlead,
+                                                            int n0, int n1, int n2, unsigned nbi, unsigned nbj, unsigned nbk) {
+  const size_t per_lead = (size_t)nbi * nbj * nbk * 32;
+  const size_t total = nlead * per_lead;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const size_t lead = e / per_lead;
+    size_t b = e - lead * per_lead;
+    const unsigned within = (unsigned)(b & 31);
+    b >>= 5;
+    const unsigned bk = (unsigned)(b % nbk); b /= nbk;
+    const unsigned bj = (unsigned)(b % nbj); b /= nbj;
+    const unsigned bi = (unsigned)b;
+    const int i = (int)bi + (int)(within >> 4);
+    const int j = (int)bj * 3 + (int)((within >> 2) & 3);
+    const int k = (int)bk * 3 + (int)(within & 3);
     T v = (T)0;
     if (i < n0 && j < n1 && k < n2) v = vals[((lead * n0 + i) * n1 + j) * n2 + k];
     bricks[e] = v;

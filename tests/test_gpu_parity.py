@@ -129,14 +129,14 @@ def test_recursive_arm_cubic_8d(oracle, kind, linearize, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["regular", "rectilinear"])
-@pytest.mark.parametrize("layout", ["off", "11", "12", "22", "c4"])
+@pytest.mark.parametrize("layout", ["off", "11", "12", "22", "c4", "j4"])
 @pytest.mark.parametrize("axis", [[2, 2, 2], [3, 4, 5], [17, 9, 32], [64, 64, 64], [8, 7, 3], [5, 9, 8, 17],
                                   [2, 3, 2, 2, 9], [3, 2, 4, 3, 5, 4]], ids=str)
 def test_linear_brick_layouts(oracle, monkeypatch, dtype, kind, layout, axis):
     """Multilinear N = 3..6 runs on a bricked copy of the grid with a quad-cooperative gather
     (k_linear_brick.hip); every brick overlap scheme and the C-order kernel must give the same
     bits, including 2-point axes, odd sizes, leading dimensions and NaN / out-of-range
-    coordinates."""
+    coordinates.  `j4` = the f32-only 2 x 4 x 4 bricks (ignored for f64)."""
     monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
     n = len(axis)
     case = synthetic_case("linear", kind, n, axis, 40_001, 900 + sum(axis), dtype, extrap=0.3,

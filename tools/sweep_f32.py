@@ -10,10 +10,14 @@ P = 100_000_000
 gen = torch.Generator(device=dev); gen.manual_seed(5)
 obs = [torch.rand(P, dtype=torch.float32, device=dev, generator=gen) * 2 - 1 for _ in range(3)]
 out = torch.empty(P, dtype=torch.float32, device=dev)
-for n in (32, 48, 56, 64, 72, 80, 96, 112, 128, 160):
+for n in (32, 48, 56, 64, 68, 72, 80, 96, 112, 128, 160):
     row = {}
-    for lay in ("22", "12", "11", "auto"):
+    for lay in ("22", "12", "11", "j4", "auto"):
+        os.environ.pop("INTERPN_HIP_PPL", None)
         if lay == "auto": os.environ.pop("INTERPN_HIP_BRICKS", None)
+        elif lay == "j4ppl2":
+            os.environ["INTERPN_HIP_BRICKS"] = "j4"
+            os.environ["INTERPN_HIP_PPL"] = "2"
         else: os.environ["INTERPN_HIP_BRICKS"] = lay
         g = np.linspace(-1, 1, n).astype(np.float32)
         vals = np.random.default_rng(1).uniform(-1, 1, n ** 3).astype(np.float32)
