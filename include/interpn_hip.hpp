@@ -254,11 +254,17 @@ class Handle {
   interpn_hip_interp* h_ = nullptr;
 };
 
+#if defined(INTERPN_HIP_FEATURE_FMA)
+constexpr int kFlavour = INTERPN_HIP_FEATURE_FMA ? INTERPN_HIP_FLAVOUR_FMA : INTERPN_HIP_FLAVOUR_NO_FMA;
+#else
+constexpr int kFlavour = 0;  // the process default (interpn_hip_set_fma)
+#endif
+
 template <class Derived, class T, std::size_t N>
 inline Result<Derived> make_regular(int method, const std::array<std::size_t, N>& dims, const std::array<T, N>& starts,
                                     const std::array<T, N>& steps, Slice<T> vals, bool linearize, int device) {
   interpn_hip_interp* h = nullptr;
-  const int st = Abi<T>::create_regular(method, dims.data(), N, starts.data(), N, steps.data(), N, vals.ptr, vals.len(),
+  const int st = Abi<T>::create_regular(method | kFlavour, dims.data(), N, starts.data(), N, steps.data(), N, vals.ptr, vals.len(),
                                         INTERPN_HIP_MEM_HOST, linearize ? 1 : 0, device, &h);
   return st == INTERPN_HIP_OK ? Result<Derived>::Ok(Derived(h)) : Result<Derived>::Err(st);
 }
@@ -267,7 +273,7 @@ template <class Derived, class T, std::size_t N>
 inline Result<Derived> make_rectilinear(int method, const std::array<Slice<T>, N>& grids, Slice<T> vals, bool linearize, int device) {
   Unpacked<T> g(grids);
   interpn_hip_interp* h = nullptr;
-  const int st = Abi<T>::create_rectilinear(method, g.ptrs.data(), g.lens.data(), N, vals.ptr, vals.len(), INTERPN_HIP_MEM_HOST,
+  const int st = Abi<T>::create_rectilinear(method | kFlavour, g.ptrs.data(), g.lens.data(), N, vals.ptr, vals.len(), INTERPN_HIP_MEM_HOST,
                                             linearize ? 1 : 0, device, &h);
   return st == INTERPN_HIP_OK ? Result<Derived>::Ok(Derived(h)) : Result<Derived>::Err(st);
 }
@@ -566,8 +572,11 @@ inline std::vector<std::vector<T>> meshgrid(const std::vector<const std::vector<
 
 }  // namespace utils
 
-// The `fma` cargo feature (Cargo.toml:35; on in the published wheels): selects the flavour the
-// kernels compute in, process-wide, for handles created afterwards.
+// The `fma` cargo feature (Cargo.toml:35; on in the published wheels).  Like the crate's it is
+// chosen at COMPILE time, per translation unit: define INTERPN_HIP_FEATURE_FMA as 1 or 0 before
+// including this header and every interpolator struct created through it carries that flavour
+// (a per-handle property of the C ABI: INTERPN_HIP_FLAVOUR_*).  Left undefined, the structs follow
+// the process default, which `set_fma` changes (also what the one-shot `interpn` functions use).
 inline void set_fma(bool enabled) { interpn_hip_set_fma(enabled ? 1 : 0); }
 
 }  // namespace interpn_hip

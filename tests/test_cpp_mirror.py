@@ -51,3 +51,14 @@ def test_reference_rust_tests_through_the_cpp_mirror(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ALL PASSED" in res.stdout and "FAIL" not in res.stdout
     assert res.stdout.count("PASS ") == 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", ["1", "0"], ids=["fma", "nofma"])
+def test_reference_rust_tests_with_the_fma_feature_chosen_at_compile_time(tmp_path, feature):
+    """`-DINTERPN_HIP_FEATURE_FMA=1|0` is the C++ counterpart of building the crate with or without
+    `--features fma` (Cargo.toml:34-38): the structs then carry that flavour (a per-handle property
+    of the ABI) and the crate's tests — whose tolerances hold for both cargo flavours — pass."""
+    res = subprocess.run([build(tmp_path, extra=(f"-DINTERPN_HIP_FEATURE_FMA={feature}",))], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ALL PASSED" in res.stdout and "FAIL" not in res.stdout
