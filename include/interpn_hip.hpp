@@ -256,6 +256,10 @@ class Handle {
 
 #if defined(INTERPN_HIP_FEATURE_FMA)
 constexpr int kFlavour = INTERPN_HIP_FEATURE_FMA ? INTERPN_HIP_FLAVOUR_FMA : INTERPN_HIP_FLAVOUR_NO_FMA;
+// The one-shot `interpn` functions have the crate's signatures — no place for a flavour — and
+// follow the process default: a program built with the feature macro sets it once, at start-up
+// (a cargo feature is a whole-program choice too).
+inline const int kFeatureFmaApplied = (interpn_hip_set_fma(INTERPN_HIP_FEATURE_FMA ? 1 : 0), 0);
 #else
 constexpr int kFlavour = 0;  // the process default (interpn_hip_set_fma)
 #endif
