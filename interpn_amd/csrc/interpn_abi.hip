@@ -337,6 +337,7 @@ struct interpn_hip_interp {
     bool busy = false;           // a host thread is enqueueing into this block right now
     hipStream_t last_stream = nullptr;
     unsigned long long stamp = 0;  // use counter value of the last use (LRU)
+    bool totals_clean = false;     // the block's bin counters are zero (left so by the last complete sort's scan)
     hipEvent_t stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // option stage_timing: start | hist | scan | scatter | kernel
     bool staged = false;           // the last use recorded them (single slice)
   };
@@ -1456,6 +1457,7 @@ interpn_hip_interp::BinSlot* take_bin_slot(interpn_hip_interp* h, size_t need, h
       pool_free(h->device, pick->scratch);
       pick->scratch = nullptr;
       pick->bytes = 0;
+      pick->totals_clean = false;
       pick->recorded = false;
       if (pool_alloc(h->device, &pick->scratch, need) != hipSuccess) { (void)hipGetLastError(); pick->scratch = nullptr; *why = INTERPN_HIP_WHY_ALLOC_FAILED; return nullptr; }
       pick->bytes = need;
@@ -1556,7 +1558,8 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part < kColumnMaxPart ? (size_t)g.cfg.column_part : kColumnMaxPart;
       const size_t max_parts = count / q + (size_t)plan.nbins + 1;
       BinExtras extras;
-      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage);
+      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage, slot->totals_clean);
+      slot->totals_clean = err == hipSuccess;
       if (err != hipSuccess) break;
       if (g.dtype == kF64)
         err = launch_cubic_column<double>(*use, plan, extras, index, reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
@@ -1564,7 +1567,8 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
         err = launch_cubic_column<float>(*use, plan, extras, index, reinterpret_cast<float*>(dst), count, max_parts, h->first_bad, begin, stream);
       continue;
     }
-    err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, nullptr, 0, stage);
+    err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, nullptr, 0, stage, slot->totals_clean);
+    slot->totals_clean = err == hipSuccess;
     if (err != hipSuccess) break;
     if (g.dtype == kF64)
       err = launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
@@ -1685,6 +1689,7 @@ int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {
     pool_free(h->device, sl.scratch);
     sl.scratch = nullptr;
     sl.bytes = 0;
+    sl.totals_clean = false;
     sl.recorded = false;
     hipError_t e = pool_alloc(h->device, &sl.scratch, need);
     if (e != hipSuccess) { (void)hipGetLastError(); sl.scratch = nullptr; return INTERPN_HIP_ERR_OUT_OF_MEMORY; }

@@ -231,11 +231,12 @@ struct BinExtras {
 };
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
 // original indices (within the slice).  `stage` (optional, 4 events): recorded in front of the
-// histogram, behind it, behind the scan and behind the scatter.  `extras` (4-D only): the sorted points are written as
+// histogram, behind it, behind the scan and behind the scatter.  `totals_clean`: the scratch block's
+// bin counters are known to be zero (the scan of the previous complete sort left them so), no reset launch.  `extras` (4-D only): the sorted points are written as
 // records instead, and the bins are cut into parts of at most `part_points` points.
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
                       const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras = nullptr,
-                      unsigned part_points = 0, hipEvent_t* stage = nullptr);
+                      unsigned part_points = 0, hipEvent_t* stage = nullptr, bool totals_clean = false);
 
 // Column evaluation of sorted 4-D multicubic points on a regular grid (cubic_column.h): does it
 // apply to this grid (LDS capacity, classes fit the bins), and the launch.

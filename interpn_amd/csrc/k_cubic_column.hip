@@ -1,4 +1,6 @@
 // Launcher of the LDS-column multicubic kernel for sorted 4-D points (cubic_column.h).
+#include <mutex>
+
 #include "cubic_column.h"
 
 namespace interpn {
@@ -10,6 +12,31 @@ constexpr size_t kColumnLdsMax = kColumnBytesMax + kColumnPermBytes;  // dynamic
 
 template <typename T>
 size_t column_bytes(const GridDesc& g) { return col_lds_bytes<T>((unsigned)g.n[2] * (unsigned)g.n[3]); }
+
+// More than 64 KiB of dynamic LDS needs the opt-in, once per kernel and device: remembered here so
+// that the launch path does not pay the call (microseconds) every time.
+hipError_t column_lds_opt_in(const void* kernel) {
+  struct Seen { const void* fn; unsigned long long devices; };
+  static std::mutex mu;
+  static Seen seen[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
+  Seen* slot = nullptr;
+  if (dev >= 0) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (Seen& s : seen) {
+      if (s.fn == kernel) { slot = &s; break; }
+      if (!s.fn) { s.fn = kernel; slot = &s; break; }
+    }
+    if (slot && ((slot->devices >> dev) & 1ull)) return hipSuccess;
+  }
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColumnLdsMax);
+  if (e == hipSuccess && slot) {
+    std::lock_guard<std::mutex> lk(mu);
+    slot->devices |= 1ull << dev;
+  }
+  return e;
+}
 }  // namespace
 
 bool cubic_column_applies(const GridDesc& g) {
@@ -60,10 +87,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.linearize = g.linearize;
   a.ablate = g.cfg.column_ablate;
   const size_t lds = column_bytes<T>(g) + kColumnPermBytes;
-  // More than 64 KiB of dynamic LDS needs the opt-in, once per kernel and device.
-  auto prepare = [&](auto kernel) -> hipError_t {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColumnLdsMax);
-  };
+  auto prepare = [&](auto kernel) -> hipError_t { return column_lds_opt_in(reinterpret_cast<const void*>(kernel)); };
   hipError_t e = hipSuccess;
   const int threads = g.cfg.column_threads == 1024 ? 1024 : (g.cfg.column_threads == 768 ? 768 : 512);
 #define GO(FMA, TH)                                                                                              \
