@@ -1770,3 +1770,44 @@ def test_rectilinear_bucket_records(oracle, monkeypatch, dtype, method, axis):
             same = (got == want) | (np.isnan(got) & np.isnan(want))
             assert np.all(same), (variant, records, axis_regs, int((~same).sum()))
             it.close()
+
+
+def test_stage_timing_of_a_sorted_evaluation(oracle, monkeypatch):
+    """`interpn_hip_stage_ms` (bench.py's per-stage split of cfg4): with option stage_timing a
+    single-slice sorted evaluation records events between its launches; the four durations are
+    positive and add up to about the whole evaluation; without the option (or before any sorted
+    evaluation) the call reports INVALID_ARGUMENT; results are unchanged by the option."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    case = synthetic_case("cubic", "regular", 4, [6, 7, 5, 6], 400_000, 9960, np.float64, extrap=0.1, specials=False)
+    want = run_oracle(oracle, case, True)
+    it = _make_interp(interpn_amd, case)
+    it.set_option("binned", 1)
+    obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+    with pytest.raises(ValueError):
+        it.stage_ms()
+    out = it.eval_tensors(obs)
+    it.finish()
+    with pytest.raises(ValueError):  # sorted, but not timed
+        it.stage_ms()
+    it.set_option("stage_timing", 1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out2 = it.eval_tensors(obs)
+    b.record()
+    it.finish()
+    st = it.stage_ms()
+    assert set(st) == {"hist", "scan", "scatter", "kernel"} and all(v > 0 for v in st.values())
+    assert sum(st.values()) <= a.elapsed_time(b) * 1.05 + 0.05
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(out2.cpu().numpy(), want)
+    # several slices: no stage record
+    it.set_option("bin_slice_log2", 16)
+    it.eval_tensors(obs)
+    it.finish()
+    with pytest.raises(ValueError):
+        it.stage_ms()
+    it.close()
