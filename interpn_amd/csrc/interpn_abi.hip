@@ -342,8 +342,9 @@ struct interpn_hip_interp {
     bool staged = false;           // the last use recorded them (single slice)
   };
   std::mutex bin_mu;
-  std::vector<BinSlot> bin_slots;
+  std::vector<BinSlot> bin_slots;  // capacity kMaxBinSlots from the start: evaluations hold pointers to elements outside the lock
   unsigned long long bin_uses = 0;
+  interpn_hip_interp() { bin_slots.reserve(kMaxBinSlots); }
   std::atomic<long long> evals_binned{0}, evals_in_place{0}, scratch_allocs{0};
 };
 
