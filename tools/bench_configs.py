@@ -75,6 +75,7 @@ if __name__ == "__main__":
         ("cfg5-shard 3D linear regular 128^3 1e8", "linear", "regular", 128, 3, 100_000_000, False),
         ("extra 3D cubic regular 64^3 1e7", "cubic", "regular", 64, 3, 10_000_000, False),
         ("extra 3D cubic rectilinear 64^3 1e7", "cubic", "rectilinear", 64, 3, 10_000_000, False),
+        ("extra 4D cubic rectilinear 32^4 1e7", "cubic", "rectilinear", 32, 4, 10_000_000, False),
         ("extra 2D linear regular 1000^2 1e8", "linear", "regular", 1000, 2, 100_000_000, False),
         ("extra 4D linear regular 32^4 1e8", "linear", "regular", 32, 4, 100_000_000, False),
     ]
@@ -84,3 +85,5 @@ if __name__ == "__main__":
         run(*c)
     if not args.only or "f32" in args.only:
         run("extra f32 3D linear regular 64^3 1e8", "linear", "regular", 64, 3, 100_000_000, False, np.float32)
+        run("extra f32 3D linear rectilinear 64^3 1e8", "linear", "rectilinear", 64, 3, 100_000_000, False, np.float32)
+        run("extra f32 4D cubic regular 32^4 1e7", "cubic", "regular", 32, 4, 10_000_000, False, np.float32)
