@@ -1613,6 +1613,17 @@ def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monke
     assert not errors, errors
     assert it.get_option("evals_binned") == before + 20  # none of them fell back
     assert it.get_option("scratch_allocs") == 2 and it.get_option("scratch_bytes") == bytes2
+    # more streams than blocks: the extra ones wait (on the device) for the least recently used
+    # block instead of allocating or falling back
+    outs = []
+    for s in [torch.cuda.Stream() for _ in range(5)]:
+        with torch.cuda.stream(s):
+            outs.append(it.eval_tensors(obs, no_alloc=True))
+        assert it.last_path == "binned"
+    torch.cuda.synchronize()
+    it.finish()
+    assert all(np.array_equal(o.cpu().numpy(), want) for o in outs)
+    assert it.get_option("scratch_allocs") == 2 and it.get_option("scratch_bytes") == bytes2
     # a larger batch than reserved: allocation allowed -> grows; forbidden -> in place
     big = [torch.cat([o, o]) for o in obs]
     o2 = it.eval_tensors(big, no_alloc=True)
