@@ -83,9 +83,20 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
   for (int b = threadIdx.x; b < p.nbins; b += kBlock) hist[b] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * kHistChunk;
-  for (int it = 0; it < kHistIters; ++it) {
-    const size_t i = first + (size_t)it * kBlock + threadIdx.x;
-    if (i < npts) atomicAdd(&hist[bin_key_at<T>(p, x0[i], x1[i], i)], 1u);
+  // eight rows at a time, all sixteen loads issued before the first key is computed
+  for (int it0 = 0; it0 < kHistIters; it0 += 8) {
+    T a0[8], a1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t i = first + (size_t)(it0 + u) * kBlock + threadIdx.x;
+      a0[u] = i < npts ? stream_load(x0 + i) : (T)0;
+      a1[u] = i < npts ? stream_load(x1 + i) : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t i = first + (size_t)(it0 + u) * kBlock + threadIdx.x;
+      if (i < npts) atomicAdd(&hist[bin_key_at<T>(p, a0[u], a1[u], i)], 1u);
+    }
   }
   __syncthreads();
   for (int b = threadIdx.x; b < p.nbins; b += kBlock)
