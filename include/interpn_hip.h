@@ -38,7 +38,8 @@
  *     environment is read ONCE PER HANDLE, when it is created (never on the launch path); the
  *     per-handle options can be changed afterwards with interpn_hip_set_option(h, "<name>", v),
  *     <name> = the variable's suffix in lower case:
- *       INTERPN_HIP_BRICKS=off|11|12|22 (linear) |44|24|22|14|11 (cubic)   force / disable a layout (creation only)
+ *       INTERPN_HIP_BRICKS=off|11|12|22|c4|j4 (linear) |44|24|22|14|11 (cubic)   force / disable a layout (creation only;
+ *                                       c4 = 4-D cell bricks, j4 = the f32-only 2 x 4 x 4 bricks)
  *       INTERPN_HIP_BLOCKS_PER_CU=n     workgroups per CU a persistent launch grid is sized for (default 8)
  *       INTERPN_HIP_ITERS_PER_BLOCK=n   256-lane rows per workgroup of the one-pass brick kernels (0 = default)
  *       INTERPN_HIP_PPL=1               one point per lane in the multilinear brick kernels (0 = auto)
@@ -52,6 +53,16 @@
  *       INTERPN_HIP_AXIS_LDS_KB=n       LDS budget of the rectilinear axis image (-1 = default)
  *       INTERPN_HIP_PERSISTENT=1        C-order regular / nearest kernels: persistent grid
  *       INTERPN_HIP_HOST_CHUNK=n        points per chunk of the host-pointer pipeline (0 = default 2 Mi)
+ *       INTERPN_HIP_BINNED=-1|0|1       tiled multicubic, device-pointer evaluation: sort the points by table position
+ *                                       first (auto: large 4-D batches; 1: always, N = 2..4; 0: never)
+ *       INTERPN_HIP_COLUMN=-1|0|1       sorted 4-D multicubic on a regular grid: evaluate out of an LDS-resident table
+ *                                       column (auto: from ~3000 points per bin; 1: wherever it applies; 0: never);
+ *                                       INTERPN_HIP_COLUMN_THREADS=512|768|1024, INTERPN_HIP_COLUMN_PART=n (points per workgroup)
+ *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
+ *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
+ *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)
+ *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms),
+ *       "column_ablate" (timing probes of the column kernel: WRONG results by design, never set from the environment)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
  *                                       (process-wide, read once; default 1024; 0 = release
  *                                       everything at destroy)
