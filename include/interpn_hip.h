@@ -61,8 +61,7 @@
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
  *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)
- *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms),
- *       "column_ablate" (timing probes of the column kernel: WRONG results by design, never set from the environment)
+ *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
  *                                       (process-wide, read once; default 1024; 0 = release
  *                                       everything at destroy)

@@ -48,7 +48,6 @@ struct CubicColumnArgs {
   int linearize;
   unsigned plane_stride[4];  // table elements per unit index of dims 2, 3
   unsigned nbj;
-  int ablate;                // timing probes only (results wrong): 1 no store, 2 points in stored order, 4 no planes, 8 no fill
 };
 
 
@@ -253,19 +252,15 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
   // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram.
   // (Loads first, then the column fill is issued, then they are used: the fill overlaps this.)
   constexpr int kMaxMine = (int)((kColumnMaxPart + THREADS - 1) / THREADS);
-  const bool lsort = !(a.ablate & (2 | 16));  // kernel-uniform: probes 2 / 16 take the points in stored order
   unsigned short cls23[kMaxMine];
   {
     T x2[kMaxMine], x3[kMaxMine];
 #pragma unroll
     for (int m = 0; m < kMaxMine; ++m) {
       const unsigned q = (unsigned)m * THREADS + tid;
-      x2[m] = x3[m] = (T)0;
-      if (lsort) {
-        const RV r = q < count ? recs[q] : recs[0];
-        x2[m] = r[2];
-        x3[m] = r[3];
-      }
+      const RV r = q < count ? recs[q] : recs[0];
+      x2[m] = r[2];
+      x3[m] = r[3];
     }
     // ---- column fill: one LDS-DMA instruction = 1 KiB = four 256-byte rows of one 16-tile group;
     // lane L delivers piece (row0 + (L >> 4)) of tile 16 g + (L & 15).
@@ -276,7 +271,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
       const unsigned ninstr = ngroups * IPG;
       const unsigned wave = tid >> 6, wl = tid & 63u;
       typedef __attribute__((address_space(3))) unsigned char lds_byte;
-      for (unsigned q = wave; q < ((a.ablate & 8) ? 0u : ninstr); q += THREADS / 64) {
+      for (unsigned q = wave; q < ninstr; q += THREADS / 64) {
         const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
         const unsigned tile = g * 16u + (wl & 15u);
         const unsigned piece = r0 + (wl >> 4);
@@ -296,7 +291,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
       const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
       const unsigned c = h2 * (unsigned)(a.n[3] - 1) + h3;  // < (n2 - 1)(n3 - 1) <= 1024
       cls23[m] = (unsigned short)c;
-      if (lsort && q < count) atomicAdd(&s_hist[c], 1u);
+      if (q < count) atomicAdd(&s_hist[c], 1u);
     }
   }
   __syncthreads();
@@ -326,7 +321,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
 #pragma unroll
   for (int m = 0; m < kMaxMine; ++m) {
     const unsigned q = (unsigned)m * THREADS + tid;
-    if (lsort && q < count) perm[atomicAdd(&s_hist[cls23[m]], 1u)] = (unsigned short)q;
+    if (q < count) perm[atomicAdd(&s_hist[cls23[m]], 1u)] = (unsigned short)q;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the column has landed
   __syncthreads();
@@ -336,8 +331,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
     const unsigned j = j0 + tid;
     const bool live = j < count;
     // dead lanes (the last row's tail) redo the part's last point: they keep their wave uniform
-    unsigned q = live ? j : count - 1;
-    if (lsort) q = perm[q];  // (never read when it was not built)
+    const unsigned q = perm[live ? j : count - 1];
     const RV r = recs[q];
     CubicDimRegular<T> dim[4];
     int loc[4];
@@ -367,8 +361,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
     const int f0 = col_wave_form<T>(dim[0]), f1 = col_wave_form<T>(dim[1]);
     const int f2 = col_wave_form<T>(dim[2]), f3 = col_wave_form<T>(dim[3]);
     const unsigned t0 = (unsigned)loc[2] * n3 + (unsigned)loc[3];
-    T res = dim[0].tt + dim[1].tt + dim[2].tt + dim[3].tt;
-    if (!(a.ablate & 4)) {
+    T res;
     if ((f0 | f1 | f2 | f3) == kFormNone) res = col_reduce<T, FMA, kFormNone, PIPE, true>(lds_col, t0, n3, dim, f1, f2, f3);
     else
     switch (f0) {  // wave-uniform
@@ -376,7 +369,6 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
       case kFormLow: res = col_reduce<T, FMA, kFormLow, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
       case kFormHigh: res = col_reduce<T, FMA, kFormHigh, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
       default: res = col_reduce<T, FMA, kFormMixed, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-    }
     }
     // not my cell (the sort's estimate and the exact cell disagree on a boundary): from the table
     if (live && (loc[0] != ci || loc[1] != cj)) {
@@ -389,7 +381,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
       for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
       res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
     }
-    if (live && (!(a.ablate & 1) || res == (T)12345.678)) {
+    if (live) {
       const unsigned orig = a.index[begin + q];
       if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
       stream_store(a.out + orig, res);

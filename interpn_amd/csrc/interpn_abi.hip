@@ -700,7 +700,6 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"column", &c.column, -1, 1},
       {"column_part", &c.column_part, 0, 1 << 20},
       {"column_threads", &c.column_threads, 512, 1024},
-      {"column_ablate", &c.column_ablate, 0, 31},
       {"bin_scramble", &c.bin_scramble, 0, 1},
       {"stage_timing", &c.stage_timing, 0, 1},
       {"axis_records", &c.axis_records, 0, 1},

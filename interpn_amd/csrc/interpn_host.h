@@ -35,7 +35,6 @@ struct LaunchConfig {
   int axis_records = 1;    // rectilinear multilinear / nearest: search with per-bucket records where the handle has them (0: coordinates + tables as before)
   int stage_timing = 0;    // binned evaluation: record HIP events between its launches (interpn_hip_stage_ms; bench.py)
   int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
-  int column_ablate = 0;   // column evaluation, timing probes only (results wrong): 1 no store, 2 stored order, 4 no planes, 8 no fill
   int column_threads = 768; // column evaluation: threads per workgroup (768 = three waves per SIMD with 168 VGPRs, planes software-pipelined: 1.10 ms for cfg4; 1024: 1.17; 512: 1.18)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
 };

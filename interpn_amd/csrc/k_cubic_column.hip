@@ -85,7 +85,6 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.nb1 = plan.nb1;
   a.inv_mult = (unsigned)plan.inv_mult;
   a.linearize = g.linearize;
-  a.ablate = g.cfg.column_ablate;
   const size_t lds = column_bytes<T>(g) + kColumnPermBytes;
   auto prepare = [&](auto kernel) -> hipError_t { return column_lds_opt_in(reinterpret_cast<const void*>(kernel)); };
   hipError_t e = hipSuccess;
