@@ -31,9 +31,19 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # INTERPN_TEST_BACKEND=gloo + INTERPN_TEST_SAME_DEVICE=1: several ranks sharing the one GPU of the
+    # test box (RCCL refuses two ranks on one device): the same sharded call sequence with real
+    # handles, the grid staged through the host for the broadcast.
+    backend = os.environ.get("INTERPN_TEST_BACKEND", "nccl")
+    if os.environ.get("INTERPN_TEST_SAME_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where broadcast tensors live
     executed = {"backend": dist.get_backend(), "world": dist.get_world_size(), "cases": []}
     try:
         n, P = 24, 200_003
@@ -51,14 +61,16 @@ def main() -> int:
         # Rank 0 owns the grid; every rank receives vals AND the rectilinear axes as CUDA tensors
         # through RCCL broadcasts (one per array), then builds its interpolator on the broadcast
         # buffer itself (INTERPN_HIP_MEM_DEVICE: the handle borrows it, no second copy).
-        vals = torch.zeros(n**3, dtype=torch.float64, device=dev)
-        axes = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+        vals = torch.zeros(n**3, dtype=torch.float64, device=cdev)
+        axes = [torch.zeros(n, dtype=torch.float64, device=cdev) for _ in range(3)]
         if rank == 0:
             vals.copy_(torch.from_numpy(vals_host))
             for a, h in zip(axes, axes_host):
                 a.copy_(torch.from_numpy(h))
         broadcast_grid(vals, axes)
         torch.cuda.synchronize()
+        if backend != "nccl":
+            vals = vals.to(dev)  # the handle is built on a device buffer either way
         assert np.array_equal(vals.cpu().numpy(), vals_host)
         grids = [a.cpu().numpy() for a in axes]
         assert all(np.array_equal(a, b) for a, b in zip(grids, axes_host))

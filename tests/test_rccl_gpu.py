@@ -53,6 +53,27 @@ def test_sharded_path_over_rccl_world_size_1():
 
 
 @pytest.mark.gpu
+def test_sharded_path_two_ranks_on_one_gpu_over_gloo():
+    """Two real ranks (two processes, two HIP contexts, real interpolator handles) sharing the test
+    box's one GPU over gloo: contiguous shards, the first-bad index found in the LAST rank's shard
+    and reported by every rank, results assembled on rank 0 and bit-identical to the oracle."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = _env()
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "2", "MASTER_PORT": str(port),
+                    "INTERPN_TEST_BACKEND": "gloo", "INTERPN_TEST_SAME_DEVICE": "1"})
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests.rccl_child"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(o[0][-1000:], o[1][-3000:]) for o in outs]
+    rec = _last_json(outs[0][0])
+    assert rec["backend"] == "gloo" and rec["world"] == 2
+    kinds = {c["kind"]: c for c in rec["cases"]}
+    assert all(c["bitwise_equal"] for c in kinds.values()) and kinds["regular"]["first_bad_index"] == 200_003 - 1234
+
+
+@pytest.mark.gpu
 def test_bench_force_dist_over_rccl_records_what_happened():
     env = _env()
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):  # bench.py is started plainly, as the driver does at N = 1
