@@ -89,7 +89,9 @@ with open(OUT + '/cfg4_counters.txt', 'w') as f:
     for mode in (1, 0):
         agg = collections.OrderedDict()
         for r in rows(f'c4_b{mode}_p*'):
-            k = r['Kernel_Name'].split('(')[0].split('<')[0].split('::')[-1]
+            import re
+            m = re.search(r'(k_[a-z0-9_]+)', r['Kernel_Name'])
+            k = m.group(1) if m else r['Kernel_Name'][:24]
             agg.setdefault((k, r['Counter_Name']), []).append(float(r['Counter_Value']))
         ms = None
         try:
