@@ -61,6 +61,23 @@ def _collective_device(dist):
     return torch.device("cpu")
 
 
+_HOST_GROUP = None  # one gloo group beside an nccl default group, shared by every ShardedInterpolator
+
+
+def _host_side_group(dist):
+    """The group host-memory objects travel through: the default group unless it is nccl (RCCL moves
+    device memory only), in which case ONE gloo group over the same ranks, created on first use —
+    `new_group` is a collective, so every rank creates it at the same point: its first
+    ShardedInterpolator."""
+    global _HOST_GROUP
+    if dist.get_backend() != "nccl":
+        return None
+    world = dist.group.WORLD
+    if _HOST_GROUP is None or _HOST_GROUP[0] is not world:  # (a process may destroy its group and initialise another)
+        _HOST_GROUP = (world, dist.new_group(backend="gloo"))
+    return _HOST_GROUP[1]
+
+
 class ShardedInterpolator:
     """One rank's view of a sharded evaluation."""
 
@@ -74,9 +91,7 @@ class ShardedInterpolator:
         # Host-side assembly of `out` moves numpy shards: RCCL moves device memory only, so under
         # the nccl backend a gloo group over the same ranks carries them (created here because
         # new_group is itself a collective every rank must join).
-        self._host_group = None
-        if self._grouped and dist.get_backend() == "nccl":
-            self._host_group = dist.new_group(backend="gloo")
+        self._host_group = _host_side_group(dist) if self._grouped else None
         self.method, self.kind = method, kind
         if evaluator_factory is None:
             from .handle import Interpolator
