@@ -1,26 +1,34 @@
-// 4-D multicubic on SORTED points with the table column of a cell resident in LDS.
+// 4-D multicubic on SORTED points with (part of) the table column of a cell resident in LDS.
 //
 // After the counting sort of k_bin_points.hip with one bin per (i, j) cell of dims 0 and 1, all
 // points of a bin read the SAME 4 x 4 (i, j) footprint of every (k, l) plane: n2 x n3 tiles of the
 // fully overlapped tile table (cubic_brick.h), 128 B each in f64 — 128 KiB for cfg4's 32 x 32
-// planes, which fits the 160 KiB LDS of a CU.  A 1024-thread workgroup therefore loads that column
-// ONCE (LDS-DMA, one 1-KiB instruction per 8 tiles) and then evaluates its share of the bin's
-// points entirely out of LDS: a point still reads its 16 tiles = 2 KiB, but from the CU's own
-// LDS (256 B/clk) instead of 16 L2 lines (the tiled kernel on sorted points spends 1.04 ms per
-// 1e7 points on 1.6e8 L2-hit line requests; here the L2 sees 1024 lines per ~6000 points).
+// planes.  A workgroup takes one part of a bin (<= 16 points per thread), sorts it locally by the
+// class pair of dims 2, 3 and evaluates it out of LDS: a point still reads its 16 tiles = 2 KiB,
+// but from the CU's own LDS (256 B/clk) instead of 16 L2 lines.
+//
+// Round 4: the column is resident only a K-RANGE AT A TIME.  The part's local order is by the
+// class of dim 2 first, so the points whose dim-2 class lies in [r * cpp, (r + 1) * cpp) are one
+// contiguous stretch of it ("phase" r) and need only the tile rows k = loc2 .. loc2 + 3 of those
+// classes: cpp + 3 rows of n3 tiles.  With 13-row sub-columns (52 KiB for cfg4) TWO workgroups fit
+// a CU, and the set-up of one (part lookup, record loads, local sort, LDS-DMA fill: memory
+// latency, no arithmetic) runs under the plane arithmetic of the other; with the whole column
+// (round 3: 148 KiB, one workgroup per CU) those phases were serial on every CU.  Columns larger
+// than the LDS (48^4: 288 KiB) are simply more phases.  A wave whose 64 slots of a phase are all
+// beyond its end skips the row (no idle arithmetic in the tail rows), and the record of the next
+// row is requested before this row's planes are evaluated.
 //
 // LDS layout: tiles are interleaved sixteen at a time — piece c (16 bytes) of tile T sits at
 //   (T >> 4) * (16 * TILE) + c * 256 + (T & 15) * 16,          TILE = 16 * sizeof(T) bytes
-// so a `ds_read_b128` of piece c by 16 lanes (one LDS lane group) with different tiles hits the
-// 16-byte slot (T & 15): different slots for different (l + dl) & 15, no fixed conflict pattern
-// (tile-major storage would put all 16 lanes of a group on two slots: 8-way conflicts), and the
-// eight pieces of a tile are reached from ONE address register with immediate offsets c * 256.
+// (T counted from the first row of the phase) so the eight pieces of a tile are reached from ONE
+// address register with immediate offsets c * 256; lanes of a wave mostly read the SAME tile after
+// the local sort (broadcast), so the layout never conflicts in a fixed pattern.
 //
 // Arithmetic, plane order and reduction tree are those of cubic_brick.h / the reference
 // (src/multicubic/regular.rs:325-623): bit-identical results.  A point whose exact cell is not
-// the workgroup's (the sort's cell estimate multiplies by a reciprocal, the kernel divides like
-// the reference; they can disagree on a cell boundary) is evaluated from the table in global
-// memory by the same code path as the unsorted kernel's gather.
+// the workgroup's, or whose exact dim-2 rows are not in the phase's sub-column (the sorts estimate
+// classes by multiplying with a reciprocal, the kernel divides like the reference; they can
+// disagree on a cell boundary) is evaluated from the table in global memory by the same tree.
 #pragma once
 #include "cubic_brick.h"
 
@@ -48,7 +56,16 @@ struct CubicColumnArgs {
   int linearize;
   unsigned plane_stride[4];  // table elements per unit index of dims 2, 3
   unsigned nbj;
+  // K-range phases (see the head of this file)
+  int cpp;                   // classes of dim 2 per phase (>= 1); a phase's sub-column has at most cpp + 3 tile rows
+  int nphase;                // ceil((n2 - 1) / cpp)
+  int q3;                    // local sort key = class of dim 2 * q3 + (class of dim 3 >> sh3); (n2 - 1) * q3 <= 1024
+  int sh3;
+  unsigned sub_bytes;        // LDS bytes reserved for the sub-column; the part's local order (16-bit) sits behind them
+  unsigned long long* stamps;  // measurement aid (option debug_stamps): 8 words per workgroup, or null
 };
+
+constexpr int kColPerThread = 16;  // points of a part per thread at most (register arrays of the local sort)
 
 
 template <typename T> constexpr unsigned col_tile_bytes() { return 16u * (unsigned)sizeof(T); }
@@ -194,18 +211,27 @@ __device__ __forceinline__ unsigned col_class_hint(T x, T start, T rstep, int n)
   return u >= (T)1 ? (u < (T)(n - 2) ? (unsigned)(int)u : (unsigned)(n - 2)) : 0u;
 }
 
+// Registers: 12 waves per CU = three per SIMD (168 VGPRs) whether they come as two 384-thread
+// workgroups, three of 256 or one of 768; 512-thread workgroups pair up at four per SIMD (128).
 template <typename T, bool FMA, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<T> a) {
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? 4 : 3)))
+k_cubic_column(const CubicColumnArgs<T> a) {
   constexpr bool PIPE = THREADS <= 768;  // 168+ VGPRs per lane: room for a second tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_col[];
   __shared__ int s_bin;
   __shared__ unsigned s_begin, s_end;
-  __shared__ unsigned s_hist[1024];   // local sort: points per (dim 2, dim 3) class pair, then their first slot
+  __shared__ unsigned s_hist[1024];   // local sort: points per key, then (after pass 2) the END of every key's stretch
+  __shared__ unsigned s_wave[THREADS / 64];
+  __shared__ unsigned s_row;          // next 64-slot row of the current phase (rows are dealt to the waves as they free up)
   const unsigned tid = threadIdx.x;
+  const unsigned wave = tid >> 6, wl = tid & 63u;
+  unsigned long long t_stamp[6] = {0, 0, 0, 0, 0, 0};
+  if (a.stamps && tid == 0) t_stamp[0] = wall_clock64();
   // Which (bin, part) is this workgroup?  part_prefix is non-decreasing, [nbins] = number of parts:
-  // the bin b with part_prefix[b] <= w < part_prefix[b + 1] — every thread tests one bin (a
-  // single thread bisecting costs ten dependent global loads, ~10 us of the workgroup's ~100).
-  if (tid == 0) s_bin = -1;
+  // the bin b with part_prefix[b] <= w < part_prefix[b + 1] — every thread tests bins (a single
+  // thread bisecting costs ten dependent global loads, ~10 us).
+  if (tid == 0) { s_bin = -1; s_row = 0; }
+  for (unsigned c = tid; c < 1024u; c += THREADS) s_hist[c] = 0;
   __syncthreads();
   {
     const unsigned w = blockIdx.x;
@@ -227,74 +253,90 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
       }
     }
   }
-  for (unsigned c = tid; c < 1024u; c += THREADS) s_hist[c] = 0;
   __syncthreads();
   const int bin = s_bin;
   if (bin < 0) return;
   const unsigned begin = s_begin, end = s_end;
   if (begin >= end) return;
-  const unsigned count = end - begin;  // <= kColumnMaxPart
+  const unsigned count = end - begin;  // <= kColPerThread * THREADS (the scan cut the bin accordingly)
+  if (a.stamps && tid == 0) t_stamp[1] = wall_clock64();
   const unsigned key = (unsigned)(((unsigned long long)(unsigned)bin * a.inv_mult) % (unsigned)a.nbins);
   const int c0 = (int)(key / (unsigned)a.nb1), c1 = (int)(key % (unsigned)a.nb1);  // nominal classes of dims 0, 1
   const int ci = c0 - 1 < 0 ? 0 : (c0 - 1 > a.n[0] - 4 ? a.n[0] - 4 : c0 - 1);      // their footprint cell
   const int cj = c1 - 1 < 0 ? 0 : (c1 - 1 > a.n[1] - 4 ? a.n[1] - 4 : c1 - 1);
   const unsigned n3 = (unsigned)a.n[3];
-  const unsigned ntiles = (unsigned)a.n[2] * n3;
+  const int ncls2 = a.n[2] - 1;
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.tiles, a.table_bytes);
   const unsigned cell_off = (unsigned)(ci * (int)a.nbj + cj) * 16u * (unsigned)sizeof(T);  // my cell's tile inside a plane, bytes
   const unsigned ps2 = a.plane_stride[2] * (unsigned)sizeof(T), ps3 = a.plane_stride[3] * (unsigned)sizeof(T);
   const unsigned lds_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_col;
-  const size_t col_bytes = col_lds_bytes<T>(ntiles);
-  unsigned short* perm = reinterpret_cast<unsigned short*>(smem_col + col_bytes);  // local order: slot -> point of the part
+  unsigned short* perm = reinterpret_cast<unsigned short*>(smem_col + a.sub_bytes);  // local order: slot -> point of the part
   typedef T RV __attribute__((ext_vector_type(4)));
   const RV* __restrict__ recs = reinterpret_cast<const RV*>(a.records) + begin;
+  const unsigned* __restrict__ index = a.index + begin;
+
+  // tile rows of phase r: the footprints loc2 .. loc2 + 3 of the dim-2 classes [r cpp, (r + 1) cpp)
+  auto phase_rows = [&](int r, unsigned* row0, unsigned* nrows) {
+    const int c_lo = r * a.cpp;
+    int c_hi = c_lo + a.cpp;
+    c_hi = (c_hi < ncls2 ? c_hi : ncls2) - 1;
+    const int top = a.n[2] - 4;
+    const int l_lo = c_lo - 1 < 0 ? 0 : (c_lo - 1 > top ? top : c_lo - 1);
+    const int l_hi = c_hi - 1 < 0 ? 0 : (c_hi - 1 > top ? top : c_hi - 1);
+    *row0 = (unsigned)l_lo;
+    *nrows = (unsigned)(l_hi + 4 - l_lo);
+  };
+  // sub-column fill: one LDS-DMA instruction = 1 KiB = four 256-byte rows of one 16-tile group;
+  // lane L delivers piece (r0 + (L >> 4)) of tile 16 g + (L & 15).
+  auto fill = [&](unsigned row0, unsigned nrows) {
+    constexpr unsigned PP = (unsigned)sizeof(T);  // pieces (256-byte LDS rows) per group
+    constexpr unsigned IPG = PP / 4u;             // DMA instructions per group (4 rows each)
+    const unsigned ntiles = nrows * n3;
+    const unsigned ninstr = ((ntiles + 15u) / 16u) * IPG;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    for (unsigned q = wave; q < ninstr; q += THREADS / 64) {
+      const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
+      const unsigned tile = g * 16u + (wl & 15u);
+      const unsigned piece = r0 + (wl >> 4);
+      unsigned src = 0xFFFFFFF0u;  // out of range: the descriptor's check turns it into zeros
+      if (tile < ntiles) {
+        const unsigned k = tile / n3, l = tile - k * n3;
+        src = (row0 + k) * ps2 + l * ps3 + cell_off + piece * 16u;
+      }
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + g * (16u * col_tile_bytes<T>()) + r0 * 256u));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, src, 0, 0, 0);
+    }
+  };
 
   // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram.
-  // (Loads first, then the column fill is issued, then they are used: the fill overlaps this.)
-  constexpr int kMaxMine = (int)((kColumnMaxPart + THREADS - 1) / THREADS);
-  unsigned short cls23[kMaxMine];
+  // (Loads first, then the first phase's fill is issued, then they are used: the fill overlaps this.)
+  unsigned short cls23[kColPerThread];
   {
-    T x2[kMaxMine], x3[kMaxMine];
+    T x2[kColPerThread], x3[kColPerThread];
 #pragma unroll
-    for (int m = 0; m < kMaxMine; ++m) {
+    for (int m = 0; m < kColPerThread; ++m) {
       const unsigned q = (unsigned)m * THREADS + tid;
       const RV r = q < count ? recs[q] : recs[0];
       x2[m] = r[2];
       x3[m] = r[3];
     }
-    // ---- column fill: one LDS-DMA instruction = 1 KiB = four 256-byte rows of one 16-tile group;
-    // lane L delivers piece (row0 + (L >> 4)) of tile 16 g + (L & 15).
     {
-      constexpr unsigned PP = (unsigned)sizeof(T);  // pieces (rows) per group
-      constexpr unsigned IPG = PP / 4u;             // DMA instructions per group (4 rows each)
-      const unsigned ngroups = (ntiles + 15u) / 16u;
-      const unsigned ninstr = ngroups * IPG;
-      const unsigned wave = tid >> 6, wl = tid & 63u;
-      typedef __attribute__((address_space(3))) unsigned char lds_byte;
-      for (unsigned q = wave; q < ninstr; q += THREADS / 64) {
-        const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
-        const unsigned tile = g * 16u + (wl & 15u);
-        const unsigned piece = r0 + (wl >> 4);
-        unsigned src = 0xFFFFFFF0u;  // out of range: the descriptor's check turns it into zeros
-        if (tile < ntiles) {
-          const unsigned k = tile / n3, l = tile - k * n3;
-          src = k * ps2 + l * ps3 + cell_off + piece * 16u;
-        }
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + g * (16u * col_tile_bytes<T>()) + r0 * 256u));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, src, 0, 0, 0);
-      }
+      unsigned row0, nrows;
+      phase_rows(0, &row0, &nrows);
+      fill(row0, nrows);
     }
 #pragma unroll
-    for (int m = 0; m < kMaxMine; ++m) {
+    for (int m = 0; m < kColPerThread; ++m) {
       const unsigned q = (unsigned)m * THREADS + tid;
       const unsigned h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
       const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
-      const unsigned c = h2 * (unsigned)(a.n[3] - 1) + h3;  // < (n2 - 1)(n3 - 1) <= 1024
+      const unsigned c = h2 * (unsigned)a.q3 + (h3 >> a.sh3);  // < (n2 - 1) q3 <= 1024
       cls23[m] = (unsigned short)c;
       if (q < count) atomicAdd(&s_hist[c], 1u);
     }
   }
   __syncthreads();
+  if (a.stamps && tid == 0) t_stamp[2] = wall_clock64();
   // exclusive scan of the 1024 counters: CPT consecutive counters per thread, wave scan, wave totals
   {
     constexpr int CPT = (1024 + THREADS - 1) / THREADS;
@@ -306,85 +348,142 @@ __global__ void __launch_bounds__(THREADS) k_cubic_column(const CubicColumnArgs<
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned up = (unsigned)__shfl_up((int)incl, off);
-      if ((tid & 63u) >= (unsigned)off) incl += up;
+      if (wl >= (unsigned)off) incl += up;
     }
-    __shared__ unsigned s_wave[THREADS / 64];
-    if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+    if (wl == 63u) s_wave[wave] = incl;
     __syncthreads();
     unsigned run = incl - sum;
-    for (unsigned w = 0; w < (tid >> 6); ++w) run += s_wave[w];
+    for (unsigned w = 0; w < wave; ++w) run += s_wave[w];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) { if (tid * CPT + c < 1024u) s_hist[tid * CPT + c] = run; run += mine[c]; }
   }
   __syncthreads();
-  // pass 2: slots
+  // pass 2: slots (each counter ends up at the END of its key's stretch = the start of the next key's)
 #pragma unroll
-  for (int m = 0; m < kMaxMine; ++m) {
+  for (int m = 0; m < kColPerThread; ++m) {
     const unsigned q = (unsigned)m * THREADS + tid;
     if (q < count) perm[atomicAdd(&s_hist[cls23[m]], 1u)] = (unsigned short)q;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the column has landed
   __syncthreads();
+  if (a.stamps && tid == 0) t_stamp[3] = wall_clock64();
 
-  // ---- the part's points in local order
-  for (unsigned j0 = 0; j0 < count; j0 += THREADS) {
-    const unsigned j = j0 + tid;
-    const bool live = j < count;
-    // dead lanes (the last row's tail) redo the part's last point: they keep their wave uniform
-    const unsigned q = perm[live ? j : count - 1];
-    const RV r = recs[q];
-    CubicDimRegular<T> dim[4];
-    int loc[4];
-    bool ok = true;
+  // ---- the phases: K-range r of the column in LDS, the stretch of the local order that needs it
+  for (int r = 0; r < a.nphase; ++r) {
+    const unsigned klo = (unsigned)(r * a.cpp) * (unsigned)a.q3;
+    int chi = (r + 1) * a.cpp;
+    chi = chi < ncls2 ? chi : ncls2;
+    const unsigned khi = (unsigned)chi * (unsigned)a.q3;
+    const unsigned ps = klo ? s_hist[klo - 1] : 0u, pe = s_hist[khi - 1];  // workgroup-uniform
+    unsigned row0, nrows;
+    phase_rows(r, &row0, &nrows);
+    if (r > 0) {
+      if (pe == ps) continue;
+      __syncthreads();  // every wave has finished with the previous sub-column
+      if (tid == 0) s_row = 0;
+      fill(row0, nrows);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the sub-column has landed
+    __syncthreads();
+    if (a.stamps && tid == 0 && r == 0) t_stamp[4] = wall_clock64();
+    if (pe == ps) continue;
+    const int row_top = (int)nrows - 4;  // largest footprint row inside the sub-column
+
+    // Rows of 64 slots are handed to the waves as they free up (a shared counter: rows differ in
+    // cost — node forms, out-of-cell points — and the waves of a SIMD share its issue slots, so a
+    // fixed deal left waves idle at the end of every phase); a wave that draws a row beyond the
+    // stretch is done with the phase.
+    auto draw_row = [&]() -> unsigned {
+      unsigned v = 0;
+      if (wl == 0) v = atomicAdd(&s_row, 1u);
+      return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    unsigned jw = ps + draw_row() * 64u;
+    if (jw >= pe) continue;
+    // dead lanes (the stretch's tail) redo its last point: they keep their wave uniform
+    unsigned q = perm[jw + wl < pe ? jw + wl : pe - 1];
+    RV rec = recs[q];
+    for (;;) {
+      const bool live = jw + wl < pe;
+      const unsigned orig = index[q];  // used at the very end: its latency hides behind the planes
+      const RV rcur = rec;
+      const unsigned jn = ps + draw_row() * 64u;
+      if (jn < pe) {  // wave-uniform: next row's record on its way while this row's planes are evaluated
+        q = perm[jn + wl < pe ? jn + wl : pe - 1];
+        rec = recs[q];
+      }
+      CubicDimRegular<T> dim[4];
+      int loc[4];
+      bool ok = true;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const T x = r[d];
-      T floc;
-      ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
-      ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
-      const T nn = (T)a.n[d];
-      const int l = clamp_loc<T>(floc - (T)1, a.n[d] - 4);      // regular.rs:440-442
-      int sat;
-      bool outside;
-      if (floc < (T)0) { sat = kSatLow; outside = true; }       // regular.rs:445-466 on floc = iloc + 1
-      else if (floc == (T)0) { sat = kSatLow; outside = false; }
-      else if (floc > nn - (T)2) { sat = kSatHigh; outside = true; }
-      else if (floc == nn - (T)2) { sat = kSatHigh; outside = false; }
-      else { sat = kSatNone; outside = false; }
-      const T index_one_loc = mul_add<false>(a.step[d], (T)(l + 1), a.start[d]);  // regular.rs:356-360, never fused
-      const T t = (x - index_one_loc) / a.step[d];
-      dim[d].sat = sat;
-      dim[d].linear = (outside && a.linearize) ? 1 : 0;
-      dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
-      loc[d] = l;
-    }
-    const int f0 = col_wave_form<T>(dim[0]), f1 = col_wave_form<T>(dim[1]);
-    const int f2 = col_wave_form<T>(dim[2]), f3 = col_wave_form<T>(dim[3]);
-    const unsigned t0 = (unsigned)loc[2] * n3 + (unsigned)loc[3];
-    T res;
-    if ((f0 | f1 | f2 | f3) == kFormNone) res = col_reduce<T, FMA, kFormNone, PIPE, true>(lds_col, t0, n3, dim, f1, f2, f3);
-    else
-    switch (f0) {  // wave-uniform
-      case kFormNone: res = col_reduce<T, FMA, kFormNone, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-      case kFormLow: res = col_reduce<T, FMA, kFormLow, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-      case kFormHigh: res = col_reduce<T, FMA, kFormHigh, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-      default: res = col_reduce<T, FMA, kFormMixed, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-    }
-    // not my cell (the sort's estimate and the exact cell disagree on a boundary): from the table
-    if (live && (loc[0] != ci || loc[1] != cj)) {
-      const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
-                             (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
-      // a COPY goes to the out-of-line routine: taking the address of `dim` itself would keep it
-      // in scratch memory for every point
-      CubicDimRegular<T> dcopy[4];
+      for (int d = 0; d < 4; ++d) {
+        const T x = rcur[d];
+        T floc;
+        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
+        ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
+        const T nn = (T)a.n[d];
+        const int l = clamp_loc<T>(floc - (T)1, a.n[d] - 4);      // regular.rs:440-442
+        int sat;
+        bool outside;
+        if (floc < (T)0) { sat = kSatLow; outside = true; }       // regular.rs:445-466 on floc = iloc + 1
+        else if (floc == (T)0) { sat = kSatLow; outside = false; }
+        else if (floc > nn - (T)2) { sat = kSatHigh; outside = true; }
+        else if (floc == nn - (T)2) { sat = kSatHigh; outside = false; }
+        else { sat = kSatNone; outside = false; }
+        const T index_one_loc = mul_add<false>(a.step[d], (T)(l + 1), a.start[d]);  // regular.rs:356-360, never fused
+        const T t = (x - index_one_loc) / a.step[d];
+        dim[d].sat = sat;
+        dim[d].linear = (outside && a.linearize) ? 1 : 0;
+        dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
+        loc[d] = l;
+      }
+      const int f0 = col_wave_form<T>(dim[0]), f1 = col_wave_form<T>(dim[1]);
+      const int f2 = col_wave_form<T>(dim[2]), f3 = col_wave_form<T>(dim[3]);
+      // footprint rows relative to the sub-column; a point whose exact rows are not all in it is
+      // evaluated from the table below (its LDS reads stay inside the sub-column, result dropped)
+      const int rel2 = loc[2] - (int)row0;
+      const bool in_rows = rel2 >= 0 && rel2 <= row_top;
+      const unsigned t0 = (unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3];
+      T res;
+      if ((f0 | f1 | f2 | f3) == kFormNone) res = col_reduce<T, FMA, kFormNone, PIPE, true>(lds_col, t0, n3, dim, f1, f2, f3);
+      else
+      switch (f0) {  // wave-uniform
+        case kFormNone: res = col_reduce<T, FMA, kFormNone, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+        case kFormLow: res = col_reduce<T, FMA, kFormLow, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+        case kFormHigh: res = col_reduce<T, FMA, kFormHigh, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+        default: res = col_reduce<T, FMA, kFormMixed, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
+      }
+      // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
+      if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
+        const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
+                               (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
+        // a COPY goes to the out-of-line routine: taking the address of `dim` itself would keep it
+        // in scratch memory for every point
+        CubicDimRegular<T> dcopy[4];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
-      res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
+        for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
+        res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
+      }
+      if (live) {
+        if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
+        stream_store(a.out + orig, res);
+      }
+      if (jn >= pe) break;
+      jw = jn;
     }
-    if (live) {
-      const unsigned orig = a.index[begin + q];
-      if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
-      stream_store(a.out + orig, res);
+  }
+  if (a.stamps) {
+    // [0..4] thread 0's stamps, [5] the LAST wave's end, [6] ids, [7] count | thread 0's own duration (ticks, 16 bits) | bin
+    unsigned long long* w = a.stamps + (size_t)blockIdx.x * 8u;
+    const unsigned long long t_end = wall_clock64();
+    if (wl == 0) atomicMax(&w[5], t_end);
+    if (tid == 0) {
+      for (int k = 0; k < 5; ++k) w[k] = t_stamp[k];
+      unsigned hw = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      w[6] = ((unsigned long long)xcc << 32) | hw;
+      w[7] = ((unsigned long long)count << 32) | ((unsigned long long)((t_end - t_stamp[0]) & 0xFFFFu) << 16) | (unsigned)(bin & 0xFFFF);
     }
   }
 }

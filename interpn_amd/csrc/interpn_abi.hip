@@ -699,7 +699,9 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"bin_slice_log2", &c.bin_slice_log2, 16, 27},
       {"column", &c.column, -1, 1},
       {"column_part", &c.column_part, 0, 1 << 20},
-      {"column_threads", &c.column_threads, 512, 1024},
+      {"column_threads", &c.column_threads, 256, 1024},
+      {"column_wgs", &c.column_wgs, 1, 4},
+      {"column_cpp", &c.column_cpp, 0, 1 << 20},
       {"bin_scramble", &c.bin_scramble, 0, 1},
       {"stage_timing", &c.stage_timing, 0, 1},
       {"axis_records", &c.axis_records, 0, 1},
@@ -712,6 +714,11 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
     } else {
       *value = c.host_chunk;
     }
+    return true;
+  }
+  if (!strcmp(name, "debug_stamps")) {  // a device address (measurement aid, cubic_column.h)
+    if (set) c.debug_stamps = *value;
+    else *value = c.debug_stamps;
     return true;
   }
   for (const Opt& o : opts) {
@@ -731,7 +738,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads", "axis_records", "bin_scramble"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_wgs", "column_cpp", "axis_records", "bin_scramble"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -1549,13 +1556,13 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     const unsigned* index = nullptr;
     char* dst = static_cast<char*>(out) + begin * elem;
     if (column) {
-      // parts of about count / (3 per CU) points (the dispatcher hands them to the CUs as they free
-      // up), as large as the LDS allows: a part pays for its column fill and its local sort once, and
-      // its last 1024-lane row is the only partly filled one
-      size_t q = count / ((size_t)g.cfg.num_cus * 3) + 1;
-      q = (q + 1023) / 1024 * 1024;
-      q = q < 2048 ? 2048 : (q > kColumnMaxPart ? kColumnMaxPart : q);
-      if (g.cfg.column_part > 0) q = (size_t)g.cfg.column_part < kColumnMaxPart ? (size_t)g.cfg.column_part : kColumnMaxPart;
+      // a bin is cut into equal parts of at most 16 points per thread of the column workgroup (the
+      // registers of its local sort); two such workgroups share a CU, the dispatcher hands parts
+      // to whichever frees up
+      ColumnPlan cplan;
+      if (!cubic_column_plan(*use, &cplan)) { err = hipErrorInvalidValue; break; }
+      size_t q = cplan.part_points;
+      if (g.cfg.column_part > 0 && (size_t)g.cfg.column_part < q) q = (size_t)g.cfg.column_part;
       const size_t max_parts = count / q + (size_t)plan.nbins + 1;
       BinExtras extras;
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage, slot->totals_clean);

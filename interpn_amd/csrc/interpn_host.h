@@ -35,7 +35,10 @@ struct LaunchConfig {
   int axis_records = 1;    // rectilinear multilinear / nearest: search with per-bucket records where the handle has them (0: coordinates + tables as before)
   int stage_timing = 0;    // binned evaluation: record HIP events between its launches (interpn_hip_stage_ms; bench.py)
   int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
-  int column_threads = 768; // column evaluation: threads per workgroup (768 = three waves per SIMD with 168 VGPRs, planes software-pipelined: 1.10 ms for cfg4; 1024: 1.17; 512: 1.18)
+  int column_threads = 384; // column evaluation: threads per workgroup (256 / 384 / 512 / 768); with column_wgs = 2: 12 waves per CU = three per SIMD at 168 VGPRs
+  int column_wgs = 2;       // column evaluation: workgroups that share a CU's LDS (1..4): sizes the K-range sub-column of each (cubic_column.h)
+  int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
+  long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
 };
 
@@ -241,6 +244,17 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
 // apply to this grid (LDS capacity, classes fit the bins), and the launch.
 bool cubic_column_applies(const GridDesc& g);
 constexpr unsigned kColumnMaxPart = 12288;  // points per workgroup at most (16-bit local order: 24 KiB of LDS beside the column)
+// The K-range phases of the column evaluation for this grid and these options (k_cubic_column.hip).
+struct ColumnPlan {
+  int threads = 384;         // workgroup size
+  unsigned part_points = 0;  // points of a part at most (16 per thread)
+  int cpp = 0;               // classes of dim 2 per phase
+  int nphase = 0;
+  int q3 = 0, sh3 = 0;       // local sort key = class2 * q3 + (class3 >> sh3)
+  unsigned sub_bytes = 0;    // LDS bytes of a phase's sub-column
+  size_t lds_bytes = 0;      // dynamic LDS of a workgroup: sub-column + local order
+};
+bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan);
 template <typename T>
 hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
                                T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,
