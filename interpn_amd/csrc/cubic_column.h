@@ -3,30 +3,39 @@
 // After the counting sort of k_bin_points.hip with one bin per (i, j) cell of dims 0 and 1, all
 // points of a bin read the SAME 4 x 4 (i, j) footprint of every (k, l) plane: n2 x n3 tiles of the
 // fully overlapped tile table (cubic_brick.h), 128 B each in f64 — 128 KiB for cfg4's 32 x 32
-// planes.  A workgroup takes one part of a bin (<= 16 points per thread), sorts it locally by the
-// class pair of dims 2, 3 and evaluates it out of LDS: a point still reads its 16 tiles = 2 KiB,
-// but from the CU's own LDS (256 B/clk) instead of 16 L2 lines.
+// planes.  A part of a bin (<= 32 points per thread of a wave group) is sorted locally by the
+// class pair of dims 2, 3 and evaluated out of LDS: a point still reads its 16 tiles = 2 KiB, but
+// from the CU's own LDS (256 B/clk) instead of 16 L2 lines.
 //
-// Round 4: the column is resident only a K-RANGE AT A TIME.  The part's local order is by the
-// class of dim 2 first, so the points whose dim-2 class lies in [r * cpp, (r + 1) * cpp) are one
-// contiguous stretch of it ("phase" r) and need only the tile rows k = loc2 .. loc2 + 3 of those
-// classes: cpp + 3 rows of n3 tiles.  With 13-row sub-columns (52 KiB for cfg4) TWO workgroups fit
-// a CU, and the set-up of one (part lookup, record loads, local sort, LDS-DMA fill: memory
-// latency, no arithmetic) runs under the plane arithmetic of the other; with the whole column
-// (round 3: 148 KiB, one workgroup per CU) those phases were serial on every CU.  Columns larger
-// than the LDS (48^4: 288 KiB) are simply more phases.  A wave whose 64 slots of a phase are all
-// beyond its end skips the row (no idle arithmetic in the tail rows), and the record of the next
-// row is requested before this row's planes are evaluated.
+// Round 4 shape (profiles/r04_column_stamps.txt has the in-kernel time stamps behind it):
 //
-// LDS layout: tiles are interleaved sixteen at a time — piece c (16 bytes) of tile T sits at
-//   (T >> 4) * (16 * TILE) + c * 256 + (T & 15) * 16,          TILE = 16 * sizeof(T) bytes
-// (T counted from the first row of the phase) so the eight pieces of a tile are reached from ONE
-// address register with immediate offsets c * 256; lanes of a wave mostly read the SAME tile after
-// the local sort (broadcast), so the layout never conflicts in a fixed pattern.
+//  * PERSISTENT workgroups, one per CU, of GROUPS wave groups (two groups of six waves for cfg4).
+//    Each group draws parts from a global counter and works through them on its own — its own LDS
+//    sub-column, local order, histogram, and a group barrier made of an LDS counter (no s_barrier
+//    after the prologue) — so the set-up of one group's part (part lookup, record loads, local
+//    sort, LDS-DMA fill: memory latency, no arithmetic; 13 % of a round-3 workgroup's life) runs
+//    under the plane arithmetic of the other group, and there is no dispatch gap between parts.
+//    (Two 384-thread WORKGROUPS per CU would be the obvious form; the dispatcher does not
+//    co-schedule them at three waves per SIMD — measured: 92 % of the time one workgroup per CU —
+//    hence the groups inside one workgroup.)
+//  * the column is resident only a K-RANGE AT A TIME.  The local order is by the class of dim 2
+//    first, so the points whose dim-2 class lies in [r * cpp, (r + 1) * cpp) are one contiguous
+//    stretch of it ("phase" r) and need only the tile rows k = loc2 .. loc2 + 3 of those classes:
+//    cpp + 3 rows of n3 tiles.  Columns larger than the LDS (48^4: 288 KiB) are more phases.
+//  * rows of 64 slots are handed to a group's waves on demand (LDS counter), a wave whose row is
+//    beyond the stretch is done, and the record of the next row is requested before this row's
+//    planes are evaluated.
+//  * LDS layout: tile T of the sub-column (T = row * n3 + l) at T * PITCH, PITCH = tile + 16 bytes
+//    (144 / 80): consecutive tiles fall on different 16-byte bank groups (9 and 5 are odd), lanes
+//    that read the same tile broadcast, and a tile's address is ONE multiply-add per point plus
+//    wave-uniform and immediate offsets (the 16-tile interleave of round 3 spent 28 VALU
+//    instructions per plane row on addresses).  Rows are filled by LDS-DMA with lane -> (tile l,
+//    piece) fixed per instruction slot and the row in the scalar offset: no per-lane division
+//    (round 3's fill divided by n3 per lane and instruction: 13 % of the kernel's VALU work).
 //
 // Arithmetic, plane order and reduction tree are those of cubic_brick.h / the reference
 // (src/multicubic/regular.rs:325-623): bit-identical results.  A point whose exact cell is not
-// the workgroup's, or whose exact dim-2 rows are not in the phase's sub-column (the sorts estimate
+// the part's, or whose exact dim-2 rows are not in the phase's sub-column (the sorts estimate
 // classes by multiplying with a reciprocal, the kernel divides like the reference; they can
 // disagree on a cell boundary) is evaluated from the table in global memory by the same tree.
 #pragma once
@@ -45,7 +54,8 @@ struct CubicColumnArgs {
   size_t index_base;
   size_t npts;
   const unsigned* bin_end;      // end of bin b in sorted order (the scatter's cursors after the scatter)
-  const unsigned* part_prefix;  // workgroups (parts) in front of bin b; [nbins] = total
+  const unsigned* part_prefix;  // parts in front of bin b; [nbins] = total
+  unsigned* work;               // next part to hand out (zeroed by the sort's scan kernel)
   int nbins;
   int nb1;                   // classes along dim 1 (n1 - 1)
   unsigned inv_mult;         // sorted bin b holds class pair (b * inv_mult) % nbins
@@ -61,39 +71,68 @@ struct CubicColumnArgs {
   int nphase;                // ceil((n2 - 1) / cpp)
   int q3;                    // local sort key = class of dim 2 * q3 + (class of dim 3 >> sh3); (n2 - 1) * q3 <= 1024
   int sh3;
-  unsigned sub_bytes;        // LDS bytes reserved for the sub-column; the part's local order (16-bit) sits behind them
-  unsigned long long* stamps;  // measurement aid (option debug_stamps): 8 words per workgroup, or null
+  unsigned sub_bytes;        // LDS bytes of a group's sub-column; its local order (16-bit) sits behind them
+  unsigned group_bytes;      // dynamic LDS bytes per group (sub-column + local order, 16-byte multiple)
+  unsigned long long* stamps;  // measurement aid (option debug_stamps): 8 words per part, or null
 };
 
-constexpr int kColPerThread = 16;  // points of a part per thread at most (register arrays of the local sort)
+constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
+constexpr unsigned kColMaxPart = 12288;  // points of a part at most (16-bit local order; = kColumnMaxPart of interpn_host.h)
+// points per thread of a group of GT threads: 16 for 768 threads, 32 for 384 and fewer
+constexpr int col_per_thread(int gt) { return (int)((kColMaxPart + gt - 1) / gt) < kColPerThread ? (((int)((kColMaxPart + gt - 1) / gt) + 1) / 2 * 2) : kColPerThread; }
+constexpr int kColKeys = 1024;     // keys of the local sort
 
-
-template <typename T> constexpr unsigned col_tile_bytes() { return 16u * (unsigned)sizeof(T); }
-// LDS bytes of a column of `ntiles` tiles (whole 16-tile groups)
-template <typename T> __host__ __device__ inline size_t col_lds_bytes(unsigned ntiles) { return (size_t)((ntiles + 15u) / 16u) * 16u * col_tile_bytes<T>(); }
-
-template <typename T>
-__device__ __forceinline__ unsigned col_tile_base(unsigned tile) {  // LDS byte offset of piece 0 of `tile`
-  return (tile >> 4) * (16u * col_tile_bytes<T>()) + (tile & 15u) * 16u;
+// LDS pitch of a tile: its 16 elements + 16 bytes (see the head of this file)
+template <typename T> constexpr unsigned col_pitch() { return 16u * (unsigned)sizeof(T) + 16u; }
+template <typename T> constexpr unsigned col_pitch_units() { return (unsigned)sizeof(T) + 1u; }  // in 16-byte units: 9 / 5
+// LDS bytes of `nrows` rows of n3 tiles, whole KiB
+template <typename T> __host__ __device__ inline size_t col_lds_bytes(unsigned nrows, unsigned n3) {
+  return ((size_t)nrows * n3 * col_pitch<T>() + 1023u) / 1024u * 1024u;
 }
 
-// my tile (16 elements, e = ei * 4 + ej) out of the LDS column
+template <typename T> __device__ __forceinline__ T dev_fabs(T a);
+template <> __device__ __forceinline__ double dev_fabs<double>(double a) { return __builtin_fabs(a); }
+template <> __device__ __forceinline__ float dev_fabs<float>(float a) { return __builtin_fabsf(a); }
+template <typename T> __device__ __forceinline__ T dev_fmax(T a, T b);
+template <> __device__ __forceinline__ double dev_fmax<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> __device__ __forceinline__ float dev_fmax<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <typename T> __device__ __forceinline__ T dev_fmin(T a, T b);
+template <> __device__ __forceinline__ double dev_fmin<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> __device__ __forceinline__ float dev_fmin<float>(float a, float b) { return __builtin_fminf(a, b); }
+
+// my tile (16 elements, e = ei * 4 + ej) at LDS byte address `addr`
 template <typename T>
-__device__ __forceinline__ void col_take_tile(unsigned lds_col, unsigned tile, T (&v)[16]) {
+__device__ __forceinline__ void col_take_tile(unsigned addr, T (&v)[16]) {
   constexpr int PP = (int)sizeof(T);       // 16-byte pieces per tile
   constexpr int EP = 16 / (int)sizeof(T);  // elements per piece
   typedef T TP __attribute__((ext_vector_type(EP), may_alias));
   typedef __attribute__((address_space(3))) const TP lds_TP;
-  const unsigned base = lds_col + col_tile_base<T>(tile);
 #pragma unroll
   for (int c = 0; c < PP; ++c) {
-    const TP w = *(lds_TP*)(size_t)(base + (unsigned)c * 256u);
+    const TP w = *(lds_TP*)(size_t)(addr + (unsigned)c * 16u);
 #pragma unroll
     for (int k = 0; k < EP; ++k) v[EP * c + k] = w[k];
   }
 }
 
-// One point from the table in global memory (points that are not in this workgroup's cell):
+// Per-dimension state of a point on a regular grid, as the column kernel keeps it: `tt` as in
+// CubicDimRegular (t, -t or t - 1), the class as three predicates (wave masks, not integers).
+template <typename T>
+struct ColDim {
+  T tt;
+  bool low, high, lin;  // saturated low / high (inside or outside); outside with linearised extrapolation
+};
+
+template <typename T>
+__device__ __forceinline__ CubicDimRegular<T> col_full_dim(const ColDim<T>& d) {
+  CubicDimRegular<T> r;
+  r.tt = d.tt;
+  r.sat = d.low ? kSatLow : (d.high ? kSatHigh : kSatNone);
+  r.linear = d.lin ? 1 : 0;
+  return r;
+}
+
+// One point from the table in global memory (points that are not in this part's cell or rows):
 // same tree as reduce_planes_dma, plane (k2, k3) at k2 * stride2 + k3 * stride3.
 template <typename T, bool FMA>
 __device__ __noinline__ T col_slow_point(__amdgpu_buffer_rsrc_t rsrc, unsigned tile_off_bytes, unsigned ps2_bytes, unsigned ps3_bytes,
@@ -116,16 +155,16 @@ __device__ __noinline__ T col_slow_point(__amdgpu_buffer_rsrc_t rsrc, unsigned t
 }
 
 // ---- nodes with a wave-uniform form -------------------------------------------------------------
-// Within a workgroup all points share the class of dims 0 and 1, and the local sort below puts
-// points of one (dim 2, dim 3) class pair next to each other, so almost every wave is uniform
-// along every dimension: all lanes interior (the reference's Saturation::None arm), all saturated
-// low, or all saturated high, none of them extrapolating linearly.  Each of these is the
-// reference's arm for that case without the selects of the general form (same operations, same
-// bits, multicubic/regular.rs:495-623); anything else takes the general form.
+// Within a part all points share the class of dims 0 and 1, and the local sort puts points of one
+// (dim 2, dim 3) class pair next to each other, so almost every wave is uniform along every
+// dimension: all lanes interior (the reference's Saturation::None arm), all saturated low, or all
+// saturated high, none of them extrapolating linearly.  Each of these is the reference's arm for
+// that case without the selects of the general form (same operations, same bits,
+// multicubic/regular.rs:495-623); anything else takes the general form.
 enum : int { kFormNone = 0, kFormLow = 1, kFormHigh = 2, kFormMixed = 3 };
 
 template <bool FMA, int FORM, typename T>
-__device__ __forceinline__ T col_node(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
+__device__ __forceinline__ T col_node(T v0, T v1, T v2, T v3, const ColDim<T>& d) {
   const T two = (T)2;
   if constexpr (FORM == kFormNone) {
     return cubic_regular_node_interior<FMA, T>(v0, v1, v2, v3, d.tt);
@@ -140,12 +179,12 @@ __device__ __forceinline__ T col_node(T v0, T v1, T v2, T v3, const CubicDimRegu
     const T k1 = two * dy - k0;
     return hermite<FMA>(d.tt, v2, dy, k0, k1);
   } else {
-    return cubic_regular_node<FMA, T>(v0, v1, v2, v3, d);
+    return cubic_regular_node<FMA, T>(v0, v1, v2, v3, col_full_dim<T>(d));
   }
 }
 
 template <bool FMA, typename T>
-__device__ __forceinline__ T col_node_rt(int form, T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
+__device__ __forceinline__ T col_node_rt(int form, T v0, T v1, T v2, T v3, const ColDim<T>& d) {
   switch (form) {  // wave-uniform
     case kFormNone: return col_node<FMA, kFormNone, T>(v0, v1, v2, v3, d);
     case kFormLow: return col_node<FMA, kFormLow, T>(v0, v1, v2, v3, d);
@@ -156,52 +195,75 @@ __device__ __forceinline__ T col_node_rt(int form, T v0, T v1, T v2, T v3, const
 
 // the wave's form along one dimension (every lane must call this)
 template <typename T>
-__device__ __forceinline__ int col_wave_form(const CubicDimRegular<T>& d) {
-  if (__builtin_amdgcn_ballot_w64(d.linear != 0) != 0) return kFormMixed;
-  if (__builtin_amdgcn_ballot_w64(d.sat != kSatNone) == 0) return kFormNone;
-  if (__builtin_amdgcn_ballot_w64(d.sat != kSatLow) == 0) return kFormLow;
-  if (__builtin_amdgcn_ballot_w64(d.sat != kSatHigh) == 0) return kFormHigh;
+__device__ __forceinline__ int col_wave_form(const ColDim<T>& d) {
+  if (__builtin_amdgcn_ballot_w64(d.lin) != 0) return kFormMixed;
+  if (__builtin_amdgcn_ballot_w64(d.low || d.high) == 0) return kFormNone;
+  if (__builtin_amdgcn_ballot_w64(!d.low) == 0) return kFormLow;
+  if (__builtin_amdgcn_ballot_w64(!d.high) == 0) return kFormHigh;
   return kFormMixed;
 }
 
-// All 16 planes of a point out of the LDS column, dim 0 in form F0: dim 2 index = k & 3, dim 3
-// index = k >> 2 (the reference's order, multicubic/regular.rs:368-421).  The tile of the next plane
-// is requested before this plane's nodes are evaluated (PIPE: needs 32 more VGPRs).
+// All 16 planes of a point out of the LDS sub-column, dim 0 in form F0: dim 2 index = k2, dim 3
+// index = k3 (the reference's order, multicubic/regular.rs:368-421).  `a0` = LDS address of the
+// point's tile (k2, k3) = (0, 0); `rowpitch` = bytes between tile rows (wave-uniform).  The tile of
+// the next plane is requested before this plane's nodes are evaluated (32 more VGPRs).
 // ALLNONE: every dimension of the wave is interior (the common case): no form tests at all.
-template <typename T, bool FMA, int F0, bool PIPE, bool ALLNONE = false>
-__device__ __forceinline__ T col_reduce(unsigned lds_col, unsigned t0, unsigned n3, const CubicDimRegular<T>* dim, int f1, int f2, int f3) {
+template <typename T, bool FMA, int F0, bool ALLNONE = false>
+__device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const ColDim<T>* dim, int f1, int f2, int f3) {
+  constexpr unsigned PITCH = col_pitch<T>();
   T s3[4];
   T cur[16];
-  if constexpr (PIPE) col_take_tile<T>(lds_col, t0, cur);
+  unsigned ak = a0;  // tile (0, k3)
+  col_take_tile<T>(ak, cur);
 #pragma unroll 1
   for (int k3 = 0; k3 < 4; ++k3) {
     T s2[4];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
       T nxt[16];
-      if constexpr (PIPE) {
-        // plane after (k2, k3): (k2 + 1, k3), or (0, k3 + 1); behind the last plane this reads one
-        // tile too many (t0 + 4: still inside the column)
-        const unsigned tn = k2 < 3 ? t0 + (unsigned)(k2 + 1) * n3 + (unsigned)k3 : t0 + (unsigned)(k3 + 1);
-        col_take_tile<T>(lds_col, tn, nxt);
-      } else {
-        col_take_tile<T>(lds_col, t0 + (unsigned)k2 * n3 + (unsigned)k3, cur);
-      }
+      // plane after (k2, k3): (k2 + 1, k3), or (0, k3 + 1); behind the last plane this reads one
+      // tile too many ((0, 4): the next tile of the point's first row or the first of the next row,
+      // still inside the sub-column)
+      const unsigned an = k2 < 3 ? ak + (unsigned)(k2 + 1) * rowpitch : ak + PITCH;
+      col_take_tile<T>(an, nxt);
       T w[4];
 #pragma unroll
       for (int ej = 0; ej < 4; ++ej) w[ej] = col_node<FMA, F0, T>(cur[ej], cur[4 + ej], cur[8 + ej], cur[12 + ej], dim[0]);
       if constexpr (ALLNONE) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
       else s2[k2] = col_node_rt<FMA, T>(f1, w[0], w[1], w[2], w[3], dim[1]);
-      if constexpr (PIPE) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cur[e] = nxt[e];
-      }
+      for (int e = 0; e < 16; ++e) cur[e] = nxt[e];
     }
+    ak += PITCH;
     if constexpr (ALLNONE) s3[k3] = col_node<FMA, kFormNone, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
     else s3[k3] = col_node_rt<FMA, T>(f2, s2[0], s2[1], s2[2], s2[3], dim[2]);
   }
   if constexpr (ALLNONE) return col_node<FMA, kFormNone, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
   else return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
+// The waves that are not interior along every dimension (boundary bins, boundary classes of dims
+// 2, 3, extrapolating points): out of line, so that their node forms' registers do not weigh on the
+// allocation of the common path (measured: the inlined switch made the compiler spill 24 registers
+// around every form).
+template <typename T, bool FMA>
+__device__ __noinline__ T col_reduce_general(unsigned a0, unsigned rowpitch, T tt0, T tt1, T tt2, T tt3, unsigned cls, int forms) {
+  ColDim<T> dim[4];
+  const T tt[4] = {tt0, tt1, tt2, tt3};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    dim[d].tt = tt[d];
+    dim[d].low = (cls >> (3 * d)) & 1u;
+    dim[d].high = (cls >> (3 * d + 1)) & 1u;
+    dim[d].lin = (cls >> (3 * d + 2)) & 1u;
+  }
+  const int f0 = forms & 3, f1 = (forms >> 2) & 3, f2 = (forms >> 4) & 3, f3 = (forms >> 6) & 3;
+  switch (f0) {  // wave-uniform
+    case kFormNone: return col_reduce<T, FMA, kFormNone>(a0, rowpitch, dim, f1, f2, f3);
+    case kFormLow: return col_reduce<T, FMA, kFormLow>(a0, rowpitch, dim, f1, f2, f3);
+    case kFormHigh: return col_reduce<T, FMA, kFormHigh>(a0, rowpitch, dim, f1, f2, f3);
+    default: return col_reduce<T, FMA, kFormMixed>(a0, rowpitch, dim, f1, f2, f3);
+  }
 }
 
 // class estimate of the local sort (a hint only): 0 = floc <= 0, c = floc, n - 2 = floc >= n - 2
@@ -211,69 +273,60 @@ __device__ __forceinline__ unsigned col_class_hint(T x, T start, T rstep, int n)
   return u >= (T)1 ? (u < (T)(n - 2) ? (unsigned)(int)u : (unsigned)(n - 2)) : 0u;
 }
 
-// Registers: 12 waves per CU = three per SIMD (168 VGPRs) whether they come as two 384-thread
-// workgroups, three of 256 or one of 768; 512-thread workgroups pair up at four per SIMD (128).
-template <typename T, bool FMA, int THREADS>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? 4 : 3)))
-k_cubic_column(const CubicColumnArgs<T> a) {
-  constexpr bool PIPE = THREADS <= 768;  // 168+ VGPRs per lane: room for a second tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_col[];
-  __shared__ int s_bin;
-  __shared__ unsigned s_begin, s_end;
-  __shared__ unsigned s_hist[1024];   // local sort: points per key, then (after pass 2) the END of every key's stretch
-  __shared__ unsigned s_wave[THREADS / 64];
-  __shared__ unsigned s_row;          // next 64-slot row of the current phase (rows are dealt to the waves as they free up)
-  const unsigned tid = threadIdx.x;
-  const unsigned wave = tid >> 6, wl = tid & 63u;
-  unsigned long long t_stamp[6] = {0, 0, 0, 0, 0, 0};
-  if (a.stamps && tid == 0) t_stamp[0] = wall_clock64();
-  // Which (bin, part) is this workgroup?  part_prefix is non-decreasing, [nbins] = number of parts:
-  // the bin b with part_prefix[b] <= w < part_prefix[b + 1] — every thread tests bins (a single
-  // thread bisecting costs ten dependent global loads, ~10 us).
-  if (tid == 0) { s_bin = -1; s_row = 0; }
-  for (unsigned c = tid; c < 1024u; c += THREADS) s_hist[c] = 0;
-  __syncthreads();
-  {
-    const unsigned w = blockIdx.x;
-    for (int b = (int)tid; b < a.nbins; b += THREADS) {
-      const unsigned p0 = a.part_prefix[b], p1 = a.part_prefix[b + 1];
-      if (p0 <= w && w < p1) {
-        const unsigned b0 = b ? a.bin_end[b - 1] : 0u;
-        const unsigned b1 = a.bin_end[b];
-        const unsigned cnt = b1 - b0;
-        const unsigned nparts = p1 - p0;
-        const unsigned j = w - p0;
-        const unsigned per = (cnt + nparts - 1) / nparts;  // equal parts (<= the scan's part_points)
-        const unsigned lo_p = b0 + j * per;
-        unsigned hi_p = lo_p + per;
-        if (hi_p > b1) hi_p = b1;
-        s_begin = lo_p < b1 ? lo_p : b1;
-        s_end = hi_p;
-        s_bin = b;
-      }
-    }
+// Barrier of one wave group (GW waves) of a persistent workgroup: an LDS counter that only ever
+// grows; `epoch` (wave-uniform register) is the count that completes the next barrier.  LDS
+// instructions of a wave execute in order and the LDS serialises the waves' accesses, so what a
+// wave wrote to LDS before its add is visible to every wave that sees the counter complete; the
+// LDS-DMA of a fill is waited for (vmcnt) by the issuing wave before it arrives here.  GW == 0: the
+// group is the whole workgroup (s_barrier).
+template <int GW>
+__device__ __forceinline__ void col_group_barrier(unsigned* ctr, unsigned& epoch, unsigned wl) {
+  if constexpr (GW == 0) {
+    __syncthreads();
+  } else {
+    epoch += (unsigned)GW;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (wl == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch) < 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  __syncthreads();
-  const int bin = s_bin;
-  if (bin < 0) return;
-  const unsigned begin = s_begin, end = s_end;
-  if (begin >= end) return;
-  const unsigned count = end - begin;  // <= kColPerThread * THREADS (the scan cut the bin accordingly)
-  if (a.stamps && tid == 0) t_stamp[1] = wall_clock64();
-  const unsigned key = (unsigned)(((unsigned long long)(unsigned)bin * a.inv_mult) % (unsigned)a.nbins);
-  const int c0 = (int)(key / (unsigned)a.nb1), c1 = (int)(key % (unsigned)a.nb1);  // nominal classes of dims 0, 1
-  const int ci = c0 - 1 < 0 ? 0 : (c0 - 1 > a.n[0] - 4 ? a.n[0] - 4 : c0 - 1);      // their footprint cell
-  const int cj = c1 - 1 < 0 ? 0 : (c1 - 1 > a.n[1] - 4 ? a.n[1] - 4 : c1 - 1);
+}
+
+// Registers: 12 waves per CU = three per SIMD (168 VGPRs).  GROUPS wave groups of THREADS / GROUPS
+// threads each; GROUPS == 1: the whole workgroup is one group and synchronises with s_barrier.
+// STAMPS: the measurement build (option debug_stamps) — time stamps cost registers the product kernel needs.
+template <typename T, bool FMA, int THREADS, int GROUPS, bool STAMPS = false>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_cubic_column(const CubicColumnArgs<T> a) {
+  static_assert(THREADS % (64 * GROUPS) == 0, "whole waves per group");
+  constexpr int GT = THREADS / GROUPS;   // threads of a group
+  constexpr int GW = GT / 64;            // its waves
+  constexpr int PT = col_per_thread(GT); // points of a part per thread at most
+  constexpr int BAR = GW;  // (s_barrier for GROUPS == 1 — BAR = 0 — hangs on the GPU at 32^4 inside this persistent loop: not used)
+  constexpr unsigned PITCH = col_pitch<T>();
+  constexpr unsigned PU = col_pitch_units<T>();
+  constexpr unsigned PP = (unsigned)sizeof(T);  // 16-byte pieces of a tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_col[];
+  __shared__ unsigned s_hist_all[GROUPS][kColKeys];  // local sort: points per key, then (after pass 2) the END of every key's stretch
+  __shared__ unsigned s_wave_all[GROUPS][GW];
+  __shared__ unsigned s_ctl_all[GROUPS][8];           // 0 barrier counter | 1 part | 2 bin | 3 begin | 4 end | 5 next row
+  const unsigned tid = threadIdx.x;
+  const unsigned grp = GROUPS == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)(tid / (unsigned)GT));
+  unsigned* const s_hist = s_hist_all[grp];
+  unsigned* const s_wave = s_wave_all[grp];
+  unsigned* const s_ctl = s_ctl_all[grp];
+  if (tid - grp * (unsigned)GT < 8) s_ctl[tid - grp * (unsigned)GT] = 0;
+  __syncthreads();  // the only s_barrier of the workgroup
+  unsigned epoch = 0;
+  const unsigned total_parts = (unsigned)__builtin_amdgcn_readfirstlane((int)a.part_prefix[a.nbins]);
   const unsigned n3 = (unsigned)a.n[3];
   const int ncls2 = a.n[2] - 1;
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.tiles, a.table_bytes);
-  const unsigned cell_off = (unsigned)(ci * (int)a.nbj + cj) * 16u * (unsigned)sizeof(T);  // my cell's tile inside a plane, bytes
   const unsigned ps2 = a.plane_stride[2] * (unsigned)sizeof(T), ps3 = a.plane_stride[3] * (unsigned)sizeof(T);
-  const unsigned lds_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_col;
-  unsigned short* perm = reinterpret_cast<unsigned short*>(smem_col + a.sub_bytes);  // local order: slot -> point of the part
+  const unsigned lds_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_col + grp * a.group_bytes;
+  unsigned short* const perm = reinterpret_cast<unsigned short*>(smem_col + (size_t)grp * a.group_bytes + a.sub_bytes);  // local order: slot -> point of the part
+  const unsigned rowpitch = n3 * PITCH;  // LDS bytes of a tile row
   typedef T RV __attribute__((ext_vector_type(4)));
-  const RV* __restrict__ recs = reinterpret_cast<const RV*>(a.records) + begin;
-  const unsigned* __restrict__ index = a.index + begin;
 
   // tile rows of phase r: the footprints loc2 .. loc2 + 3 of the dim-2 classes [r cpp, (r + 1) cpp)
   auto phase_rows = [&](int r, unsigned* row0, unsigned* nrows) {
@@ -286,204 +339,276 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     *row0 = (unsigned)l_lo;
     *nrows = (unsigned)(l_hi + 4 - l_lo);
   };
-  // sub-column fill: one LDS-DMA instruction = 1 KiB = four 256-byte rows of one 16-tile group;
-  // lane L delivers piece (r0 + (L >> 4)) of tile 16 g + (L & 15).
-  auto fill = [&](unsigned row0, unsigned nrows) {
-    constexpr unsigned PP = (unsigned)sizeof(T);  // pieces (256-byte LDS rows) per group
-    constexpr unsigned IPG = PP / 4u;             // DMA instructions per group (4 rows each)
-    const unsigned ntiles = nrows * n3;
-    const unsigned ninstr = ((ntiles + 15u) / 16u) * IPG;
-    typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    for (unsigned q = wave; q < ninstr; q += THREADS / 64) {
-      const unsigned g = q / IPG, r0 = (q % IPG) * 4u;
-      const unsigned tile = g * 16u + (wl & 15u);
-      const unsigned piece = r0 + (wl >> 4);
-      unsigned src = 0xFFFFFFF0u;  // out of range: the descriptor's check turns it into zeros
-      if (tile < ntiles) {
-        const unsigned k = tile / n3, l = tile - k * n3;
-        src = (row0 + k) * ps2 + l * ps3 + cell_off + piece * 16u;
-      }
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + g * (16u * col_tile_bytes<T>()) + r0 * 256u));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, src, 0, 0, 0);
-    }
-  };
-
-  // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram.
-  // (Loads first, then the first phase's fill is issued, then they are used: the fill overlaps this.)
-  unsigned short cls23[kColPerThread];
-  {
-    T x2[kColPerThread], x3[kColPerThread];
-#pragma unroll
-    for (int m = 0; m < kColPerThread; ++m) {
-      const unsigned q = (unsigned)m * THREADS + tid;
-      const RV r = q < count ? recs[q] : recs[0];
-      x2[m] = r[2];
-      x3[m] = r[3];
-    }
-    {
-      unsigned row0, nrows;
-      phase_rows(0, &row0, &nrows);
-      fill(row0, nrows);
-    }
-#pragma unroll
-    for (int m = 0; m < kColPerThread; ++m) {
-      const unsigned q = (unsigned)m * THREADS + tid;
-      const unsigned h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
-      const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
-      const unsigned c = h2 * (unsigned)a.q3 + (h3 >> a.sh3);  // < (n2 - 1) q3 <= 1024
-      cls23[m] = (unsigned short)c;
-      if (q < count) atomicAdd(&s_hist[c], 1u);
-    }
-  }
-  __syncthreads();
-  if (a.stamps && tid == 0) t_stamp[2] = wall_clock64();
-  // exclusive scan of the 1024 counters: CPT consecutive counters per thread, wave scan, wave totals
-  {
-    constexpr int CPT = (1024 + THREADS - 1) / THREADS;
-    unsigned mine[CPT];
-    unsigned sum = 0;
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) { mine[c] = tid * CPT + c < 1024u ? s_hist[tid * CPT + c] : 0u; sum += mine[c]; }
-    unsigned incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned up = (unsigned)__shfl_up((int)incl, off);
-      if (wl >= (unsigned)off) incl += up;
-    }
-    if (wl == 63u) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned run = incl - sum;
-    for (unsigned w = 0; w < wave; ++w) run += s_wave[w];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) { if (tid * CPT + c < 1024u) s_hist[tid * CPT + c] = run; run += mine[c]; }
-  }
-  __syncthreads();
-  // pass 2: slots (each counter ends up at the END of its key's stretch = the start of the next key's)
-#pragma unroll
-  for (int m = 0; m < kColPerThread; ++m) {
-    const unsigned q = (unsigned)m * THREADS + tid;
-    if (q < count) perm[atomicAdd(&s_hist[cls23[m]], 1u)] = (unsigned short)q;
-  }
-  __syncthreads();
-  if (a.stamps && tid == 0) t_stamp[3] = wall_clock64();
-
-  // ---- the phases: K-range r of the column in LDS, the stretch of the local order that needs it
-  for (int r = 0; r < a.nphase; ++r) {
+  // the stretch of the local order that belongs to phase r (valid once pass 2 and a barrier are behind us)
+  auto phase_stretch = [&](int r, unsigned* ps, unsigned* pe) {
     const unsigned klo = (unsigned)(r * a.cpp) * (unsigned)a.q3;
     int chi = (r + 1) * a.cpp;
     chi = chi < ncls2 ? chi : ncls2;
     const unsigned khi = (unsigned)chi * (unsigned)a.q3;
-    const unsigned ps = klo ? s_hist[klo - 1] : 0u, pe = s_hist[khi - 1];  // workgroup-uniform
-    unsigned row0, nrows;
-    phase_rows(r, &row0, &nrows);
-    if (r > 0) {
-      if (pe == ps) continue;
-      __syncthreads();  // every wave has finished with the previous sub-column
-      if (tid == 0) s_row = 0;
-      fill(row0, nrows);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the sub-column has landed
-    __syncthreads();
-    if (a.stamps && tid == 0 && r == 0) t_stamp[4] = wall_clock64();
-    if (pe == ps) continue;
-    const int row_top = (int)nrows - 4;  // largest footprint row inside the sub-column
+    *ps = klo ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_hist[klo - 1]) : 0u;
+    *pe = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hist[khi - 1]);
+  };
 
-    // Rows of 64 slots are handed to the waves as they free up (a shared counter: rows differ in
-    // cost — node forms, out-of-cell points — and the waves of a SIMD share its issue slots, so a
-    // fixed deal left waves idle at the end of every phase); a wave that draws a row beyond the
-    // stretch is done with the phase.
-    auto draw_row = [&]() -> unsigned {
-      unsigned v = 0;
-      if (wl == 0) v = atomicAdd(&s_row, 1u);
-      return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-    };
-    unsigned jw = ps + draw_row() * 64u;
-    if (jw >= pe) continue;
-    // dead lanes (the stretch's tail) redo its last point: they keep their wave uniform
-    unsigned q = perm[jw + wl < pe ? jw + wl : pe - 1];
-    RV rec = recs[q];
-    for (;;) {
-      const bool live = jw + wl < pe;
-      const unsigned orig = index[q];  // used at the very end: its latency hides behind the planes
-      const RV rcur = rec;
-      const unsigned jn = ps + draw_row() * 64u;
-      if (jn < pe) {  // wave-uniform: next row's record on its way while this row's planes are evaluated
-        q = perm[jn + wl < pe ? jn + wl : pe - 1];
-        rec = recs[q];
+  const unsigned gtid_k = tid - grp * (unsigned)GT;
+  for (;;) {
+    // Per-part copies of the thread ids that the optimiser cannot see through: everything derived
+    // from them (16 record addresses, fill offsets, ...) is then recomputed per part instead of
+    // being hoisted out of the persistent loop and kept in (spilled) registers for the whole kernel.
+    unsigned gtid = gtid_k;
+    asm volatile("" : "+v"(gtid));
+    const unsigned gwave = (unsigned)__builtin_amdgcn_readfirstlane((int)(gtid >> 6)), wl = gtid & 63u;
+    // ---- next part for this group
+    if (gtid == 0) s_ctl[1] = atomicAdd(a.work, 1u);
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[1]);  // group-uniform values go to scalar registers
+    if (w >= total_parts) break;
+    unsigned long long t_stamp[5] = {0, 0, 0, 0, 0};
+    if (STAMPS && gtid == 0) t_stamp[0] = wall_clock64();
+    // Which (bin, part) is it?  part_prefix is non-decreasing: the bin b with part_prefix[b] <= w <
+    // part_prefix[b + 1] — every thread tests bins.
+    for (int b = (int)gtid; b < a.nbins; b += GT) {
+      const unsigned p0 = a.part_prefix[b], p1 = a.part_prefix[b + 1];
+      if (p0 <= w && w < p1) {
+        const unsigned b0 = b ? a.bin_end[b - 1] : 0u;
+        const unsigned b1 = a.bin_end[b];
+        const unsigned cnt = b1 - b0;
+        const unsigned nparts = p1 - p0;
+        const unsigned j = w - p0;
+        const unsigned per = (cnt + nparts - 1) / nparts;  // equal parts (<= the scan's part_points)
+        const unsigned lo_p = b0 + j * per;
+        unsigned hi_p = lo_p + per;
+        if (hi_p > b1) hi_p = b1;
+        s_ctl[3] = lo_p < b1 ? lo_p : b1;
+        s_ctl[4] = hi_p;
+        s_ctl[2] = (unsigned)b;
       }
-      CubicDimRegular<T> dim[4];
-      int loc[4];
-      bool ok = true;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const T x = rcur[d];
-        T floc;
-        ok &= regular_floc<T>(x, a.start[d], a.step[d], &floc);   // multicubic/regular.rs:435-438
-        ok &= floc != (T)-9223372036854775808.0;                  // `- 1` would overflow isize
-        const T nn = (T)a.n[d];
-        const int l = clamp_loc<T>(floc - (T)1, a.n[d] - 4);      // regular.rs:440-442
-        int sat;
-        bool outside;
-        if (floc < (T)0) { sat = kSatLow; outside = true; }       // regular.rs:445-466 on floc = iloc + 1
-        else if (floc == (T)0) { sat = kSatLow; outside = false; }
-        else if (floc > nn - (T)2) { sat = kSatHigh; outside = true; }
-        else if (floc == nn - (T)2) { sat = kSatHigh; outside = false; }
-        else { sat = kSatNone; outside = false; }
-        const T index_one_loc = mul_add<false>(a.step[d], (T)(l + 1), a.start[d]);  // regular.rs:356-360, never fused
-        const T t = (x - index_one_loc) / a.step[d];
-        dim[d].sat = sat;
-        dim[d].linear = (outside && a.linearize) ? 1 : 0;
-        dim[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
-        loc[d] = l;
-      }
-      const int f0 = col_wave_form<T>(dim[0]), f1 = col_wave_form<T>(dim[1]);
-      const int f2 = col_wave_form<T>(dim[2]), f3 = col_wave_form<T>(dim[3]);
-      // footprint rows relative to the sub-column; a point whose exact rows are not all in it is
-      // evaluated from the table below (its LDS reads stay inside the sub-column, result dropped)
-      const int rel2 = loc[2] - (int)row0;
-      const bool in_rows = rel2 >= 0 && rel2 <= row_top;
-      const unsigned t0 = (unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3];
-      T res;
-      if ((f0 | f1 | f2 | f3) == kFormNone) res = col_reduce<T, FMA, kFormNone, PIPE, true>(lds_col, t0, n3, dim, f1, f2, f3);
-      else
-      switch (f0) {  // wave-uniform
-        case kFormNone: res = col_reduce<T, FMA, kFormNone, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-        case kFormLow: res = col_reduce<T, FMA, kFormLow, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-        case kFormHigh: res = col_reduce<T, FMA, kFormHigh, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-        default: res = col_reduce<T, FMA, kFormMixed, PIPE>(lds_col, t0, n3, dim, f1, f2, f3); break;
-      }
-      // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
-      if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
-        const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
-                               (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
-        // a COPY goes to the out-of-line routine: taking the address of `dim` itself would keep it
-        // in scratch memory for every point
-        CubicDimRegular<T> dcopy[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
-        res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
-      }
-      if (live) {
-        if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
-        stream_store(a.out + orig, res);
-      }
-      if (jn >= pe) break;
-      jw = jn;
     }
-  }
-  if (a.stamps) {
-    // [0..4] thread 0's stamps, [5] the LAST wave's end, [6] ids, [7] count | thread 0's own duration (ticks, 16 bits) | bin
-    unsigned long long* w = a.stamps + (size_t)blockIdx.x * 8u;
-    const unsigned long long t_end = wall_clock64();
-    if (wl == 0) atomicMax(&w[5], t_end);
-    if (tid == 0) {
-      for (int k = 0; k < 5; ++k) w[k] = t_stamp[k];
-      unsigned hw = 0;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      unsigned xcc = 0;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      w[6] = ((unsigned long long)xcc << 32) | hw;
-      w[7] = ((unsigned long long)count << 32) | ((unsigned long long)((t_end - t_stamp[0]) & 0xFFFFu) << 16) | (unsigned)(bin & 0xFFFF);
+    for (unsigned c = gtid; c < (unsigned)kColKeys; c += GT) s_hist[c] = 0;
+    if (gtid == 0) s_ctl[5] = 0;
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    const int bin = __builtin_amdgcn_readfirstlane((int)s_ctl[2]);
+    const unsigned begin = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[3]), end = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[4]);
+    if (begin >= end) continue;          // group-uniform
+    const unsigned count = end - begin;  // <= PT * GT (the scan cut the bin accordingly)
+    if (STAMPS && gtid == 0) t_stamp[1] = wall_clock64();
+    const unsigned key = (unsigned)(((unsigned long long)(unsigned)bin * a.inv_mult) % (unsigned)a.nbins);
+    const int c0 = (int)(key / (unsigned)a.nb1), c1 = (int)(key % (unsigned)a.nb1);  // nominal classes of dims 0, 1
+    const int ci = c0 - 1 < 0 ? 0 : (c0 - 1 > a.n[0] - 4 ? a.n[0] - 4 : c0 - 1);      // their footprint cell
+    const int cj = c1 - 1 < 0 ? 0 : (c1 - 1 > a.n[1] - 4 ? a.n[1] - 4 : c1 - 1);
+    const unsigned cell_off = (unsigned)(ci * (int)a.nbj + cj) * 16u * (unsigned)sizeof(T);  // my cell's tile inside a plane, bytes
+    const RV* __restrict__ recs = reinterpret_cast<const RV*>(a.records) + begin;
+    const unsigned* __restrict__ index = a.index + begin;
+
+    // Sub-column fill, row by row: instruction slot j of a row moves the row's 16-byte units
+    // 64 j .. 64 j + 63 (1 KiB); unit u = tile l = u / PU, piece u % PU (the last unit of a tile
+    // is its padding: not written).  Lane -> (l, piece) does not depend on the row; the row goes
+    // into the instruction's scalar offset.  Rows are dealt to the group's waves.
+    auto fill = [&](unsigned row0, unsigned nrows) {
+      typedef __attribute__((address_space(3))) unsigned char lds_byte;
+      const unsigned units = n3 * PU;
+      const unsigned slots = (units + 63u) / 64u;
+      for (unsigned j = 0; j < slots; ++j) {
+        const unsigned u = j * 64u + wl;
+        const unsigned l = u / PU, piece = u - l * PU;
+        const bool valid = l < n3 && piece < PP;
+        const unsigned voff = l * ps3 + cell_off + piece * 16u;
+        for (unsigned k = gwave; k < nrows; k += GW) {
+          const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_col + k * rowpitch + j * 1024u));
+          if (valid) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_byte*)(size_t)dst, 16, voff, (row0 + k) * ps2, 0, 0);
+        }
+      }
+    };
+
+    // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram,
+    // in two batches of 16 loads per thread; the first phase's fill is issued behind the first.
+    unsigned cls23[PT / 2];  // two 16-bit keys per register
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      constexpr int HB = PT / 2;
+      if (h == 1 && (unsigned)HB * (unsigned)GT >= count) {  // group-uniform: nothing in the second batch
+#pragma unroll
+        for (int m = 0; m < HB / 2; ++m) cls23[HB / 2 + m] = 0;
+      } else {
+        T x2[HB], x3[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+          const unsigned q = (unsigned)(h * HB + m) * (unsigned)GT + gtid;
+          const RV r = q < count ? recs[q] : recs[0];
+          x2[m] = r[2];
+          x3[m] = r[3];
+        }
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+          const unsigned q = (unsigned)(h * HB + m) * (unsigned)GT + gtid;
+          const unsigned h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
+          const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
+          const unsigned c = h2 * (unsigned)a.q3 + (h3 >> a.sh3);  // < (n2 - 1) q3 <= 1024
+          const int mm = h * HB + m;
+          if (mm & 1) cls23[mm / 2] |= c << 16;
+          else cls23[mm / 2] = c;
+          if (q < count) atomicAdd(&s_hist[c], 1u);
+        }
+      }
+      if (h == 0) {  // the first sub-column travels while the second batch and the scan run
+        unsigned row0, nrows;
+        phase_rows(0, &row0, &nrows);
+        fill(row0, nrows);
+      }
+    }
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    if (STAMPS && gtid == 0) t_stamp[2] = wall_clock64();
+    // exclusive scan of the counters: CPT consecutive counters per thread, wave scan, wave totals
+    {
+      constexpr int CPT = (kColKeys + GT - 1) / GT;
+      unsigned mine[CPT];
+      unsigned sum = 0;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) { mine[c] = gtid * CPT + c < (unsigned)kColKeys ? s_hist[gtid * CPT + c] : 0u; sum += mine[c]; }
+      unsigned incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, off);
+        if (wl >= (unsigned)off) incl += up;
+      }
+      if (wl == 63u) s_wave[gwave] = incl;
+      col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+      unsigned run = incl - sum;
+      for (unsigned ww = 0; ww < gwave; ++ww) run += s_wave[ww];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) { if (gtid * CPT + c < (unsigned)kColKeys) s_hist[gtid * CPT + c] = run; run += mine[c]; }
+    }
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    // pass 2: slots (each counter ends up at the END of its key's stretch = the start of the next key's)
+#pragma unroll
+    for (int m = 0; m < PT; ++m) {
+      const unsigned q = (unsigned)m * (unsigned)GT + gtid;
+      const unsigned c = (m & 1) ? (cls23[m / 2] >> 16) : (cls23[m / 2] & 0xFFFFu);
+      if (q < count) perm[atomicAdd(&s_hist[c], 1u)] = (unsigned short)q;
+    }
+    if (STAMPS && gtid == 0) t_stamp[3] = wall_clock64();
+
+    // ---- the phases: K-range r of the column in LDS, the stretch of the local order that needs it
+    for (int r = 0; r < a.nphase; ++r) {
+      unsigned row0, nrows, ps = 0, pe = 0;
+      phase_rows(r, &row0, &nrows);
+      if (r > 0) {
+        phase_stretch(r, &ps, &pe);  // final: phase 0's barrier lies behind pass 2
+        if (pe == ps) continue;      // group-uniform: nobody needs these rows
+        col_group_barrier<BAR>(&s_ctl[0], epoch, wl);  // every wave has finished with the previous sub-column
+        if (gtid == 0) s_ctl[5] = 0;
+        fill(row0, nrows);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the sub-column has landed
+      col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+      if (r == 0) {
+        if (STAMPS && gtid == 0) t_stamp[4] = wall_clock64();
+        phase_stretch(0, &ps, &pe);
+        if (pe == ps) continue;
+      }
+      const int row_top = (int)nrows - 4;  // largest footprint row inside the sub-column
+
+      // Rows of 64 slots are handed to the waves as they free up (a shared counter: rows differ in
+      // cost — node forms, out-of-cell points — and the waves of a SIMD share its issue slots); a
+      // wave that draws a row beyond the stretch is done with the phase.
+      auto draw_row = [&]() -> unsigned {
+        unsigned v = 0;
+        if (wl == 0) v = atomicAdd(&s_ctl[5], 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+      };
+      unsigned jw = ps + draw_row() * 64u;
+      if (jw >= pe) continue;
+      // dead lanes (the stretch's tail) redo its last point: they keep their wave uniform
+      unsigned q = perm[jw + wl < pe ? jw + wl : pe - 1];
+      RV rec = recs[q];
+      for (;;) {
+        const bool live = jw + wl < pe;
+        const unsigned orig = index[q];  // used at the very end: its latency hides behind the planes
+        const RV rcur = rec;
+        const unsigned jn = ps + draw_row() * 64u;
+        if (jn < pe) {  // wave-uniform: next row's record on its way while this row's planes are evaluated
+          q = perm[jn + wl < pe ? jn + wl : pe - 1];
+          rec = recs[q];
+        }
+        ColDim<T> dim[4];
+        int loc[4];
+        bool ok = true;
+        unsigned cls = 0;    // per lane: bit 3d low, 3d + 1 high, 3d + 2 linearised (the general forms' input)
+        unsigned forms = 0;  // per wave: the form of dim d in bits 2d, 2d + 1
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const T x = rcur[d];
+          const T floc = dev_floor<T>((x - a.start[d]) / a.step[d]);        // multicubic/regular.rs:435-438
+          // num-traits <isize as NumCast>::from: Some iff -2^63 <= floc < 2^63, and `floc - 1` must not
+          // overflow isize (floc != -2^63): together |floc| < 2^63 (NaN fails)
+          ok &= dev_fabs<T>(floc) < (T)9223372036854775808.0;
+          const T nn2 = (T)(a.n[d] - 2);
+          // regular.rs:440-442: iloc = floc - 1 clamped to [0, n - 4], in the float domain (exact
+          // integers below 2^31; +-inf clamp; NaN -> 0: that point has failed anyway)
+          T c = floc - (T)1;
+          c = dev_fmax<T>(c, (T)0);
+          c = dev_fmin<T>(c, (T)(a.n[d] - 4));
+          const int l = (int)c;
+          // regular.rs:445-466 on floc = iloc + 1
+          const bool low = floc <= (T)0, high = floc >= nn2;
+          const bool lin = (floc < (T)0 || floc > nn2) && a.linearize != 0;
+          const T index_one_loc = mul_add<false>(a.step[d], c + (T)1, a.start[d]);  // regular.rs:356-360, never fused; (T)(l + 1) == c + 1
+          const T t = (x - index_one_loc) / a.step[d];
+          dim[d].low = low;
+          dim[d].high = high;
+          dim[d].lin = lin;
+          dim[d].tt = low ? -t : (high ? t - (T)1 : t);
+          loc[d] = l;
+          const int f = col_wave_form<T>(dim[d]);  // wave-uniform
+          forms |= (unsigned)f << (2 * d);
+          if (f != kFormNone) cls |= ((low ? 1u : 0u) | (high ? 2u : 0u) | (lin ? 4u : 0u)) << (3 * d);
+        }
+        // footprint rows relative to the sub-column; a point whose exact rows are not all in it is
+        // evaluated from the table below (its LDS reads stay inside the sub-column, result dropped)
+        const int rel2 = loc[2] - (int)row0;
+        const bool in_rows = rel2 >= 0 && rel2 <= row_top;
+        const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
+        T res;
+        if (forms == 0) {
+          res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, 0, 0);
+        } else {
+          res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
+        }
+        // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
+        if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
+          const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
+                                 (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
+          CubicDimRegular<T> dcopy[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {  // from the packed classes (all zero where the wave's form is None: sat None, not linearised)
+            dcopy[d].tt = dim[d].tt;
+            dcopy[d].sat = ((cls >> (3 * d)) & 1u) ? kSatLow : (((cls >> (3 * d + 1)) & 1u) ? kSatHigh : kSatNone);
+            dcopy[d].linear = (int)((cls >> (3 * d + 2)) & 1u);
+          }
+          res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
+        }
+        if (live) {
+          if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
+          stream_store(a.out + orig, res);
+        }
+        if (jn >= pe) break;
+        jw = jn;
+      }
+    }
+    if (STAMPS && a.stamps) {
+      // [0..4] thread 0's stamps (part drawn | part known | histogram | local order | first sub-column),
+      // [5] the group's LAST wave's end, [6] ids, [7] count | group | bin
+      unsigned long long* ws = a.stamps + (size_t)w * 8u;
+      const unsigned long long t_end = wall_clock64();
+      if (wl == 0) atomicMax(&ws[5], t_end);
+      if (gtid == 0) {
+        for (int k = 0; k < 5; ++k) ws[k] = t_stamp[k];
+        unsigned hw = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ws[6] = ((unsigned long long)xcc << 32) | hw;
+        ws[7] = ((unsigned long long)count << 32) | ((unsigned long long)grp << 16) | (unsigned)(bin & 0xFFFF);
+      }
     }
   }
 }

@@ -35,8 +35,8 @@ struct LaunchConfig {
   int axis_records = 1;    // rectilinear multilinear / nearest: search with per-bucket records where the handle has them (0: coordinates + tables as before)
   int stage_timing = 0;    // binned evaluation: record HIP events between its launches (interpn_hip_stage_ms; bench.py)
   int bin_scramble = 0;    // testing: the sort misplaces every 5th point by one bin (results must not change: exercises the column kernel's out-of-cell path)
-  int column_threads = 384; // column evaluation: threads per workgroup (256 / 384 / 512 / 768); with column_wgs = 2: 12 waves per CU = three per SIMD at 168 VGPRs
-  int column_wgs = 2;       // column evaluation: workgroups that share a CU's LDS (1..4): sizes the K-range sub-column of each (cubic_column.h)
+  int column_threads = 768; // column evaluation: threads of the persistent workgroup (768 = 12 waves = three per SIMD at 168 VGPRs; 384 and 256: tests)
+  int column_groups = 1;    // column evaluation: independent wave groups inside the workgroup (768 threads: 1 or 2; measured on cfg4: 0.74 ms with one group, 0.79 with two — the set-up two groups hide from each other costs less than the coarser end of the launch; cubic_column.h)
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
   long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
@@ -230,6 +230,7 @@ struct BinExtras {
   const void* records = nullptr;          // the slice's points in bin order, one N-element record each
   const unsigned* bin_end = nullptr;      // end of every bin in sorted order
   const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
+  unsigned* work = nullptr;               // the column kernel's part counter (zeroed by the scan)
 };
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
 // original indices (within the slice).  `stage` (optional, 4 events): recorded in front of the
@@ -246,13 +247,15 @@ bool cubic_column_applies(const GridDesc& g);
 constexpr unsigned kColumnMaxPart = 12288;  // points per workgroup at most (16-bit local order: 24 KiB of LDS beside the column)
 // The K-range phases of the column evaluation for this grid and these options (k_cubic_column.hip).
 struct ColumnPlan {
-  int threads = 384;         // workgroup size
-  unsigned part_points = 0;  // points of a part at most (16 per thread)
+  int threads = 768;         // workgroup size
+  int groups = 2;            // wave groups of a workgroup, each working on a part of its own
+  unsigned part_points = 0;  // points of a part at most (32 per thread of a group)
   int cpp = 0;               // classes of dim 2 per phase
   int nphase = 0;
   int q3 = 0, sh3 = 0;       // local sort key = class2 * q3 + (class3 >> sh3)
   unsigned sub_bytes = 0;    // LDS bytes of a phase's sub-column
-  size_t lds_bytes = 0;      // dynamic LDS of a workgroup: sub-column + local order
+  unsigned group_bytes = 0;  // dynamic LDS of a group: sub-column + local order
+  size_t lds_bytes = 0;      // dynamic LDS of a workgroup
 };
 bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan);
 template <typename T>

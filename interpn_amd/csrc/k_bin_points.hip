@@ -18,7 +18,7 @@ constexpr int kHistIters = 32;                             // histogram: 256-lan
 constexpr size_t kHistChunk = (size_t)kBlock * kHistIters;
 constexpr size_t kBinChunk = 4096;                         // scatter: points per workgroup (sorted in LDS)
 constexpr size_t kRecChunk = 4096;                         // ... when it writes records for the column kernel (measured: 2048 0.234, 4096 0.239, 8192 0.26, 12288 0.32 ms per 1e7 points)
-// totals[kMaxBins] | cursor[kMaxBins] | part_prefix[kMaxBins + 1] (+ padding)
+// totals[kMaxBins] | cursor[kMaxBins] | part_prefix[kMaxBins + 1] | ... | work counter of the column kernel at [3 kMaxBins + 16]
 constexpr size_t kCounterBytes = (size_t)4 * kMaxBins * sizeof(unsigned);
 
 struct BinParams {
@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals
   const int t = threadIdx.x;
   const unsigned mine = t < nbins ? totals[t] : 0u;
   if (t < kMaxBins) totals[t] = 0;  // ready for the next sort through this scratch block (no separate reset launch)
+  if (t == 0) totals[3 * kMaxBins + 16] = 0;  // the column kernel's part counter (cubic_column.h)
   const unsigned parts = part_points ? (mine + part_points - 1u) / part_points : 0u;
   s[t] = mine;
   sp[t] = parts;
@@ -326,6 +327,7 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     extras->records = a.records;
     extras->bin_end = cursor;  // after the scatter every cursor stands at the end of its bin
     extras->part_prefix = part_prefix;
+    extras->work = totals + 3 * kMaxBins + 16;
   }
   a.index = idx;
   a.cursor = cursor;

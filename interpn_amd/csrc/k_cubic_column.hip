@@ -6,18 +6,14 @@
 namespace interpn {
 
 namespace {
-// LDS of a CU and what a workgroup of this kernel declares statically (s_hist + a few words, rounded up)
+// LDS of a CU, and what a workgroup of this kernel declares statically per wave group (histogram +
+// control words, rounded up)
 constexpr size_t kCuLdsBytes = 160 * 1024;
-constexpr size_t kColumnStaticLds = 4608;
-
-int column_threads_of(const GridDesc& g) {
-  const int t = g.cfg.column_threads;
-  return t <= 256 ? 256 : (t <= 384 ? 384 : (t <= 512 ? 512 : 768));
-}
+constexpr size_t kColumnStaticPerGroup = 4096 + 256;
 
 // More than 64 KiB of dynamic LDS needs the opt-in, once per kernel and device: remembered here so
 // that the launch path does not pay the call (microseconds) every time.
-hipError_t column_lds_opt_in(const void* kernel) {
+hipError_t column_lds_opt_in(const void* kernel, int groups) {
   struct Seen { const void* fn; unsigned long long devices; };
   static std::mutex mu;
   static Seen seen[32] = {};
@@ -32,7 +28,8 @@ hipError_t column_lds_opt_in(const void* kernel) {
     }
     if (slot && ((slot->devices >> dev) & 1ull)) return hipSuccess;
   }
-  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCuLdsBytes - kColumnStaticLds));
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(kCuLdsBytes - (size_t)groups * kColumnStaticPerGroup));
   if (e == hipSuccess && slot) {
     std::lock_guard<std::mutex> lk(mu);
     slot->devices |= 1ull << dev;
@@ -41,28 +38,42 @@ hipError_t column_lds_opt_in(const void* kernel) {
 }
 }  // namespace
 
-// How the column evaluation cuts this grid's (k, l) column into K-range phases (cubic_column.h):
-// `column_wgs` workgroups share a CU's LDS; each keeps the local order of its part (16-bit, 16
-// points per thread) and a sub-column of cpp + 3 tile rows.  false: not even one class per phase
-// fits, or the local sort's keys do not.
+// How the column evaluation runs on this grid (cubic_column.h): one persistent workgroup per CU
+// of `groups` wave groups; each group keeps the local order of its part (16-bit, 32 points per
+// thread at most) and a sub-column of cpp + 3 tile rows in its share of the CU's LDS.  false: not
+// even one class per phase fits, or the local sort's keys do not.
 bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   ColumnPlan p;
-  p.threads = column_threads_of(g);
-  p.part_points = (unsigned)(kColPerThread * p.threads);
-  if (p.part_points > kColumnMaxPart) p.part_points = kColumnMaxPart;
+  // compiled shapes: 768 threads as two groups of six waves (the product shape) or as one group;
+  // 384 threads as one group; 256 threads as two groups of two waves (tests)
+  const int t = g.cfg.column_threads;
+  p.threads = t <= 256 ? 256 : (t <= 384 ? 384 : 768);
+  p.groups = p.threads == 384 ? 1 : (p.threads == 256 ? 2 : (g.cfg.column_groups == 1 ? 1 : 2));
   const size_t elem = g.dtype == kF64 ? 8 : 4;
-  const size_t tile = 16 * elem;
-  const int wgs = g.cfg.column_wgs >= 1 && g.cfg.column_wgs <= 4 ? g.cfg.column_wgs : 2;
-  const size_t per_wg = (kCuLdsBytes / (size_t)wgs) / 256 * 256;
-  const size_t perm = 2 * (size_t)p.part_points;
-  if (per_wg < kColumnStaticLds + perm + 4 * tile) return false;
-  const size_t room = per_wg - kColumnStaticLds - perm;
+  const size_t pitch = 16 * elem + 16;
+  const size_t per_group = ((kCuLdsBytes - (size_t)p.groups * kColumnStaticPerGroup) / (size_t)p.groups) / 1024 * 1024;
   const int n2 = g.n[2], n3 = g.n[3];
-  auto sub_bytes = [&](int rows) { return (size_t)(((size_t)rows * (size_t)n3 + 15) / 16) * 16 * tile; };
-  int rows = n2;  // the whole column if it fits
-  while (rows > 4 && sub_bytes(rows) > room) --rows;
-  if (sub_bytes(rows) > room) return false;
+  auto sub_bytes = [&](int rows) { return ((size_t)rows * (size_t)n3 * pitch + 1023) / 1024 * 1024; };
   const int ncls2 = n2 - 1;
+  // the largest part whose local order leaves room for at least a useful sub-column: parts as large
+  // as the registers of the local sort allow (fewer fills per point, longer phases), halved until
+  // at least a quarter of the classes fit a phase (or down to 2048 points)
+  unsigned part = (unsigned)(col_per_thread(p.threads / p.groups) * (p.threads / p.groups));
+  if (part > kColumnMaxPart) part = kColumnMaxPart;
+  int rows = 0;
+  for (;; part /= 2) {
+    const size_t perm = (2 * (size_t)part + 15) / 16 * 16;
+    rows = 0;
+    if (per_group > perm) {
+      const size_t room = per_group - perm;
+      rows = n2;
+      while (rows >= 4 && sub_bytes(rows) > room) --rows;
+    }
+    const bool roomy = rows >= n2 || (rows >= 4 && (rows - 3) * 4 >= ncls2);
+    if (roomy || part <= 2048) break;
+  }
+  if (rows < 4) return false;
+  p.part_points = part;
   int cpp = rows >= n2 ? ncls2 : rows - 3;  // a phase of cpp classes spans cpp + 3 rows at most
   if (cpp < 1) return false;
   if (g.cfg.column_cpp > 0 && g.cfg.column_cpp < cpp) cpp = g.cfg.column_cpp;
@@ -76,10 +87,11 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   // local sort keys: class of dim 2 x (class of dim 3 >> sh3), at most 1024
   p.sh3 = 0;
   auto q3_of = [&](int sh) { return ((n3 - 2) >> sh) + 1; };
-  while ((long long)ncls2 * q3_of(p.sh3) > 1024 && p.sh3 < 30) ++p.sh3;
+  while ((long long)ncls2 * q3_of(p.sh3) > kColKeys && p.sh3 < 30) ++p.sh3;
   p.q3 = q3_of(p.sh3);
-  if ((long long)ncls2 * p.q3 > 1024) return false;
-  p.lds_bytes = (size_t)p.sub_bytes + perm;
+  if ((long long)ncls2 * p.q3 > kColKeys) return false;
+  p.group_bytes = p.sub_bytes + (unsigned)((2 * (size_t)part + 15) / 16 * 16);
+  p.lds_bytes = (size_t)p.group_bytes * (size_t)p.groups;
   *plan = p;
   return true;
 }
@@ -127,6 +139,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.npts = npts;
   a.bin_end = extras.bin_end;
   a.part_prefix = extras.part_prefix;
+  a.work = extras.work;
   a.nbins = plan.nbins;
   a.nb1 = plan.nb1;
   a.inv_mult = (unsigned)plan.inv_mult;
@@ -136,24 +149,45 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.q3 = cp.q3;
   a.sh3 = cp.sh3;
   a.sub_bytes = cp.sub_bytes;
+  a.group_bytes = cp.group_bytes;
   a.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)g.cfg.debug_stamps);
   const size_t lds = cp.lds_bytes;
+  // persistent: one workgroup per CU (its LDS leaves room for no second one), fewer when there are fewer parts
+  size_t wgs = (max_parts + (size_t)cp.groups - 1) / (size_t)cp.groups;
+  if (wgs > (size_t)g.cfg.num_cus) wgs = (size_t)g.cfg.num_cus;
+  if (wgs < 1) wgs = 1;
   auto prepare = [&](auto kernel) -> hipError_t {
     if (lds <= 64 * 1024) return hipSuccess;
-    return column_lds_opt_in(reinterpret_cast<const void*>(kernel));
+    return column_lds_opt_in(reinterpret_cast<const void*>(kernel), cp.groups);
   };
   hipError_t e = hipSuccess;
-#define GO(FMA, TH)                                                                                              \
+#define GO(FMA, TH, GR)                                                                                          \
   do {                                                                                                           \
-    e = prepare(k_cubic_column<T, FMA, TH>);                                                                     \
+    e = prepare(k_cubic_column<T, FMA, TH, GR>);                                                                 \
     if (e != hipSuccess) return e;                                                                               \
-    g.tag.set("k_cubic_column", {FMA, TH}, 0b01u);                                                               \
-    hipLaunchKernelGGL((k_cubic_column<T, FMA, TH>), dim3((unsigned)max_parts), dim3(TH), lds, stream, a);       \
+    g.tag.set("k_cubic_column", {FMA, TH, GR, 0}, 0b1001u);                                                          \
+    hipLaunchKernelGGL((k_cubic_column<T, FMA, TH, GR>), dim3((unsigned)wgs), dim3(TH), lds, stream, a);         \
   } while (0)
+  // the measurement build (time stamps): the product shapes in f64 only
+  if (a.stamps && sizeof(T) == 8 && g.fma && cp.threads == 768) {
+    if constexpr (sizeof(T) == 8) {
+      if (cp.groups == 1) {
+        e = prepare(k_cubic_column<T, true, 768, 1, true>);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_cubic_column<T, true, 768, 1, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
+      } else {
+        e = prepare(k_cubic_column<T, true, 768, 2, true>);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_cubic_column<T, true, 768, 2, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
+      }
+      g.tag.set("k_cubic_column", {1, 768, cp.groups, 1}, 0b1001u);
+      return hipGetLastError();
+    }
+  }
 #define GO_T(FMA)                                                                                                \
   do {                                                                                                           \
-    if (cp.threads == 256) GO(FMA, 256); else if (cp.threads == 384) GO(FMA, 384);                               \
-    else if (cp.threads == 512) GO(FMA, 512); else GO(FMA, 768);                                                 \
+    if (cp.threads == 256) GO(FMA, 256, 2); else if (cp.threads == 384) GO(FMA, 384, 1);                         \
+    else if (cp.groups == 1) GO(FMA, 768, 1); else GO(FMA, 768, 2);                                              \
   } while (0)
   if (g.fma) GO_T(true); else GO_T(false);
 #undef GO_T

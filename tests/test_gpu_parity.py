@@ -1670,9 +1670,10 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     point to several workgroup parts with ragged tails, ~30 % of the points extrapolating (every
     node form: interior, saturated low / high, linearised, mixed waves), NaN / inf / huge
     coordinates (first failing index = the ORIGINAL index), both `linearize_extrapolation` values,
-    part sizes down to one row, 256 / 384 / 512 / 768-thread workgroups, the column resident whole
-    or one K-range at a time (`column_cpp`: 1..3 classes of dim 2 per phase, i.e. up to n2 - 1 phases
-    per part, some of them empty), and — `bin_scramble` — every fifth point deliberately sorted into
+    part sizes down to one row, persistent workgroups of 768 threads as two wave groups or one, of
+    384 threads (one group) and of 256 (two groups of two waves), the column resident whole or one
+    K-range at a time (`column_cpp`: 1..3 classes of dim 2 per phase, i.e. up to n2 - 1 phases per
+    part, some of them empty), and — `bin_scramble` — every fifth point deliberately sorted into
     the wrong bin, so that the kernel's out-of-cell path (the same tree from the table in global
     memory) is exercised: always the oracle's bits.  src/multicubic/regular.rs:325-623."""
     import torch
@@ -1682,16 +1683,16 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
     dev = torch.device("cuda:0")
     want_t = torch.float64 if dtype == np.float64 else torch.float32
-    for nobs, threads, part, scramble, cpp in ((1, 768, 0, 0, 0), (700, 384, 0, 0, 2), (5_000, 512, 0, 1, 1), (40_001, 256, 2048, 0, 3),
-                                               (40_001, 768, 1, 1, 0), (250_013, 384, 0, 0, 1), (250_013, 384, 0, 0, 0),
-                                               (250_013, 768, 3000, 1, 2)):
+    for nobs, threads, part, scramble, cpp in ((1, 768, 0, 0, 0), (700, 384, 0, 0, 2), (5_000, 768, 0, 1, 1), (40_001, 256, 2048, 0, 3),
+                                               (40_001, 768, 1, 1, 0), (250_013, 384, 0, 0, 1), (250_013, 768, 0, 0, 0),
+                                               (250_014, 768, 3000, 1, 2)):
         lin = bool((nobs + threads) % 2)
         case = synthetic_case("cubic", "regular", 4, axis, nobs, 9900 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
                               specials=min(axis) >= 8)
         want = run_oracle(oracle, case, True)
         it = _make_interp(interpn_amd, case)
         for k, v in (("binned", 1), ("column", 1), ("column_threads", threads), ("column_part", part), ("bin_scramble", scramble),
-                     ("column_cpp", cpp), ("column_wgs", 1 + nobs % 3)):
+                     ("column_cpp", cpp), ("column_groups", 1 + nobs % 2)):
             it.set_option(k, v)
         obs = [torch.from_numpy(o).to(dev) for o in case.obs]
         out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)

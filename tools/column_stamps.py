@@ -108,12 +108,15 @@ def main():
     print(json.dumps({"variant": "in place", "ms": round(t[0], 4), "kernel": it.kernel_name()}), flush=True)
     it.set_option("binned", 1)
     it.set_option("column", 1)
-    variants = [(768, 1, 0), (384, 2, 0), (256, 3, 0), (768, 1, 0), (256, 2, 0)]
+    variants = [(768, 2, 0), (768, 1, 0), (768, 2, 0), (768, 2, 5), (384, 1, 0)]
     if os.environ.get("STAMPS_VARIANTS"):
         variants = [tuple(int(v) for v in x.split("x")) for x in os.environ["STAMPS_VARIANTS"].split(",")]
-    for threads, wgs, cpp in variants:
+    for var in variants:
+        threads, wgs, cpp = var[:3]
+        part = var[3] if len(var) > 3 else 0
+        it.set_option("column_part", part)
         it.set_option("column_threads", threads)
-        it.set_option("column_wgs", wgs)
+        it.set_option("column_groups", wgs)
         it.set_option("column_cpp", cpp)
         it.set_option("debug_stamps", 0)
         it.set_option("stage_timing", 0)
@@ -134,7 +137,7 @@ def main():
         st = stamps.cpu().numpy().view(np.uint64).reshape(-1, 8)
         if os.environ.get("STAMPS_DIR"):
             np.save(os.path.join(os.environ["STAMPS_DIR"], f"stamps_{threads}x{wgs}_{len(os.listdir(os.environ['STAMPS_DIR']))}.npy"), st[st[:, 5] != 0])
-        print(json.dumps({"threads": threads, "wgs_per_cu": wgs, "ms": round(t[0], 4), "min": round(t[1], 4), "stage_ms": stage,
+        print(json.dumps({"threads": threads, "groups": wgs, "cpp": cpp, "part": part, "ms": round(t[0], 4), "min": round(t[1], 4), "stage_ms": stage,
                           "kernel": it.kernel_name(), "bit_identical_to_in_place": same, "stamps": analyse(st)}), flush=True)
     it.close()
 

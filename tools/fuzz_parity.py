@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_WGS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -113,8 +113,8 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 env["INTERPN_HIP_BINNED"] = "1"
                 env["INTERPN_HIP_BRICKS"] = "11"
                 env["INTERPN_HIP_COLUMN"] = str(int(rng.choice([-1, 1, 1, 1, 0])))
-                env["INTERPN_HIP_COLUMN_THREADS"] = str(int(rng.choice([256, 384, 384, 512, 768])))
-                env["INTERPN_HIP_COLUMN_WGS"] = str(int(rng.integers(1, 5)))
+                env["INTERPN_HIP_COLUMN_THREADS"] = str(int(rng.choice([256, 384, 768, 768])))
+                env["INTERPN_HIP_COLUMN_GROUPS"] = str(int(rng.integers(1, 3)))
                 if rng.random() < 0.6: env["INTERPN_HIP_COLUMN_CPP"] = str(int(rng.choice([1, 2, 3, 5])))  # several K-range phases on small grids
                 if rng.random() < 0.5: env["INTERPN_HIP_COLUMN_PART"] = str(int(rng.choice([1, 64, 700, 2048, 12288])))
                 if rng.random() < 0.4: env["INTERPN_HIP_BIN_SCRAMBLE"] = "1"
