@@ -1563,7 +1563,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       if (!cubic_column_plan(*use, &cplan)) { err = hipErrorInvalidValue; break; }
       size_t q = cplan.part_points;
       if (g.cfg.column_part > 0 && (size_t)g.cfg.column_part < q) q = (size_t)g.cfg.column_part;
-      const size_t max_parts = count / q + (size_t)plan.nbins + 1;
+      const size_t max_parts = 4 * (count / q) + (size_t)plan.nbins + 1;  // upper bound (the scan cuts the last bins finer)
       BinExtras extras;
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage, slot->totals_clean);
       slot->totals_clean = err == hipSuccess;

@@ -114,7 +114,12 @@ __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals
   const unsigned mine = t < nbins ? totals[t] : 0u;
   if (t < kMaxBins) totals[t] = 0;  // ready for the next sort through this scratch block (no separate reset launch)
   if (t == 0) totals[3 * kMaxBins + 16] = 0;  // the column kernel's part counter (cubic_column.h)
-  const unsigned parts = part_points ? (mine + part_points - 1u) / part_points : 0u;
+  // The column kernel's persistent workgroups draw parts in bin order: the last fifth of the bins
+  // is cut four times finer (never below 1024 points), so that the launch ends in small pieces
+  // (a whole bin is 1/4 of a workgroup's share of cfg4: the end of the launch idled 8 % of the CU time).
+  unsigned pp = part_points;
+  if (pp && t >= nbins - nbins / 5) pp = pp / 4 > 1024u ? pp / 4 : (pp < 1024u ? pp : 1024u);
+  const unsigned parts = pp ? (mine + pp - 1u) / pp : 0u;
   s[t] = mine;
   sp[t] = parts;
   __syncthreads();
