@@ -219,7 +219,8 @@ struct BinPlan {
   double start[2] = {0, 0};
   double scale[2] = {0, 0};  // cell ~ floor((x - start) * scale) - 1
 };
-constexpr int kMaxBins = 1024;  // one bin per thread of the scatter kernel's scan; 16-bit keys
+constexpr int kMaxBins = 4096;       // class-pair bins of the column evaluation (16-bit keys; 64^4 has 63^2 = 3969)
+constexpr int kMaxTiledBins = 1024;  // bins of the tiled kernels' sort: one bin per thread of its scatter kernel's scan
 constexpr size_t kBinSlicePoints = (size_t)1 << 25;  // points sorted and evaluated per slice (bounds the scratch)
 // `classes`: one bin per pair of saturation classes of dims 0, 1 (what the column evaluation
 // needs; regular grids); false when they do not fit kMaxBins.

@@ -1,6 +1,7 @@
 // Counting sort of a batch of observation points by the tile position of their multicubic
 // footprint (interpn_host.h: "Binned evaluation").  Three launches per slice of at most 2^25
-// points: histogram of the bin keys, exclusive scan of the <= 256 bin totals, scatter of the
+// points: histogram of the bin keys, exclusive scan of the bin totals (<= 1024 tile-position bins,
+// <= 4096 class-pair bins), scatter of the
 // coordinates (all N dimensions) and of the original indices into bin order.  Every workgroup owns
 // a contiguous chunk of 4096 points: it counts its chunk in LDS, sorts the chunk's local indices
 // by bin in LDS, reserves one run per non-empty bin with a single global atomic, and copies its
@@ -108,20 +109,29 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
 // ceil(c / part_points) parts, part_prefix[b] = parts in front of bin b, part_prefix[nbins] = all.
 __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals, unsigned* __restrict__ cursor, int nbins,
                                                    unsigned* __restrict__ part_prefix, unsigned part_points) {
+  constexpr int BPT = kMaxBins / 1024;  // consecutive bins per thread
   __shared__ unsigned s[1024];
   __shared__ unsigned sp[1024];
   const int t = threadIdx.x;
-  const unsigned mine = t < nbins ? totals[t] : 0u;
-  if (t < kMaxBins) totals[t] = 0;  // ready for the next sort through this scratch block (no separate reset launch)
+  unsigned mine[BPT], parts[BPT];
+  unsigned sum = 0, sump = 0;
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) {
+    const int b = t * BPT + k;
+    mine[k] = b < nbins ? totals[b] : 0u;
+    totals[b] = 0;  // ready for the next sort through this scratch block (no separate reset launch)
+    // The column kernel's persistent workgroups draw parts in bin order: the last fifth of the bins
+    // is cut four times finer (never below 1024 points), so that the launch ends in small pieces
+    // (a whole bin is 1/4 of a workgroup's share of cfg4: the end of the launch idled 8 % of the CU time).
+    unsigned pp = part_points;
+    if (pp && b >= nbins - nbins / 5) pp = pp / 4 > 1024u ? pp / 4 : (pp < 1024u ? pp : 1024u);
+    parts[k] = pp ? (mine[k] + pp - 1u) / pp : 0u;
+    sum += mine[k];
+    sump += parts[k];
+  }
   if (t == 0) totals[3 * kMaxBins + 16] = 0;  // the column kernel's part counter (cubic_column.h)
-  // The column kernel's persistent workgroups draw parts in bin order: the last fifth of the bins
-  // is cut four times finer (never below 1024 points), so that the launch ends in small pieces
-  // (a whole bin is 1/4 of a workgroup's share of cfg4: the end of the launch idled 8 % of the CU time).
-  unsigned pp = part_points;
-  if (pp && t >= nbins - nbins / 5) pp = pp / 4 > 1024u ? pp / 4 : (pp < 1024u ? pp : 1024u);
-  const unsigned parts = pp ? (mine + pp - 1u) / pp : 0u;
-  s[t] = mine;
-  sp[t] = parts;
+  s[t] = sum;
+  sp[t] = sump;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
     const unsigned add = t >= off ? s[t - off] : 0u;
@@ -131,10 +141,17 @@ __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals
     sp[t] += addp;
     __syncthreads();
   }
-  if (t < nbins) {
-    cursor[t] = s[t] - mine;
-    part_prefix[t] = sp[t] - parts;
-    if (t == nbins - 1) part_prefix[nbins] = sp[t];
+  unsigned run = s[t] - sum, runp = sp[t] - sump;
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) {
+    const int b = t * BPT + k;
+    if (b < nbins) {
+      cursor[b] = run;
+      part_prefix[b] = runp;
+      if (b == nbins - 1) part_prefix[nbins] = runp + parts[k];
+    }
+    run += mine[k];
+    runp += parts[k];
   }
 }
 
@@ -158,17 +175,17 @@ constexpr int kScatThreads = 1024;
 // CH = points per workgroup.
 template <typename T, int N, int CH>
 __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<T, N> a) {
-  static_assert(kMaxBins <= kScatThreads && kMaxBins <= 65536 && CH <= 65536, "one bin per thread in the scan; keys and local indices are 16-bit");
+  static_assert(kMaxTiledBins <= kScatThreads && kMaxTiledBins <= 65536 && CH <= 65536, "one bin per thread in the scan; keys and local indices are 16-bit");
   constexpr int kIters = CH / kScatThreads;
-  __shared__ unsigned fill[kMaxBins];
-  __shared__ unsigned lstart[kMaxBins];   // first local position of a bin inside this chunk
-  __shared__ unsigned base[kMaxBins];     // first global position of this chunk's run in a bin
+  __shared__ unsigned fill[kMaxTiledBins];
+  __shared__ unsigned lstart[kMaxTiledBins];   // first local position of a bin inside this chunk
+  __shared__ unsigned base[kMaxTiledBins];     // first global position of this chunk's run in a bin
   __shared__ unsigned short keys[CH];       // key of local point l
   __shared__ unsigned short sorted_src[CH]; // local point at sorted position j
   __shared__ unsigned short sorted_key[CH];
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
-  if (tid < kMaxBins) fill[tid] = 0;
+  if (tid < kMaxTiledBins) fill[tid] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * CH;
   const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
@@ -192,18 +209,18 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
   }
   __syncthreads();
   // exclusive scan of the bin counts: one bin per thread, Hillis-Steele
-  const unsigned mine = tid < kMaxBins ? fill[tid] : 0u;
-  if (tid < kMaxBins) lstart[tid] = mine;
+  const unsigned mine = tid < kMaxTiledBins ? fill[tid] : 0u;
+  if (tid < kMaxTiledBins) lstart[tid] = mine;
   __syncthreads();
-  for (int off = 1; off < kMaxBins; off <<= 1) {
-    const unsigned add = (tid < kMaxBins && tid >= (unsigned)off) ? lstart[tid - off] : 0u;
+  for (int off = 1; off < kMaxTiledBins; off <<= 1) {
+    const unsigned add = (tid < kMaxTiledBins && tid >= (unsigned)off) ? lstart[tid - off] : 0u;
     __syncthreads();
-    if (tid < kMaxBins) lstart[tid] += add;
+    if (tid < kMaxTiledBins) lstart[tid] += add;
     __syncthreads();
   }
-  const unsigned excl = tid < kMaxBins ? lstart[tid] - mine : 0u;
+  const unsigned excl = tid < kMaxTiledBins ? lstart[tid] - mine : 0u;
   __syncthreads();
-  if (tid < kMaxBins) {
+  if (tid < kMaxTiledBins) {
     lstart[tid] = excl;
     base[tid] = (mine && (int)tid < nbins) ? atomicAdd(&a.cursor[tid], mine) : 0u;  // one run per non-empty bin
     fill[tid] = 0;
@@ -255,13 +272,12 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter(const ScatterArgs<
 // lives on one XCD) merges them into whole lines before they leave.  Two barriers, no gathers.
 template <typename T, int N, int CH>
 __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const ScatterArgs<T, N> a) {
-  static_assert(kMaxBins <= kScatThreads, "one bin per thread when the runs are reserved");
   constexpr int kIters = CH / kScatThreads;
   __shared__ unsigned fill[kMaxBins];
   __shared__ unsigned base[kMaxBins];
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
-  if (tid < kMaxBins) fill[tid] = 0;
+  for (int b = (int)tid; b < nbins; b += kScatThreads) fill[b] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * CH;
   const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
@@ -285,9 +301,9 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const Scat
     }
   }
   __syncthreads();
-  if (tid < kMaxBins) {
-    const unsigned mine = fill[tid];
-    base[tid] = (mine && (int)tid < nbins) ? atomicAdd(&a.cursor[tid], mine) : 0u;  // one run per non-empty bin
+  for (int b = (int)tid; b < nbins; b += kScatThreads) {
+    const unsigned mine = fill[b];
+    base[b] = mine ? atomicAdd(&a.cursor[b], mine) : 0u;  // one run per non-empty bin
   }
   __syncthreads();
   typedef T RV __attribute__((ext_vector_type(N)));
@@ -391,7 +407,7 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool cl
   // in flight then share an L2-sized piece of it): 32^4 f64 (113 MiB) -> 225 bins, 48^4 (597 MiB)
   // -> 529; never fewer than 64 (balance across the XCDs), never more than kMaxBins.
   long long target = (long long)(table_bytes >> 19);
-  target = target < 64 ? 64 : (target > kMaxBins ? kMaxBins : target);
+  target = target < 64 ? 64 : (target > kMaxTiledBins ? kMaxTiledBins : target);
   if (classes) {  // one bin per pair of saturation classes (column evaluation): only if they all fit
     if ((long long)p.ncell[0] * p.ncell[1] > kMaxBins) return false;
     target = kMaxBins;

@@ -1662,7 +1662,7 @@ def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monke
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("axis", [[6, 7, 5, 6], [4, 4, 4, 4], [9, 5, 12, 7], [33, 32, 6, 5]], ids=str)
+@pytest.mark.parametrize("axis", [[6, 7, 5, 6], [4, 4, 4, 4], [9, 5, 12, 7], [33, 32, 6, 5], [41, 40, 5, 6]], ids=str)
 def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, axis):
     """Column evaluation (cubic_column.h): large 4-D multicubic batches on a regular grid are sorted
     by the saturation-class pair of dims 0, 1 and a workgroup evaluates its bin's points out of an
@@ -1675,7 +1675,8 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     K-range at a time (`column_cpp`: 1..3 classes of dim 2 per phase, i.e. up to n2 - 1 phases per
     part, some of them empty), and — `bin_scramble` — every fifth point deliberately sorted into
     the wrong bin, so that the kernel's out-of-cell path (the same tree from the table in global
-    memory) is exercised: always the oracle's bits.  src/multicubic/regular.rs:325-623."""
+    memory) is exercised: always the oracle's bits.  [41, 40, 5, 6]: 1560 class-pair bins (more than
+    one per thread of the sort's kernels).  src/multicubic/regular.rs:325-623."""
     import torch
 
     import interpn_amd
