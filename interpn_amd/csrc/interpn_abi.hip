@@ -895,19 +895,28 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       return INTERPN_HIP_ERR_UNSUPPORTED;
     }
   }
-  // Per-bucket search records (interpn_host.h: axis_rec_*; multilinear and nearest only): built on
-  // the host with the arithmetic bucket_of() uses on the device (same type, same operations, no
-  // contraction), for axes whose buckets hold at most one coordinate each.  All axes or none.
+  // Per-bucket search records (interpn_host.h: axis_rec_*; multilinear only — the nearest kernel
+  // measured slower with them and never reads them): built on the host with the arithmetic
+  // bucket_of() uses on the device (same type, same operations, no contraction), for axes whose
+  // buckets hold at most one coordinate each.  All axes or none.  They sit BEHIND the image
+  // (coordinates + tables), which keeps its own size: a kernel that searches without records
+  // stages the image alone.  The form is chosen for the LDS budget of the kernel that will run
+  // (rect_args.h): full records {g[k-1], g[k], g[k+1], k} when they fit it, else the compact
+  // form {g[k], k} + a copy of the coordinates, else none.
+  g.axis_image_bytes = (unsigned)bytes;
   std::vector<std::vector<unsigned char>> recs(ngrids);
   {
-    bool all = method != kCubic;
-    size_t rbytes = 0;
-    const size_t rsize = sizeof(T) == 8 ? 32 : 16;
+    bool all = method == kLinear;
+    const size_t cap = ngrids <= 2 ? kMaxGridLdsBytesWide : kMaxGridLdsBytes;
+    std::vector<std::vector<int>> firsts(ngrids);
+    size_t full_bytes = 0, compact_bytes = 0;
+    const size_t rsize = sizeof(T) == 8 ? 32 : 16, csize = sizeof(T) == 8 ? 16 : 8;
     for (size_t i = 0; i < ngrids && all; ++i) {
       const int n = (int)grid_lens[i], M = g.axis_buckets[i];
       if (M <= 0) { all = false; break; }
       const T g0 = (T)g.axis_g0[i], scale = (T)g.axis_scale[i];
-      std::vector<int> first(M + 1, n);  // first[b] = tab[b]: coordinates in buckets < b
+      std::vector<int>& first = firsts[i];
+      first.assign(M + 1, n);  // first[b] = tab[b]: coordinates in buckets < b
       int prev = -1;
       for (int k = 0; k < n && all; ++k) {
         const T u = (grids[i][k] - g0) * scale;
@@ -916,23 +925,50 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
         for (int q = prev + 1; q <= b; ++q) first[q] = k;
         prev = b;
       }
-      if (!all) break;
-      recs[i].assign((size_t)M * rsize, 0);
-      for (int b = 0; b < M; ++b) {
-        const int k = first[b];
-        if (k >= n) { all = false; break; }  // cannot happen: g[n-1] lies in bucket M-1
-        T triple[3] = {k > 0 ? grids[i][k - 1] : (T)0, grids[i][k], k + 1 < n ? grids[i][k + 1] : (T)0};
-        unsigned char* r = recs[i].data() + (size_t)b * rsize;
-        memcpy(r, triple, 3 * sizeof(T));
-        const unsigned ku = (unsigned)k;
-        memcpy(r + 3 * sizeof(T), &ku, sizeof(ku));
-      }
-      rbytes += recs[i].size();
+      for (int b = 0; b < M && all; ++b)
+        if (first[b] >= n) all = false;  // cannot happen: g[n-1] lies in bucket M-1
+      full_bytes += (size_t)M * rsize;
+      compact_bytes += (((size_t)n * sizeof(T) + 15) & ~(size_t)15) + (size_t)M * csize;
     }
-    if (all && rbytes <= kMaxGridLdsBytesWide && bytes + rbytes < 0xFFFFFF00ull) {
+    // INTERPN_HIP_AXIS_REC_FORM = 1 / 2 forces the full / compact form where it fits (tuning, tests)
+    const char* form_env = getenv("INTERPN_HIP_AXIS_REC_FORM");
+    const int form = form_env ? atoi(form_env) : 0;
+    // N <= 2: beyond 32 KiB the full records cost a resident workgroup per CU more than their
+    // single access saves (2-D 384^2: 1.05 ms with 49 KiB of full records, see profiles/r04_rect_bucket_records.txt)
+    const size_t full_cap = ngrids <= 2 ? (size_t)32 * 1024 : cap;
+    const bool full = all && (form == 1 ? full_bytes <= cap : (form == 2 ? false : full_bytes <= full_cap));
+    const bool compact = all && !full && compact_bytes <= cap;
+    if ((full || compact) && bytes + (full ? full_bytes : compact_bytes) < 0xFFFFFF00ull) {
       g.axis_rec_base = (unsigned)bytes;
+      g.axis_rec_compact = compact ? 1 : 0;
       for (size_t i = 0; i < ngrids; ++i) {
-        g.axis_rec_off[i] = (unsigned)bytes;
+        const int n = (int)grid_lens[i], M = g.axis_buckets[i];
+        const std::vector<int>& first = firsts[i];
+        if (full) {
+          recs[i].assign((size_t)M * rsize, 0);
+          for (int b = 0; b < M; ++b) {
+            const int k = first[b];
+            T triple[3] = {k > 0 ? grids[i][k - 1] : (T)0, grids[i][k], k + 1 < n ? grids[i][k + 1] : (T)0};
+            unsigned char* r = recs[i].data() + (size_t)b * rsize;
+            memcpy(r, triple, 3 * sizeof(T));
+            const unsigned ku = (unsigned)k;
+            memcpy(r + 3 * sizeof(T), &ku, sizeof(ku));
+          }
+          g.axis_rec_off[i] = (unsigned)bytes;
+        } else {
+          const size_t gbytes = ((size_t)n * sizeof(T) + 15) & ~(size_t)15;
+          recs[i].assign(gbytes + (size_t)M * csize, 0);
+          memcpy(recs[i].data(), grids[i], (size_t)n * sizeof(T));
+          for (int b = 0; b < M; ++b) {
+            const int k = first[b];
+            unsigned char* r = recs[i].data() + gbytes + (size_t)b * csize;
+            memcpy(r, &grids[i][k], sizeof(T));
+            const unsigned ku = (unsigned)k;
+            memcpy(r + sizeof(T), &ku, sizeof(ku));
+          }
+          g.axis_recg_off[i] = (unsigned)bytes;
+          g.axis_rec_off[i] = (unsigned)(bytes + gbytes);
+        }
         bytes += recs[i].size();
       }
       g.axis_rec_bytes = (unsigned)(bytes - g.axis_rec_base);
@@ -940,7 +976,7 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       for (auto& r : recs) r.clear();
     }
   }
-  g.axis_image_bytes = (unsigned)bytes;
+  g.axis_alloc_bytes = (unsigned)bytes;
   hipError_t e = pool_alloc(h->device, &h->grids_owned, bytes);
   if (e == hipSuccess) e = hipMemsetAsync(h->grids_owned, 0, bytes, nullptr);
   if (e != hipSuccess) {
@@ -959,7 +995,8 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       e = build_lane_table<T>(reinterpret_cast<const T*>(gdev), g.n[i], (T)g.axis_g0[i], (T)g.axis_lscale[i],
                               reinterpret_cast<unsigned*>((char*)h->grids_owned + g.axis_ltab_off[i]), nullptr);
     if (e == hipSuccess && g.axis_rec_bytes)
-      e = hipMemcpy((char*)h->grids_owned + g.axis_rec_off[i], recs[i].data(), recs[i].size(), hipMemcpyHostToDevice);
+      e = hipMemcpy((char*)h->grids_owned + (g.axis_rec_compact ? g.axis_recg_off[i] : g.axis_rec_off[i]), recs[i].data(), recs[i].size(),
+                    hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       interpn_hip_destroy(h);
       return hip_fail(e);
@@ -1237,9 +1274,9 @@ int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip
   const size_t elem = g.dtype == kF64 ? 8 : 4;
   hipError_t e = pool_alloc(dev, &h->vals_owned, g.nvals * elem);
   if (e == hipSuccess) e = hipMemcpyPeer(h->vals_owned, dev, src->desc.vals, src->device, g.nvals * elem);
-  if (e == hipSuccess && src->desc.axis_image && g.axis_image_bytes) {
-    e = pool_alloc(dev, &h->grids_owned, g.axis_image_bytes);
-    if (e == hipSuccess) e = hipMemcpyPeer(h->grids_owned, dev, src->desc.axis_image, src->device, g.axis_image_bytes);
+  if (e == hipSuccess && src->desc.axis_image && g.axis_alloc_bytes) {
+    e = pool_alloc(dev, &h->grids_owned, g.axis_alloc_bytes);
+    if (e == hipSuccess) e = hipMemcpyPeer(h->grids_owned, dev, src->desc.axis_image, src->device, g.axis_alloc_bytes);
     if (e == hipSuccess) {
       g.axis_image = h->grids_owned;
       for (int d = 0; d < g.ndims; ++d) g.grid[d] = (const char*)h->grids_owned + g.axis_g_off[d];
@@ -1286,6 +1323,10 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
     return INTERPN_HIP_OK;
   }
   if (!strcmp(name, "fma")) { *value = h->desc.fma; return INTERPN_HIP_OK; }
+  // read-only: how the handle's rectilinear axes will be searched (0 no records, 1 full, 2 compact) and what is staged
+  if (!strcmp(name, "axis_rec_mode")) { *value = h->desc.axis_rec_bytes ? (h->desc.axis_rec_compact ? 2 : 1) : 0; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "axis_rec_bytes")) { *value = h->desc.axis_rec_bytes; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "axis_image_bytes")) { *value = h->desc.axis_image_bytes; return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_binned")) { *value = h->evals_binned.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }

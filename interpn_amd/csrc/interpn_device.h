@@ -164,6 +164,7 @@ struct Axis {
   T g0;
   T scale;
   const unsigned char* rec = nullptr;  // per-bucket records (below), or null
+  bool compact = false;                // `rec` holds AxisRecordC (g[k] and k only; the brackets are read from `g`)
 };
 
 // Per-bucket record of an axis whose buckets hold at most one coordinate each: with k = tab[b],
@@ -171,6 +172,13 @@ struct Axis {
 template <typename T> struct AxisRecord;
 template <> struct __attribute__((aligned(16))) AxisRecord<double> { double gm1, g0, gp1; unsigned k, pad; };
 template <> struct __attribute__((aligned(16))) AxisRecord<float> { float gm1, g0, gp1; unsigned k; };
+
+// Compact form (round 4), for axes whose full records do not fit the kernel's LDS budget: {g[k], k}
+// — 16 bytes in f64, 8 in f32 — next to the coordinates themselves (8n / 4n bytes): 40n bytes per
+// f64 axis instead of 64n, a second (dependent) LDS access for the two brackets.
+template <typename T> struct AxisRecordC;
+template <> struct __attribute__((aligned(16))) AxisRecordC<double> { double g0; unsigned k, pad; };
+template <> struct __attribute__((aligned(8))) AxisRecordC<float> { float g0; unsigned k; };
 
 constexpr int kLaneBuckets = 255;  // buckets of a lane table (256 byte entries = 64 lanes x 4)
 
@@ -209,6 +217,15 @@ __device__ __forceinline__ int axis_cell(const Axis<T>& ax, T x, T* x0, T* x1) {
     // k + (g[k] < x), and cell l = clamp(that - 1, 0, n - 2) is k (brackets g[k], g[k+1]) or k - 1
     // (brackets g[k-1], g[k]).  NaN: bucket 0, g[0] < NaN is false, l = 0 like the reference.
     const int b = bucket_of<T>(x, ax.g0, ax.scale, ax.M);
+    if (ax.compact) {
+      const AxisRecordC<T> r = reinterpret_cast<const AxisRecordC<T>*>(ax.rec)[b];
+      const int k = (int)r.k;
+      const bool hi = (r.g0 < x && k <= n - 2) || k == 0;
+      const int l = hi ? k : k - 1;
+      *x0 = ax.g[l];
+      *x1 = ax.g[l + 1];
+      return l;
+    }
     const AxisRecord<T> r = reinterpret_cast<const AxisRecord<T>*>(ax.rec)[b];
     const int k = (int)r.k;
     const bool up = r.g0 < x;

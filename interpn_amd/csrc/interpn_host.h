@@ -77,7 +77,8 @@ struct GridDesc {
   // Rectilinear axes as one device image: per axis the coordinates (8-byte aligned) followed by
   // the bucket table ((M+1) x u32), see interpn_device.h::Axis.  Staged into LDS when small.
   const void* axis_image = nullptr;
-  unsigned axis_image_bytes = 0;
+  unsigned axis_image_bytes = 0;   // coordinates + tables only: what the kernels stage when they search without records
+  unsigned axis_alloc_bytes = 0;   // the whole allocation: image + records region
   unsigned axis_g_off[8] = {0};    // byte offsets inside the image
   unsigned axis_tab_off[8] = {0};
   int axis_buckets[8] = {0};       // M per axis, 0 = no table
@@ -95,9 +96,15 @@ struct GridDesc {
   // the table's two words, a scan probe and the two bracketing coordinates (interpn_device.h::
   // axis_cell).  They sit behind the coordinates and tables in the axis image and are staged
   // INSTEAD of them.  axis_rec_bytes = 0: none (some axis is not eligible, or every axis fits a lane).
-  unsigned axis_rec_off[8] = {0};   // byte offsets inside the image
-  unsigned axis_rec_base = 0;       // first byte of the records region
+  unsigned axis_rec_off[8] = {0};   // byte offsets inside the allocation
+  unsigned axis_rec_base = 0;       // first byte of the records region (behind the image)
   unsigned axis_rec_bytes = 0;      // its size
+  // Compact form (interpn_device.h::AxisRecordC), built when the full records exceed the LDS
+  // budget of the kernel that will run (20 KiB for N >= 3, 60 KiB for N <= 2) but {g[k], k} plus
+  // a copy of the coordinates fit: the region then holds, per axis, the coordinates
+  // (axis_recg_off) followed by the records (axis_rec_off).
+  int axis_rec_compact = 0;
+  unsigned axis_recg_off[8] = {0};
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell

@@ -58,7 +58,8 @@ struct AxisArgs {
   T lscale[N];
   // Per-bucket search records (GridDesc::axis_rec_*): when use_rec is set, `image` / `image_bytes`
   // are the records region alone and rec_off[d] is axis d's offset inside it; g_off / tab_off are
-  // then not to be dereferenced.
+  // then not to be dereferenced.  use_rec == 2: the compact form — `image` is the compact region
+  // (per axis its coordinates, then its AxisRecordC entries), g_off[d] / rec_off[d] offsets inside it.
   int use_rec;
   unsigned rec_off[N];
 };
@@ -73,6 +74,7 @@ __device__ __forceinline__ Axis<T> make_axis(const AxisArgs<T, N>& a, const unsi
   ax.g0 = a.g0[d];
   ax.scale = a.scale[d];
   ax.rec = a.use_rec ? base + a.rec_off[d] : nullptr;
+  ax.compact = a.use_rec == 2;
   return ax;
 }
 

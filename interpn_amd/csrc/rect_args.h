@@ -33,10 +33,13 @@ inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds
   bool lanes = g.cfg.axis_regs != 0;  // the lane-resident search (lane_axes.h) takes axes of <= 64 coordinates
   for (int d = 0; d < N; ++d) lanes = lanes && g.n[d] <= 64;
   if (records && !lanes && g.cfg.axis_records != 0 && g.axis_rec_bytes && g.axis_rec_bytes <= cap) {
-    ax.use_rec = 1;
+    ax.use_rec = g.axis_rec_compact ? 2 : 1;
     ax.image += g.axis_rec_base;
     ax.image_bytes = g.axis_rec_bytes;
-    for (int d = 0; d < N; ++d) ax.rec_off[d] = g.axis_rec_off[d] - g.axis_rec_base;
+    for (int d = 0; d < N; ++d) {
+      ax.rec_off[d] = g.axis_rec_off[d] - g.axis_rec_base;
+      if (g.axis_rec_compact) ax.g_off[d] = g.axis_recg_off[d] - g.axis_rec_base;  // the region's own copy of the coordinates
+    }
     ax.use_lds = 1;
     return g.axis_rec_bytes;
   }

@@ -1749,14 +1749,18 @@ def test_column_evaluation_is_chosen_for_large_batches_only(oracle, monkeypatch)
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("method,axis", [("linear", [300]), ("linear", [65, 130]), ("linear", [70, 9, 81]), ("linear", [7, 90, 5, 6]),
-                                         ("linear", [40, 33]), ("linear", [500, 470])], ids=str)
+                                         ("linear", [40, 33]), ("linear", [500, 470]), ("linear", [512, 512]), ("linear", [128, 120, 100]),
+                                         ("nearest", [80, 70, 90])], ids=str)
 def test_rectilinear_bucket_records(oracle, monkeypatch, dtype, method, axis):
     """Axes too long for the lane-resident search are searched through per-bucket records — one LDS
     access {g[k-1], g[k], g[k+1], k} per cell query instead of table words + scan + brackets
     (interpn_device.h::axis_cell; multilinear/rectilinear.rs:353-370).  Jittered axes (records
     built), with and without the records (option axis_records), forced LDS search on short axes
     too, and a clustered axis whose buckets hold several coordinates (no records: the old search):
-    always the oracle's bits, exact nodes / domain ends / NaN included."""
+    always the oracle's bits, exact nodes / domain ends / NaN included.  Round 4: where the full
+    records exceed the kernel's LDS budget (2-D 512^2 in f64: 64 KiB; 3-D 128 x 120 x 100) the compact
+    form {g[k], k} + coordinates is built instead (option axis_rec_mode = 2), and the image a kernel
+    stages without records is coordinates + tables only, whatever records exist (nearest: none)."""
     import torch
 
     import interpn_amd
@@ -1779,6 +1783,15 @@ def test_rectilinear_bucket_records(oracle, monkeypatch, dtype, method, axis):
         obs = [torch.from_numpy(o).to(dev) for o in case.obs]
         for records, axis_regs in ((1, -1), (0, -1), (1, 0)):
             it = _make_interp(interpn_amd, case)
+            mode = it.get_option("axis_rec_mode")
+            table_words = sum(2 * a + 1 for a in axis)  # (M + 1) u32 per axis, M = 2n
+            assert it.get_option("axis_image_bytes") <= sum(axis) * np.dtype(dtype).itemsize + 4 * table_words + 16 * 3 * n + 280 * n
+            if method == "nearest" or variant == "clustered":
+                assert mode == 0
+            elif axis in ([512, 512], [128, 120, 100]) and dtype == np.float64:
+                assert mode == 2 and it.get_option("axis_rec_bytes") <= (60 if n <= 2 else 20) * 1024
+            elif max(axis) > 64:
+                assert mode in (1, 2)
             it.set_option("axis_records", records)
             it.set_option("axis_regs", axis_regs)
             got = it.eval_tensors(obs).cpu().numpy()

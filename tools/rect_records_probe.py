@@ -37,7 +37,9 @@ def main():
             ms.append(a.elapsed_time(b))
         return float(np.median(ms))
 
-    cases = [("linear", 3, n) for n in (65, 72, 80, 100)] + [("linear", 2, n) for n in (128, 256, 384, 512)] + [("nearest", 3, 80)]
+    cases = [("linear", 3, n) for n in (65, 72, 80, 100, 128)] + [("linear", 2, n) for n in (128, 256, 384, 512)] + [("nearest", 3, 80)]
+    if "forms" in sys.argv:  # full against compact records where both fit
+        cases = [("linear", 3, 72), ("linear", 3, 100), ("linear", 2, 256), ("linear", 2, 384)]
     for method, nd, n in cases:
         rng = np.random.default_rng(n)
         g = np.linspace(-1.0, 1.0, n)
@@ -52,8 +54,20 @@ def main():
         reg = interpn_amd.Interpolator.regular(method, [n] * nd, np.full(nd, -1.0), np.full(nd, step), vals, False, 0, np.float64)
         t_reg = timed(reg, obs)
         reg.close()
+        if "forms" in sys.argv:
+            row = {"method": method, "ndims": nd, "n": n, "regular_ms": round(t_reg, 4)}
+            for form in (1, 2):
+                os.environ["INTERPN_HIP_AXIS_REC_FORM"] = str(form)
+                it = interpn_amd.Interpolator.rectilinear(method, grids, vals, False, 0, np.float64)
+                row[f"form{form}_mode"] = it.get_option("axis_rec_mode")
+                row[f"form{form}_ms"] = round(timed(it, obs), 4)
+                it.close()
+            os.environ.pop("INTERPN_HIP_AXIS_REC_FORM")
+            print(json.dumps(row), flush=True)
+            continue
         it = interpn_amd.Interpolator.rectilinear(method, grids, vals, False, 0, np.float64)
         t_rec = timed(it, obs)
+        mode = it.get_option("axis_rec_mode")
         ref = out.clone()
         kn = it.kernel_name()
         it.set_option("axis_records", 0)
@@ -62,7 +76,7 @@ def main():
         it.close()
         print(json.dumps({"method": method, "ndims": nd, "n": n, "regular_ms": round(t_reg, 4), "rect_records_ms": round(t_rec, 4),
                           "rect_round2_search_ms": round(t_old, 4), "records_vs_regular": round(t_rec / t_reg, 3),
-                          "round2_vs_regular": round(t_old / t_reg, 3), "same_bits": same, "kernel": kn}), flush=True)
+                          "round2_vs_regular": round(t_old / t_reg, 3), "same_bits": same, "rec_mode": mode, "kernel": kn}), flush=True)
 
 
 if __name__ == "__main__":
