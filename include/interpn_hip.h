@@ -232,6 +232,22 @@ int interpn_hip_eval_host_sharded(interpn_hip_interp* const* handles, size_t nha
                                   const void* const* obs, const size_t* obs_lens, size_t nobs,
                                   void* out, size_t nout, uint64_t* first_bad_index);
 
+/* Device-resident single-process multi-GPU form (round 4): a caller that is ONE process — the
+ * reference's PyO3 module is (src/python.rs:58-80) — with the observation points already sharded
+ * over the devices.  Shard r is obs[r][0..nobs) (a HOST array of `nobs` DEVICE pointers on the
+ * device of handles[r], each to npoints[r] elements) -> out[r] (a device pointer there), enqueued
+ * on streams[r] (hipStream_t; `streams` or an entry may be NULL = default stream).  All shards
+ * are enqueued before the first one is waited for; the call returns when every shard has finished.
+ * No PCIe traffic besides the 8-byte status words, no collective.  The handles must be distinct
+ * and describe the same interpolator (interpn_hip_replicate).  On
+ * INTERPN_HIP_ERR_UNREPRESENTABLE `*first_bad_index` (optional) is the global index of the
+ * first failing point, counting the shards' points in shard order; results in front of it are
+ * the reference's, results behind it unspecified. */
+int interpn_hip_eval_device_sharded(interpn_hip_interp* const* handles, size_t nhandles,
+                                    const void* const* const* obs, size_t nobs, void* const* out,
+                                    const size_t* npoints, void* const* streams,
+                                    uint64_t* first_bad_index);
+
 /* Evaluate on device arrays (asynchronous on `stream`, a hipStream_t; NULL = default stream).
  * `obs` is a HOST array of `nobs` DEVICE pointers, each to `npoints` elements; `out` is a device
  * pointer to `npoints` elements.  Returns as soon as the work is enqueued: one kernel, no copy and

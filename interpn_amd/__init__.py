@@ -16,12 +16,13 @@ import numpy as np
 from . import _lib, raw
 from .classes import (MulticubicRectilinear, MulticubicRegular, MultilinearRectilinear, MultilinearRegular,
                       NearestRectilinear, NearestRegular)
-from .handle import Interpolator, eval_host_sharded
+from .handle import Interpolator, eval_device_sharded, eval_host_sharded
 
 __version__ = "0.1.0"
 
 __all__ = [
     "eval_host_sharded",
+    "eval_device_sharded",
     "__version__",
     "raw",
     "interpn",

@@ -117,6 +117,8 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_eval_host.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_size_t, c_void_p, c_size_t]
     lib.interpn_hip_eval_host_sharded.argtypes = [POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_size_t),
                                                   c_size_t, c_void_p, c_size_t, POINTER(c_uint64)]
+    lib.interpn_hip_eval_device_sharded.argtypes = [POINTER(c_void_p), c_size_t, POINTER(POINTER(c_void_p)), c_size_t,
+                                                    POINTER(c_void_p), POINTER(c_size_t), POINTER(c_void_p), POINTER(c_uint64)]
     lib.interpn_hip_eval_device.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p]
     lib.interpn_hip_eval_device_ex.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, c_void_p, c_size_t, c_void_p,
                                                ctypes.c_uint, POINTER(c_int), POINTER(c_int)]

@@ -1,0 +1,181 @@
+// Per-handle options (latched from INTERPN_HIP_* once, at creation; nothing on the launch path
+// reads the environment), and what a handle reports about itself.  (C ABI internals, see abi_internal.h.)
+#include "abi_internal.h"
+
+using namespace interpn;
+using namespace interpn_abi;
+
+namespace interpn_abi {
+
+// Options by name (interpn_hip_set_option / interpn_hip_get_option, and the INTERPN_HIP_<NAME>
+// environment variables latched at creation).  Returns false for an unknown name or a value out
+// of range; `set == false` reads.
+bool option_access(LaunchConfig& c, const char* name, long long* value, bool set) {
+  struct Opt { const char* name; int* field; long long lo, hi; };
+  const Opt opts[] = {
+      {"blocks_per_cu", &c.blocks_per_cu, 1, 65536},
+      {"iters_per_block", &c.iters_per_block, 0, 65536},
+      {"ppl", &c.ppl, 0, 2},
+      {"axis_regs", &c.axis_regs, -1, 2},
+      {"force_generic", &c.force_generic, 0, 1},
+      {"generic_runtime", &c.generic_runtime, 0, 1},
+      {"generic_vec", &c.generic_vec, -1, 1},
+      {"persistent", &c.persistent, 0, 1},
+      {"axis_lds_kb", &c.axis_lds_kb, -1, 60},
+      {"binned", &c.binned, -1, 1},
+      {"deal", &c.deal, 0, 1},
+      {"bin_slice_log2", &c.bin_slice_log2, 16, 27},
+      {"column", &c.column, -1, 1},
+      {"column_part", &c.column_part, 0, 1 << 20},
+      {"column_threads", &c.column_threads, 256, 1024},
+      {"column_groups", &c.column_groups, 1, 2},
+      {"column_cpp", &c.column_cpp, 0, 1 << 20},
+      {"bin_scramble", &c.bin_scramble, 0, 1},
+      {"stage_timing", &c.stage_timing, 0, 1},
+      {"axis_records", &c.axis_records, 0, 1},
+  };
+  if (!name || !value) return false;
+  if (!strcmp(name, "host_chunk")) {
+    if (set) {
+      if (*value < 0) return false;
+      c.host_chunk = *value;
+    } else {
+      *value = c.host_chunk;
+    }
+    return true;
+  }
+  if (!strcmp(name, "debug_stamps")) {  // a device address (measurement aid, cubic_column.h)
+    if (set) c.debug_stamps = *value;
+    else *value = c.debug_stamps;
+    return true;
+  }
+  for (const Opt& o : opts) {
+    if (strcmp(name, o.name)) continue;
+    if (set) {
+      if (*value < o.lo || *value > o.hi) return false;
+      *o.field = (int)*value;
+    } else {
+      *value = *o.field;
+    }
+    return true;
+  }
+  return false;
+}
+
+// The environment is read here, once per handle, and nowhere on the launch path.
+void latch_env(LaunchConfig& c) {
+  static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
+                                      "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "axis_records", "bin_scramble"};
+  for (const char* nm : names) {
+    char var[64] = "INTERPN_HIP_";
+    size_t k = strlen(var);
+    for (const char* q = nm; *q && k + 1 < sizeof(var); ++q) var[k++] = (char)toupper((unsigned char)*q);
+    var[k] = 0;
+    const char* env = getenv(var);
+    if (!env || !*env) continue;
+    char* end = nullptr;
+    long long v = strtoll(env, &end, 10);
+    if (end == env) continue;
+    (void)option_access(c, nm, &v, true);  // out-of-range values are ignored, as before
+  }
+}
+
+}  // namespace interpn_abi
+
+extern "C" {
+
+int interpn_hip_set_blocks_per_cu(interpn_hip_interp* h, int blocks_per_cu) {
+  if (!h || blocks_per_cu < 1 || blocks_per_cu > 65536) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  h->desc.cfg.blocks_per_cu = blocks_per_cu;
+  return INTERPN_HIP_OK;
+}
+
+int interpn_hip_set_option(interpn_hip_interp* h, const char* name, long long value) {
+  if (!h || !name) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (!strcmp(name, "fma")) {  // the flavour is read at every launch; tables do not depend on it
+    if (value != 0 && value != 1) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+    h->desc.fma = (int)value;
+    return INTERPN_HIP_OK;
+  }
+  return option_access(h->desc.cfg, name, &value, true) ? INTERPN_HIP_OK : INTERPN_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long long* value) {
+  if (!h || !name || !value) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  if (!strcmp(name, "last_binned")) {  // read-only: did the most recent device-pointer evaluation sort its points first?
+    *value = h->desc.last_binned;
+    return INTERPN_HIP_OK;
+  }
+  if (!strcmp(name, "fma")) { *value = h->desc.fma; return INTERPN_HIP_OK; }
+  // read-only: how the handle's rectilinear axes will be searched (0 no records, 1 full, 2 compact) and what is staged
+  if (!strcmp(name, "axis_rec_mode")) { *value = h->desc.axis_rec_bytes ? (h->desc.axis_rec_compact ? 2 : 1) : 0; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "axis_rec_bytes")) { *value = h->desc.axis_rec_bytes; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "axis_image_bytes")) { *value = h->desc.axis_image_bytes; return INTERPN_HIP_OK; }
+  {  // read-only: the device the handle lives on and the thresholds derived from it (interpn_host.h::Thresholds)
+    const LaunchConfig& c = h->desc.cfg;
+    const Thresholds t = thresholds(c);
+    const struct { const char* nm; long long v; } ro[] = {
+        {"dev_num_cus", c.num_cus}, {"dev_num_xcds", c.num_xcds}, {"dev_l2_bytes", c.l2_bytes}, {"dev_lds_per_cu", c.lds_per_cu},
+        {"dev_lds_per_wg", c.lds_per_wg}, {"thr_table_l2_sized", (long long)t.table_l2_sized}, {"thr_table_l2_share", (long long)t.table_l2_share},
+        {"thr_binned_table_min", (long long)t.binned_table_min}, {"thr_binned_points_min", (long long)t.binned_points_min},
+        {"thr_bin_table_share", (long long)t.bin_table_share}, {"thr_axis_lds", (long long)t.axis_lds},
+        {"thr_axis_lds_wide", (long long)t.axis_lds_wide}, {"thr_column_lds", (long long)t.column_lds}};
+    for (const auto& r : ro)
+      if (!strcmp(name, r.nm)) { *value = r.v; return INTERPN_HIP_OK; }
+  }
+  if (!strcmp(name, "evals_binned")) { *value = h->evals_binned.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "scratch_bytes")) {
+    interpn_hip_interp* hm = const_cast<interpn_hip_interp*>(h);
+    std::lock_guard<std::mutex> lk(hm->bin_mu);
+    long long tot = 0;
+    for (const auto& sl : hm->bin_slots) tot += (long long)sl.bytes;
+    *value = tot;
+    return INTERPN_HIP_OK;
+  }
+  LaunchConfig c = h->desc.cfg;
+  return option_access(c, name, value, false) ? INTERPN_HIP_OK : INTERPN_HIP_ERR_INVALID_ARGUMENT;
+}
+
+// "interpn::k_linear_brick<double, 3, false, true, 1, 2, 2, 0>" — rocprofv3's spelling of the
+// instantiation, without the return type and the argument list.
+int interpn_hip_kernel_name(const interpn_hip_interp* h, char* buf, size_t buflen) {
+  if (!h || !buf || buflen == 0) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  const KernelTag t = h->desc.tag;
+  if (!t.name) {
+    buf[0] = 0;
+    return INTERPN_HIP_OK;
+  }
+  std::string out = std::string("interpn::") + t.name + "<" + (h->desc.dtype == kF64 ? "double" : "float");
+  for (int k = 0; k < t.nargs; ++k) {
+    out += ", ";
+    if (t.bool_mask & (1u << k)) out += t.args[k] ? "true" : "false";
+    else out += std::to_string(t.args[k]);
+  }
+  out += ">";
+  snprintf(buf, buflen, "%s", out.c_str());
+  return INTERPN_HIP_OK;
+}
+
+// Bytes of the re-laid grid copy the handle keeps (0 = kernels read the C-ordered `vals`), and
+// its layout steps; for reports.
+size_t interpn_hip_table_bytes(const interpn_hip_interp* h, int* step_i, int* step_j) {
+  if (!h || !h->desc.bricks) return 0;
+  const GridDesc& g = h->desc;
+  if (step_i) *step_i = g.brick_step[0];
+  if (step_j) *step_j = g.brick_step[1];
+  size_t bytes = 0;
+  unsigned nb[3];
+  unsigned nb4[4];
+  if (g.method == kCubic) cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+  else if (g.ndims == 1) bytes = records1_bytes(g, g.rec1_buckets);
+  else if (g.ndims == 2) brick2_geometry(g, nb, &bytes);
+  else if (g.brick_cell == 2) brick_j4_geometry(g, nb, &bytes);
+  else if (g.brick_cell) brick_cell_geometry(g, nb4, &bytes);
+  else brick_geometry(g, g.brick_step[0], g.brick_step[1], nb, &bytes);
+  return bytes;
+}
+
+}  // extern "C"

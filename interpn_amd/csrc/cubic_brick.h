@@ -79,7 +79,7 @@ template <typename T> __device__ __forceinline__ unsigned cubic_dma_rot(unsigned
 // cell indices and the tile geometry the table was built with; dead lanes carry the offsets of a
 // valid point).  Builds with -DINTERPN_HIP_DEBUG_BOUNDS fold soff into the checked voff, so that a
 // layout bug reads zeros (and fails the parity tests) instead of a neighbouring allocation.
-// Tables are kept below 4 GiB (interpn_abi.hip::maybe_build_cubic_tiles).
+// Tables are kept below 4 GiB (abi_layout.hip::maybe_build_cubic_tiles).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }

@@ -14,10 +14,14 @@ enum Kind : int { kRegular = 0, kRectilinear = 1 };
 enum DType : int { kF64 = 0, kF32 = 1 };
 
 // Per-handle launch options.  Defaults are latched from the environment ONCE, when the handle is
-// created (interpn_abi.hip::latch_env); interpn_hip_set_option changes them afterwards.  Nothing on
+// created (abi_options.hip::latch_env); interpn_hip_set_option changes them afterwards.  Nothing on
 // the launch path reads the environment.
 struct LaunchConfig {
-  int num_cus = 256;       // MI355X: 8 XCDs x 32 CUs
+  int num_cus = 256;       // MI355X: 8 XCDs x 32 CUs (queried per device at creation, like the next three)
+  int num_xcds = 8;        // L2 domains of the device
+  long long l2_bytes = 4ll << 20;        // L2 of one XCD
+  long long lds_per_cu = 160ll << 10;    // LDS of a CU
+  long long lds_per_wg = 64ll << 10;     // LDS a workgroup gets without opt-in
   int blocks_per_cu = 8;   // 256-thread workgroups resident per CU that a persistent grid is sized for
   int iters_per_block = 0; // brick kernels: 256-wide iterations per workgroup (0 = the kernel's default)
   int ppl = 0;             // multilinear brick kernels: points per lane (0 = auto, 1 = scalar streams)
@@ -151,6 +155,35 @@ constexpr unsigned long long kNoBadIndexHost = ~0ull;  // value of the device fi
 constexpr size_t kMaxGridLdsBytes = 20 * 1024;
 // ... or most of the 64 KiB a workgroup gets without opt-in, for 1-D / 2-D kernels with no other LDS use.
 constexpr size_t kMaxGridLdsBytesWide = 60 * 1024;
+
+// The tuning thresholds as functions of the device (round 4; on MI355X they evaluate to the
+// constants the measurements of DESIGN.md were taken with — tests/test_gpu_parity.py asserts it):
+// an XCD's L2 (4 MiB), the LDS of a CU (160 KiB) and of a workgroup without opt-in (64 KiB), the CUs.
+struct Thresholds {
+  size_t table_l2_sized;      // a re-laid table up to this size is "L2-sized": 1.5 x L2 (6 MiB; the L2 keeps ~3.3 MiB of it beside the streams, the rest hits often enough)
+  size_t table_l2_share;      // what an L2 holds of a table beside the streams: 0.75 x L2 (3 MiB)
+  double table_l2_model;      // the same in the multicubic tile-layout model: 0.875 x L2 (3.5 MiB)
+  size_t binned_table_min;    // sorting pays only for tables beyond 2 x L2 (8 MiB)
+  size_t binned_points_min;   // ... and batches of at least 2048 points per CU (2^19)
+  size_t bin_table_share;     // the sort's bins are sized to L2 / 8 of the table (512 KiB)
+  size_t axis_lds;            // rectilinear axes in LDS: LDS per CU / 8 (20 KiB: 8 workgroups stay resident)
+  size_t axis_lds_wide;       // ... 1-D / 2-D kernels: workgroup LDS without opt-in - 4 KiB (60 KiB)
+  size_t column_lds;          // the column kernel's workgroup: the whole LDS of a CU (160 KiB)
+};
+inline Thresholds thresholds(const LaunchConfig& c) {
+  Thresholds t;
+  const size_t l2 = (size_t)c.l2_bytes;
+  t.table_l2_sized = l2 + l2 / 2;
+  t.table_l2_share = l2 - l2 / 4;
+  t.table_l2_model = 0.875 * (double)l2;
+  t.binned_table_min = 2 * l2;
+  t.binned_points_min = (size_t)2048 * (size_t)c.num_cus;
+  t.bin_table_share = l2 / 8;
+  t.axis_lds = (size_t)c.lds_per_cu / 8;
+  t.axis_lds_wide = (size_t)c.lds_per_wg - 4096;
+  t.column_lds = (size_t)c.lds_per_cu;
+  return t;
+}
 
 template <typename T>
 hipError_t launch_linear_regular(const GridDesc& g, const T* const* obs, T* out, size_t npts,

@@ -406,7 +406,8 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool cl
   // Bins sized so that one bin's share of the table is about half a MiB (the workgroups an XCD has
   // in flight then share an L2-sized piece of it): 32^4 f64 (113 MiB) -> 225 bins, 48^4 (597 MiB)
   // -> 529; never fewer than 64 (balance across the XCDs), never more than kMaxBins.
-  long long target = (long long)(table_bytes >> 19);
+  const size_t share = thresholds(g.cfg).bin_table_share;  // L2 / 8 = 512 KiB on MI355X
+  long long target = (long long)(table_bytes / (share ? share : 1));
   target = target < 64 ? 64 : (target > kMaxTiledBins ? kMaxTiledBins : target);
   if (classes) {  // one bin per pair of saturation classes (column evaluation): only if they all fit
     if ((long long)p.ncell[0] * p.ncell[1] > kMaxBins) return false;

@@ -8,12 +8,11 @@ namespace interpn {
 namespace {
 // LDS of a CU, and what a workgroup of this kernel declares statically per wave group (histogram +
 // control words, rounded up)
-constexpr size_t kCuLdsBytes = 160 * 1024;
 constexpr size_t kColumnStaticPerGroup = 4096 + 256;
 
 // More than 64 KiB of dynamic LDS needs the opt-in, once per kernel and device: remembered here so
 // that the launch path does not pay the call (microseconds) every time.
-hipError_t column_lds_opt_in(const void* kernel, int groups) {
+hipError_t column_lds_opt_in(const void* kernel, int groups, size_t cu_lds) {
   struct Seen { const void* fn; unsigned long long devices; };
   static std::mutex mu;
   static Seen seen[32] = {};
@@ -29,7 +28,7 @@ hipError_t column_lds_opt_in(const void* kernel, int groups) {
     if (slot && ((slot->devices >> dev) & 1ull)) return hipSuccess;
   }
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(kCuLdsBytes - (size_t)groups * kColumnStaticPerGroup));
+                                           (int)(cu_lds - (size_t)groups * kColumnStaticPerGroup));
   if (e == hipSuccess && slot) {
     std::lock_guard<std::mutex> lk(mu);
     slot->devices |= 1ull << dev;
@@ -51,7 +50,9 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   p.groups = p.threads == 384 ? 1 : (p.threads == 256 ? 2 : (g.cfg.column_groups == 1 ? 1 : 2));
   const size_t elem = g.dtype == kF64 ? 8 : 4;
   const size_t pitch = 16 * elem + 16;
-  const size_t per_group = ((kCuLdsBytes - (size_t)p.groups * kColumnStaticPerGroup) / (size_t)p.groups) / 1024 * 1024;
+  const size_t cu_lds = thresholds(g.cfg).column_lds;  // the LDS of a CU: 160 KiB on MI355X
+  if (cu_lds < (size_t)p.groups * (kColumnStaticPerGroup + 8192)) return false;
+  const size_t per_group = ((cu_lds - (size_t)p.groups * kColumnStaticPerGroup) / (size_t)p.groups) / 1024 * 1024;
   const int n2 = g.n[2], n3 = g.n[3];
   auto sub_bytes = [&](int rows) { return ((size_t)rows * (size_t)n3 * pitch + 1023) / 1024 * 1024; };
   const int ncls2 = n2 - 1;
@@ -158,7 +159,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   if (wgs < 1) wgs = 1;
   auto prepare = [&](auto kernel) -> hipError_t {
     if (lds <= 64 * 1024) return hipSuccess;
-    return column_lds_opt_in(reinterpret_cast<const void*>(kernel), cp.groups);
+    return column_lds_opt_in(reinterpret_cast<const void*>(kernel), cp.groups, thresholds(g.cfg).column_lds);
   };
   hipError_t e = hipSuccess;
 #define GO(FMA, TH, GR)                                                                                          \

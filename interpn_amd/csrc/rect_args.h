@@ -28,7 +28,8 @@ inline size_t fill_axis_args(const GridDesc& g, AxisArgs<T, N>& ax, bool big_lds
     ax.ltab_off[d] = g.axis_ltab_off[d];
     ax.lscale[d] = (T)g.axis_lscale[d];
   }
-  size_t cap = (big_lds && N <= 2) ? kMaxGridLdsBytesWide : kMaxGridLdsBytes;
+  const Thresholds th = thresholds(g.cfg);
+  size_t cap = (big_lds && N <= 2) ? th.axis_lds_wide : th.axis_lds;
   if (g.cfg.axis_lds_kb >= 0 && g.cfg.axis_lds_kb <= 60) cap = (size_t)g.cfg.axis_lds_kb * 1024;  // tuning knob
   bool lanes = g.cfg.axis_regs != 0;  // the lane-resident search (lane_axes.h) takes axes of <= 64 coordinates
   for (int d = 0; d < N; ++d) lanes = lanes && g.n[d] <= 64;

@@ -314,3 +314,55 @@ def eval_host_sharded(interps, obs, out: np.ndarray) -> np.ndarray:
         raise err
     _lib.raise_for_status(st)
     return out
+
+
+def eval_device_sharded(interps, obs_shards, out_shards=None):
+    """Single-process multi-GPU evaluation of device-resident shards (`interpn_hip_eval_device_sharded`):
+    `obs_shards[r]` is the list of N coordinate tensors of shard r on the device of `interps[r]`
+    (clones made with `.replicate(device)`), `out_shards[r]` its result tensor (allocated when
+    omitted).  Every shard is enqueued on its device's current torch stream before the first is
+    waited for; returns the list of result tensors.  On "Unrepresentable coordinate value" the
+    AssertionError carries `first_bad_index`, counting the shards' points in shard order."""
+    import torch
+
+    interps = list(interps)
+    if not interps or len(obs_shards) != len(interps):
+        raise ValueError("eval_device_sharded needs one list of coordinate tensors per interpolator")
+    lib = _lib.load()
+    n = len(interps)
+    nd = interps[0].ndims
+    tdt = torch.float64 if interps[0].dtype == np.float64 else torch.float32
+    outs = list(out_shards) if out_shards is not None else [None] * n
+    hs = (c_void_p * n)()
+    obs_pp = (ctypes.POINTER(c_void_p) * n)()
+    out_p = (c_void_p * n)()
+    npts = (c_size_t * n)()
+    streams = (c_void_p * n)()
+    keep = []
+    for r, it in enumerate(interps):
+        shard = list(obs_shards[r])
+        if len(shard) != nd:
+            raise AssertionError("Dimension mismatch")
+        count = int(shard[0].numel())
+        for t in shard:
+            if t.dtype != tdt or not t.is_contiguous() or int(t.numel()) != count:
+                raise ValueError("coordinate tensors of a shard must be contiguous, of the interpolator's dtype and equally long")
+            it._check_same_device("obs", t)
+        if outs[r] is None:
+            outs[r] = torch.empty(count, dtype=tdt, device=shard[0].device)
+        it._check_same_device("out", outs[r])
+        arr = (c_void_p * max(nd, 1))(*[t.data_ptr() for t in shard])
+        keep.append(arr)
+        hs[r] = it._h
+        obs_pp[r] = ctypes.cast(arr, ctypes.POINTER(c_void_p))
+        out_p[r] = outs[r].data_ptr()
+        npts[r] = count
+        streams[r] = torch.cuda.current_stream(shard[0].device).cuda_stream
+    bad = c_uint64(0)
+    st = lib.interpn_hip_eval_device_sharded(hs, n, obs_pp, nd, out_p, npts, streams, ctypes.byref(bad))
+    if st == _lib.ERR_UNREPRESENTABLE:
+        err = AssertionError(_lib.strerror(st))
+        err.first_bad_index = bad.value
+        raise err
+    _lib.raise_for_status(st)
+    return outs

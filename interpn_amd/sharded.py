@@ -45,19 +45,33 @@ def broadcast_grid(vals, grids=None, src: int = 0):
     # Whenever a process group exists the collective is issued, also with a single rank: the RCCL
     # call sequence a 1-GPU box can execute is then the one an 8-GPU node executes.
     if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":  # RCCL moves device memory only: say so instead of failing inside the collective
+            for t in [vals] + list(grids or []):
+                if not getattr(t, "is_cuda", False):
+                    raise ValueError("broadcast_grid under the nccl (RCCL) backend needs CUDA tensors on the rank's GPU; "
+                                     "got a host tensor (allocate with device='cuda', or use the gloo backend)")
         dist.broadcast(vals, src=src)
         for g in grids or []:
             dist.broadcast(g, src=src)
     return vals, grids
 
 
-def _collective_device(dist):
+def _collective_device(dist, interp=None):
     """Where tensors handed to the default group's collectives must live: the rank's GPU for
-    nccl (= RCCL on ROCm), the host otherwise."""
+    nccl (= RCCL on ROCm) — the device the rank's interpolator lives on, not torch's current
+    device (a caller that passed device=local_rank without torch.cuda.set_device would otherwise
+    put every rank's tensor on cuda:0) —, the host otherwise."""
     import torch
 
     if dist.get_backend() == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
+        idx = None
+        dev_fn = getattr(interp, "device", None)
+        if callable(dev_fn):
+            try:
+                idx = int(dev_fn())
+            except Exception:
+                idx = None
+        return torch.device("cuda", idx if idx is not None and idx >= 0 else torch.cuda.current_device())
     return torch.device("cpu")
 
 
@@ -138,7 +152,7 @@ class ShardedInterpolator:
             # takes part, so the others never hang in the collective; -1 wins the MIN.  Issued
             # with a single rank too (same call sequence at every world size).
             t = torch.tensor([-1 if failure is not None else 0, local], dtype=torch.int64,
-                             device=_collective_device(dist))
+                             device=_collective_device(dist, self._interp))
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             any_failed, local = int(t[0].item()) < 0, int(t[1].item())
             if failure is None and any_failed:

@@ -22,7 +22,7 @@ def run(args, env_extra=None, timeout=240):
     return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])
 def test_gpus_flag_spawns_that_many_ranks(n):
     p = run(["--gpus", str(n), "--steps", "7", "--dry-run"])
     assert p.returncode == 0, p.stderr[-2000:]

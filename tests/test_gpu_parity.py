@@ -378,7 +378,7 @@ def test_unrepresentable_aborts_at_first_bad_point(oracle, method, bad):
 @pytest.mark.parametrize("nobs,k", [(1, 0), (1000, 0), (1000, 999), (5000, 4321), (8192, 8191), (8193, 8192), (8193, 10)])
 def test_small_batch_zero_copy_path(oracle, dtype, nobs, k):
     """Host batches of at most 8192 points take the zero-copy path (pinned staging the kernel reads
-    and writes over PCIe, one synchronisation; interpn_abi.hip::eval_host_small); 8193 points take
+    and writes over PCIe, one synchronisation; abi_host.hip::eval_host_small); 8193 points take
     the staged pipeline.  Same bits, and the same abort contract at the first failing point —
     prefix written, the rest of the caller's `out` untouched — on a resident handle used twice
     (the sticky status word must be clean again) and through the one-shot entry point."""
@@ -484,6 +484,82 @@ def test_eval_host_sharded(oracle, method, kind, nhandles):
             for h in hs:
                 h.close()
         assert_parity(case, got, want)
+
+
+def test_eval_host_sharded_eight_handles_cfg5_split(oracle):
+    """cfg5's split at 1/100 scale through the single-process entry point: a 128^3 grid on one
+    handle, replicated device to device into seven more (`interpn_hip_replicate`; all eight on this
+    box's one GPU), 8e6 points cut into eight contiguous ranges, one host thread per handle.
+    Bit-identical to the oracle on a sample; a NaN in the LAST range comes back as its global index
+    with everything in front of it written (multilinear/regular.rs:277-280)."""
+    import interpn_amd
+
+    n, nobs = 128, 8_000_000
+    case = synthetic_case("linear", "regular", 3, [n, n, n], nobs, 55, np.float64, specials=False)
+    first = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    hs = [first] + [first.replicate(0) for _ in range(7)]
+    try:
+        got = interpn_amd.eval_host_sharded(hs, case.obs, np.zeros(nobs))
+        rng = np.random.default_rng(7)
+        idx = np.unique(np.concatenate([rng.integers(0, nobs, 200_000), np.arange(nobs - 1000, nobs),
+                                        np.arange(nobs // 8 - 500, nobs // 8 + 500)]))
+        sub = [np.ascontiguousarray(o[idx]) for o in case.obs]
+        want = np.zeros(idx.size)
+        oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, sub, want)
+        assert np.array_equal(got[idx], want)
+        k = nobs - 12_345  # in the eighth range
+        case.obs[2][k] = np.nan
+        out = np.full(nobs, -7.0)
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            interpn_amd.eval_host_sharded(hs, case.obs, out)
+        assert ei.value.first_bad_index == k
+        assert np.array_equal(out[:k], got[:k])
+    finally:
+        for h in hs:
+            h.close()
+
+
+def test_eval_device_sharded(oracle):
+    """Device-resident single-process form (`interpn_hip_eval_device_sharded`): every shard's
+    coordinates and results live on its handle's device; all shards are enqueued before the first
+    is waited for.  Three clones on this box's one GPU, uneven shards (one of them empty-ish), 4-D
+    multicubic so that one shard is large enough to be sorted first: the oracle's bits; a failing
+    point in the last shard is reported with its index in shard order; a clean re-run afterwards."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    for method, kind, nd, axis in (("linear", "rectilinear", 3, [70, 9, 33]), ("cubic", "regular", 4, [6, 7, 5, 6])):
+        sizes = [600_000, 3, 150_001]
+        total = sum(sizes)
+        case = synthetic_case(method, kind, nd, axis, total, 77, np.float64, extrap=0.1, specials=False)
+        want = run_oracle(oracle, case, True)
+        first = _make_interp(interpn_amd, case)
+        hs = [first, first.replicate(0), first.replicate(0)]
+        try:
+            shards, lo = [], 0
+            for c in sizes:
+                shards.append([torch.from_numpy(np.ascontiguousarray(o[lo:lo + c])).to(dev) for o in case.obs])
+                lo += c
+            outs = interpn_amd.eval_device_sharded(hs, shards)
+            got = np.concatenate([o.cpu().numpy() for o in outs])
+            assert np.array_equal(got, want)
+            if kind == "regular":
+                shards[2][1][77] = float("nan")
+                shards[2][0][9_000] = float("inf")
+                with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                    interpn_amd.eval_device_sharded(hs, shards)
+                assert ei.value.first_bad_index == sizes[0] + sizes[1] + 77
+                shards[2][1][77] = float(case.obs[1][sizes[0] + sizes[1] + 77])
+                shards[2][0][9_000] = float(case.obs[0][sizes[0] + sizes[1] + 9_000])
+                outs = interpn_amd.eval_device_sharded(hs, shards, outs)
+                assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want)
+            with pytest.raises(ValueError):
+                interpn_amd.eval_device_sharded(hs[:2], shards)
+        finally:
+            for h in hs:
+                h.close()
 
 
 def test_eval_host_sharded_first_bad_index(oracle):
@@ -1002,6 +1078,35 @@ def test_handle_options_and_kernel_name(oracle):
         it.set_option("no_such_option", 1)
     with pytest.raises(ValueError):
         it.set_option("ppl", 7)
+    it.close()
+
+
+def test_thresholds_are_derived_from_the_device(oracle):
+    """The tuning thresholds (which table layout, when to sort, how much LDS the axes / the column
+    may take) are functions of the device's L2, LDS and CU count (interpn_host.h::Thresholds),
+    queried once per device.  On MI355X they evaluate to the constants the measurements behind
+    DESIGN.md were taken with."""
+    import torch
+
+    import interpn_amd
+
+    case = synthetic_case("linear", "regular", 3, [5, 6, 7], 100, 1234, np.float64)
+    it = _make_interp(interpn_amd, case)
+    props = torch.cuda.get_device_properties(0)
+    assert it.get_option("dev_num_cus") == props.multi_processor_count
+    l2, cus = it.get_option("dev_l2_bytes"), it.get_option("dev_num_cus")
+    lds_cu, lds_wg = it.get_option("dev_lds_per_cu"), it.get_option("dev_lds_per_wg")
+    assert it.get_option("thr_table_l2_sized") == l2 * 3 // 2 and it.get_option("thr_table_l2_share") == l2 * 3 // 4
+    assert it.get_option("thr_binned_table_min") == 2 * l2 and it.get_option("thr_binned_points_min") == 2048 * cus
+    assert it.get_option("thr_bin_table_share") == l2 // 8
+    assert it.get_option("thr_axis_lds") == lds_cu // 8 and it.get_option("thr_axis_lds_wide") == lds_wg - 4096
+    assert it.get_option("thr_column_lds") == lds_cu
+    if "MI355" in props.name or (cus == 256 and l2 == 4 << 20):
+        assert (l2, cus, lds_cu, lds_wg, it.get_option("dev_num_xcds")) == (4 << 20, 256, 160 << 10, 64 << 10, 8)
+        assert it.get_option("thr_table_l2_sized") == 6 << 20 and it.get_option("thr_table_l2_share") == 3 << 20
+        assert it.get_option("thr_binned_table_min") == 8 << 20 and it.get_option("thr_binned_points_min") == 1 << 19
+        assert it.get_option("thr_axis_lds") == 20 << 10 and it.get_option("thr_axis_lds_wide") == 60 << 10
+        assert it.get_option("thr_column_lds") == 160 << 10
     it.close()
 
 

@@ -52,6 +52,29 @@ def test_sharded_path_over_rccl_world_size_1():
     assert kinds["regular"]["first_bad_index"] == 200_003 - 1234
 
 
+def _drain_together(procs, timeout):
+    """communicate() with every child at once: rank 0 waits for rank 1 inside collectives, so
+    reading rank 1's pipes only after rank 0 has exited would block both once rank 1 has written
+    more than a pipe holds (RCCL / gloo warnings); the children are killed on timeout."""
+    import threading
+
+    outs = [None] * len(procs)
+
+    def drain(i):
+        try:
+            outs[i] = procs[i].communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            procs[i].kill()
+            outs[i] = procs[i].communicate()
+
+    threads = [threading.Thread(target=drain, args=(i,)) for i in range(len(procs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return outs
+
+
 @pytest.mark.gpu
 def test_sharded_path_two_ranks_on_one_gpu_over_gloo():
     """Two real ranks (two processes, two HIP contexts, real interpolator handles) sharing the test
@@ -65,7 +88,7 @@ def test_sharded_path_two_ranks_on_one_gpu_over_gloo():
                     "INTERPN_TEST_BACKEND": "gloo", "INTERPN_TEST_SAME_DEVICE": "1"})
         procs.append(subprocess.Popen([sys.executable, "-m", "tests.rccl_child"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = _drain_together(procs, 600)
     assert all(p.returncode == 0 for p in procs), [(o[0][-1000:], o[1][-3000:]) for o in outs]
     rec = _last_json(outs[0][0])
     assert rec["backend"] == "gloo" and rec["world"] == 2

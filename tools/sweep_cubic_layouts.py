@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep grid sizes x tile layouts for multicubic f64 (validates the layout model of
-interpn_abi.hip::maybe_build_cubic_tiles).  Run on the GPU box; one process, env re-read per handle."""
+abi_layout.hip::maybe_build_cubic_tiles).  Run on the GPU box; one process, env re-read per handle."""
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

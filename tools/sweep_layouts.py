@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep grid sizes x brick layouts for 3-D multilinear f64 (validates the layout heuristic of
-interpn_abi.hip::maybe_build_bricks).  Run on the GPU box."""
+abi_layout.hip::maybe_build_bricks).  Run on the GPU box."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''

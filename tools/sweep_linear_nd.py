@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep grid sizes x brick layouts for N-D multilinear f64, N = 3..5 (validates
-interpn_abi.hip::maybe_build_bricks beyond the 3-D sweep of tools/sweep_layouts.py)."""
+abi_layout.hip::maybe_build_bricks beyond the 3-D sweep of tools/sweep_layouts.py)."""
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
