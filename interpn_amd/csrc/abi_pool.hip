@@ -50,6 +50,12 @@ struct DevPool {
   std::vector<Kit> kits;
   std::vector<unsigned long long*> pinned_words;
   std::vector<void*> small_buffers;  // pinned, device-mapped staging of the small-batch path (kSmallBytes each)
+  // Blocks beyond the cap are not freed on the spot — hipFree waits for the WHOLE device, also for
+  // streams that have nothing to do with the handle being destroyed — but parked here and freed in
+  // one go by the next allocation that misses the pool once a quarter of the cap has collected
+  // (or when an allocation fails, or at the cap itself).
+  std::vector<void*> parked;
+  size_t parked_bytes = 0;
 };
 
 // Devices beyond the table are not pooled at all (plain hipMalloc / hipFree): two devices must never
@@ -86,6 +92,19 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
       return hipSuccess;
     }
   }
+  {
+    // an allocation that misses the pool is a heavyweight moment anyway (handle creation, scratch
+    // growth): the place to give back what destroy calls have parked (hipFree waits for the device)
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lk(pool.mu);
+      if (pool.parked_bytes > pool_cap_bytes() / 4) {
+        drop.swap(pool.parked);
+        pool.parked_bytes = 0;
+      }
+    }
+    for (void* b : drop) (void)hipFree(b);
+  }
   hipError_t e = hipMalloc(out, cls);
   if (e != hipSuccess) {
     // out of memory: drop everything cached and retry once
@@ -98,6 +117,9 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
         kv.second.clear();
       }
       pool.cached_bytes = 0;
+      for (void* b : pool.parked) drop.push_back(b);
+      pool.parked.clear();
+      pool.parked_bytes = 0;
     }
     for (void* b : drop) (void)hipFree(b);
     e = hipMalloc(out, cls);
@@ -113,21 +135,31 @@ void pool_free(int device, void* p) {
   if (!p) return;
   if (!pooled_device(device)) { (void)hipFree(p); return; }
   DevPool& pool = dev_pool(device);
-  size_t cls = 0;
+  std::vector<void*> drop;  // freed below, outside the lock
   {
     std::lock_guard<std::mutex> lk(pool.mu);
     auto it = pool.live.find(p);
-    if (it != pool.live.end()) {
-      cls = it->second;
+    if (it == pool.live.end()) {
+      drop.push_back(p);  // not ours: plain hipFree
+    } else {
+      const size_t cls = it->second;
       pool.live.erase(it);
       if (pool.cached_bytes + cls <= pool_cap_bytes()) {
         pool.free_blocks[cls].push_back(p);
         pool.cached_bytes += cls;
-        return;
+      } else if (pool_cap_bytes() == 0) {
+        drop.push_back(p);  // pooling switched off
+      } else {  // over the cap: park it; the parked blocks are freed together now and then
+        pool.parked.push_back(p);
+        pool.parked_bytes += cls;
+        if (pool.parked_bytes > pool_cap_bytes()) {  // hard limit; normally the next allocation that misses the pool frees them
+          drop.swap(pool.parked);
+          pool.parked_bytes = 0;
+        }
       }
     }
   }
-  (void)hipFree(p);
+  for (void* b : drop) (void)hipFree(b);
 }
 
 hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** flag_host) {
@@ -232,7 +264,10 @@ DeviceProps device_props(int device) {
   };
   p.num_cus = attr(hipDeviceAttributeMultiprocessorCount, 256);
   p.l2_bytes = attr(hipDeviceAttributeL2CacheSize, 4 << 20);
+  // what a launch gets without hipFuncSetAttribute: the runtime's 64 KiB rule, or less on a smaller part
+  // (the attribute reports the opt-in maximum: 160 KiB on MI355X)
   p.lds_per_wg = attr(hipDeviceAttributeMaxSharedMemoryPerBlock, 64 << 10);
+  if (p.lds_per_wg > (64 << 10)) p.lds_per_wg = 64 << 10;
   p.lds_per_cu = attr(hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, 160 << 10);
   if (p.lds_per_cu < p.lds_per_wg) p.lds_per_cu = p.lds_per_wg;
   // XCDs: gfx94x / gfx95x parts have 32 (MI300A: 38-CU XCDs, 228 CUs -> 6) CUs per L2 domain; the

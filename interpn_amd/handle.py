@@ -330,7 +330,7 @@ def eval_device_sharded(interps, obs_shards, out_shards=None):
         raise ValueError("eval_device_sharded needs one list of coordinate tensors per interpolator")
     lib = _lib.load()
     n = len(interps)
-    nd = interps[0].ndims
+    nd = interps[0].ndims()
     tdt = torch.float64 if interps[0].dtype == np.float64 else torch.float32
     outs = list(out_shards) if out_shards is not None else [None] * n
     hs = (c_void_p * n)()
