@@ -254,6 +254,7 @@ def config_row(torch, interpn_amd, name, spec, obs, out, device, seconds, check_
                                        "kernel on the sorted points; HIP events on the launch stream, median of 24 evaluations"}
         if spec["method"] == "cubic" and spec["ndims"] == 4:
             row["bound"] = cubic4_bound(row, P, st["kernel"], float(np.mean(ms0)), spec)
+    row["traffic"] = committed_config_traffic(row, spec)
     it.close()
     return row
 
@@ -437,15 +438,21 @@ def cpu_baseline(spec, obs_dev, sample_points):
     return rec, out, n
 
 
-def committed_traffic(kernel, points, grid, table_bytes):
-    """HBM/fabric bytes per launch from the committed rocprofv3 --pmc passes (separate runs, as the
-    guide prescribes) — reported only if that profile was taken on the SAME kernel instantiation,
-    table layout, grid and batch as this run; otherwise null."""
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def _traffic_profile():
     try:
-        with open(tpath) as f:
-            tj = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            return json.load(f)
     except Exception:
+        return None
+
+
+def committed_traffic(kernel, points, grid, table_bytes):
+    """HBM/fabric bytes per launch of the headline kernel from the committed rocprofv3 --pmc passes
+    (separate runs, as the guide prescribes) — reported only if that profile was taken on the SAME
+    kernel instantiation, table layout, grid and batch as this run; otherwise null.  Never measured
+    inside this run: PMC collection needs its own rocprofv3 passes."""
+    tj = _traffic_profile()
+    if tj is None:
         return None, "no committed traffic profile"
     same = (tj.get("points") == points and tj.get("grid") == grid and tj.get("kernel") == kernel and
             tj.get("table_bytes") == table_bytes)
@@ -453,6 +460,59 @@ def committed_traffic(kernel, points, grid, table_bytes):
         return None, (f"committed profile is for kernel={tj.get('kernel')!r} grid={tj.get('grid')} "
                       f"table_bytes={tj.get('table_bytes')}: does not match this run, not reported")
     return tj.get("hbm_bytes_per_launch"), tj.get("source", "profiles/traffic_latest.json")
+
+
+def committed_config_traffic(row, spec):
+    """The same for a row of `configs[]`: fabric-side bytes per evaluation (all of its kernels) and
+    their ratio to the algorithmic bytes, the TCC hit / miss counts of the evaluation kernel — from the
+    committed per-configuration --pmc passes (tools/profile_r04.sh), if kernel, table and batch match."""
+    tj = _traffic_profile()
+    if not tj or "configs" not in tj:
+        return {"fabric_bytes_per_evaluation": None, "measured_in_this_run": False, "source": "no committed per-configuration profile"}
+    n = spec["dims"][0]
+    for key, e in tj["configs"].items():
+        if e.get("kernel") == row["kernel"] and e.get("points") == row["points"] and e.get("grid") == n and \
+                e.get("ndims") == spec["ndims"] and abs(e.get("table_bytes", 0) - row["table_MiB"] * 2**20) < 2**16:
+            main = {}
+            for k, d in e.get("kernels", {}).items():
+                if row["kernel"].split("::")[-1].split("<")[0] == k:
+                    main = {c: d[c] for c in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum",
+                                              "TCC_EA0_WRREQ_64B_sum") if c in d}
+            return {"fabric_bytes_per_evaluation": e["fabric_bytes_per_evaluation"],
+                    "fabric_read_bytes": e["fabric_read_bytes_per_evaluation"], "fabric_write_bytes": e["fabric_write_bytes_per_evaluation"],
+                    "algorithmic_bytes": e["algorithmic_bytes"], "ratio_to_algorithmic": e["ratio_to_algorithmic"],
+                    "evaluation_kernel_tcc": main, "measured_in_this_run": False,
+                    "source": f"profiles/traffic_latest.json [{key}]: separate rocprofv3 --pmc passes (FETCH_SIZE x {tj.get('fetch_correction', 2.0):.3f}, "
+                              f"WRITE_SIZE x {tj.get('write_correction', 1.0):.3f}), same kernel instantiation, table and batch as this row"}
+    return {"fabric_bytes_per_evaluation": None, "measured_in_this_run": False,
+            "source": "committed per-configuration profile has no entry for this kernel / table / batch"}
+
+
+def host_path_block(interpn_amd, device, points=10_000_000):
+    """End to end on HOST arrays (numpy in, numpy out: upload, kernel, download) for cfg2's shapes at
+    1e7 points — SURVEY.md section 8(d) "GPU timing" asks for it as a separate line; PCIe-bound by
+    construction and never the `value`."""
+    rng = np.random.default_rng(11)
+    n = 64
+    spec = build_spec("linear", "regular", n, 3, False, 1)
+    obs = [rng.uniform(-1.0, 1.0, points) for _ in range(3)]
+    out = np.zeros(points)
+    it = make_interp(interpn_amd, spec, device)
+    it.eval_host(obs, out)  # warm-up: lanes allocated, pages touched
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        it.eval_host(obs, out)
+        best = min(best, time.perf_counter() - t0)
+    it.close()
+    t0 = time.perf_counter()
+    interpn_amd.raw.interpn_linear_regular_f64(spec["dims"], spec["starts"], spec["steps"], spec["vals"], obs, out)
+    oneshot = time.perf_counter() - t0
+    return {"workload": f"3D multilinear::regular {n}^3 f64, {points:.0e} points, numpy arrays in pageable host memory -> numpy array",
+            "resident_handle_Gpoints_per_s": round(points / best / 1e9, 3), "resident_handle_GBps_over_pcie": round(points * 32 / best / 1e9, 1),
+            "one_shot_raw_call_Gpoints_per_s": round(points / oneshot / 1e9, 3),
+            "note": "upload of 24 B/point + download of 8 B/point over one PCIe link, chunked double-lane pipeline "
+                    "(abi_host.hip); bound by the link, not by the kernel"}
 
 
 def run_ablation(torch, spec, obs, out, it, seconds):
@@ -759,6 +819,7 @@ def worker(args):
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_measured_in_this_run": False,
                 "kernel": kernel,
                 "table_bytes": tbytes,
                 "table_MiB": round(tbytes / 2**20, 2),
@@ -791,6 +852,11 @@ def worker(args):
             if not args.no_ablate:
                 try:
                     rec["roofline"]["ablation"] = run_ablation(torch, spec, obs, out, it, 0.25)
+                    so = rec["roofline"]["ablation"].get("stream_only_ms")
+                    if so:
+                        # the part's achievable rate for this 3-read / 1-write stream pattern (no table access)
+                        rec["roofline"]["stream_only_GBps"] = round(P * bpp / (so * 1e-3) / 1e9, 1)
+                        rec["roofline"]["frac_of_stream_only"] = round(so / sk, 4)
                 except Exception as e:  # a measurement aid must never take the record down
                     rec["roofline"]["ablation"] = {"error": repr(e)}
             # restore `out` (the ablation kernels scribble on it) before it is compared below
@@ -821,6 +887,10 @@ def worker(args):
                 except Exception as e:
                     rows.append({"error": repr(e)})
                 rec["configs"] = rows
+                try:
+                    rec["host_path"] = host_path_block(interpn_amd, local_rank)
+                except Exception as e:
+                    rec["host_path"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
 
     it.close()

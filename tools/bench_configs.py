@@ -54,8 +54,10 @@ def run(name, method, kind, n_axis, ndims, P, linearize=False, dtype=np.float64,
     ms.sort()
     med = ms[len(ms) // 2]
     bpp = np.dtype(dtype).itemsize * (ndims + 1)
+    tbytes, si, sj = it.table_layout()
     rec = {"config": name, "ms": round(med, 3), "Mpts/s": round(P / med / 1e3, 1), "GB/s": round(P * bpp / med / 1e6, 1),
-           "frac_of_8TB/s": round(P * bpp / med / 1e6 / 8000, 4)}
+           "frac_of_8TB/s": round(P * bpp / med / 1e6 / 8000, 4), "kernel": it.kernel_name(), "table_bytes": tbytes,
+           "points": P, "grid": n_axis, "ndims": ndims, "algorithmic_bytes": P * bpp}
     print(json.dumps(rec), flush=True)
     it.close()
     del obs, out
