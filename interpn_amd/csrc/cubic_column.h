@@ -74,6 +74,11 @@ struct CubicColumnArgs {
   unsigned sub_bytes;        // LDS bytes of a group's sub-column; its local order (16-bit) sits behind them
   unsigned group_bytes;      // dynamic LDS bytes per group (sub-column + local order, 16-byte multiple)
   unsigned long long* stamps;  // measurement aid (option debug_stamps): 8 words per part, or null
+  // Rectilinear grids (RECT kernels): the handle's axis image (coordinates + bucket tables of all
+  // four axes), staged once per workgroup behind the groups' regions at byte `axes_lds_off` of the
+  // dynamic LDS.  Classes are then exact (partition_point), not estimates.
+  AxisArgs<T, 4> ax;
+  unsigned axes_lds_off;
 };
 
 constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
@@ -273,6 +278,63 @@ __device__ __forceinline__ unsigned col_class_hint(T x, T start, T rstep, int n)
   return u >= (T)1 ? (u < (T)(n - 2) ? (unsigned)(int)u : (unsigned)(n - 2)) : 0u;
 }
 
+// ---- rectilinear grids --------------------------------------------------------------------------
+// Class of a coordinate along a rectilinear axis, from the reference's cell search
+// (multicubic/rectilinear.rs:377: iloc = partition_point(g < x) - 2): 0 = saturated low (iloc <= -1,
+// inside or outside), c = iloc + 1 for interior cells, n - 2 = saturated high (iloc >= n - 3) — the
+// same numbering as on regular grids, footprint cell = clamp(class - 1, 0, n - 4); exact, since it
+// is the search the kernel itself uses.
+template <typename T>
+__device__ __forceinline__ unsigned col_rect_class(const Axis<T>& ax, T x) {
+  int iloc = axis_partition_point<T>(ax, x) - 2;
+  iloc = iloc < -1 ? -1 : (iloc > ax.n - 3 ? ax.n - 3 : iloc);
+  return (unsigned)(iloc + 1);
+}
+
+// All 16 planes of a point on a rectilinear grid out of the LDS sub-column: the reference's tree
+// (multicubic/rectilinear.rs:290-356) with its node (rectilinear.rs:413-545; two IEEE divisions by
+// the spacing ratios per node, which is what this kernel spends its time on: no tile prefetch).
+template <typename T, bool FMA>
+__device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, const CubicDimRect<T>* dim) {
+  constexpr unsigned PITCH = col_pitch<T>();
+  T s3[4];
+  unsigned ak = a0;
+#pragma unroll 1
+  for (int k3 = 0; k3 < 4; ++k3) {
+    T s2[4];
+#pragma unroll 1
+    for (int k2 = 0; k2 < 4; ++k2) {
+      T v[16];
+      col_take_tile<T>(ak + (unsigned)k2 * rowpitch, v);
+      s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
+    }
+    ak += PITCH;
+    s3[k3] = cubic_rect_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+  }
+  return cubic_rect_node<FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
+// One rectilinear point from the table in global memory (a point that is not in this part's cell or rows).
+template <typename T, bool FMA>
+__device__ __noinline__ T col_slow_point_rect(__amdgpu_buffer_rsrc_t rsrc, unsigned tile_off_bytes, unsigned ps2_bytes, unsigned ps3_bytes,
+                                              const CubicDimRect<T>* dim) {
+  T s3[4];
+#pragma unroll 1
+  for (int k3 = 0; k3 < 4; ++k3) {
+    T s2[4];
+#pragma unroll 1
+    for (int k2 = 0; k2 < 4; ++k2) {
+      T v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        v[e] = table_load<T>(rsrc, tile_off_bytes + (unsigned)k2 * ps2_bytes + (unsigned)k3 * ps3_bytes + (unsigned)e * (unsigned)sizeof(T), 0u);
+      s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
+    }
+    s3[k3] = cubic_rect_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+  }
+  return cubic_rect_node<FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
 // Barrier of one wave group (GW waves) of a persistent workgroup: an LDS counter that only ever
 // grows; `epoch` (wave-uniform register) is the count that completes the next barrier.  LDS
 // instructions of a wave execute in order and the LDS serialises the waves' accesses, so what a
@@ -295,7 +357,8 @@ __device__ __forceinline__ void col_group_barrier(unsigned* ctr, unsigned& epoch
 // Registers: 12 waves per CU = three per SIMD (168 VGPRs).  GROUPS wave groups of THREADS / GROUPS
 // threads each; GROUPS == 1: the whole workgroup is one group and synchronises with s_barrier.
 // STAMPS: the measurement build (option debug_stamps) — time stamps cost registers the product kernel needs.
-template <typename T, bool FMA, int THREADS, int GROUPS, bool STAMPS = false>
+// RECT: rectilinear grid (exact classes from the axis search, the reference's rectilinear node).
+template <typename T, bool RECT, bool FMA, int THREADS, int GROUPS, bool STAMPS = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_cubic_column(const CubicColumnArgs<T> a) {
   static_assert(THREADS % (64 * GROUPS) == 0, "whole waves per group");
@@ -316,6 +379,13 @@ k_cubic_column(const CubicColumnArgs<T> a) {
   unsigned* const s_wave = s_wave_all[grp];
   unsigned* const s_ctl = s_ctl_all[grp];
   if (tid - grp * (unsigned)GT < 8) s_ctl[tid - grp * (unsigned)GT] = 0;
+  const unsigned char* const axis_base = smem_col + a.axes_lds_off;  // RECT: the axes in LDS
+  if constexpr (RECT) {
+    const unsigned words = a.ax.image_bytes >> 2;
+    const unsigned* src = reinterpret_cast<const unsigned*>(a.ax.image);
+    unsigned* dst = reinterpret_cast<unsigned*>(smem_col + a.axes_lds_off);
+    for (unsigned k = tid; k < words; k += THREADS) dst[k] = src[k];
+  }
   __syncthreads();  // the only s_barrier of the workgroup
   unsigned epoch = 0;
   const unsigned total_parts = (unsigned)__builtin_amdgcn_readfirstlane((int)a.part_prefix[a.nbins]);
@@ -440,8 +510,14 @@ k_cubic_column(const CubicColumnArgs<T> a) {
 #pragma unroll
         for (int m = 0; m < HB; ++m) {
           const unsigned q = (unsigned)(h * HB + m) * (unsigned)GT + gtid;
-          const unsigned h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
-          const unsigned h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
+          unsigned h2, h3;
+          if constexpr (RECT) {
+            h2 = col_rect_class<T>(make_axis<T, 4>(a.ax, axis_base, 2), x2[m]);
+            h3 = col_rect_class<T>(make_axis<T, 4>(a.ax, axis_base, 3), x3[m]);
+          } else {
+            h2 = col_class_hint<T>(x2[m], a.start[2], a.rstep[2], a.n[2]);
+            h3 = col_class_hint<T>(x3[m], a.start[3], a.rstep[3], a.n[3]);
+          }
           const unsigned c = h2 * (unsigned)a.q3 + (h3 >> a.sh3);  // < (n2 - 1) q3 <= 1024
           const int mm = h * HB + m;
           if (mm & 1) cls23[mm / 2] |= c << 16;
@@ -529,62 +605,82 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           q = perm[jn + wl < pe ? jn + wl : pe - 1];
           rec = recs[q];
         }
-        ColDim<T> dim[4];
-        int loc[4];
-        bool ok = true;
-        unsigned cls = 0;    // per lane: bit 3d low, 3d + 1 high, 3d + 2 linearised (the general forms' input)
-        unsigned forms = 0;  // per wave: the form of dim d in bits 2d, 2d + 1
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const T x = rcur[d];
-          const T floc = dev_floor<T>((x - a.start[d]) / a.step[d]);        // multicubic/regular.rs:435-438
-          // num-traits <isize as NumCast>::from: Some iff -2^63 <= floc < 2^63, and `floc - 1` must not
-          // overflow isize (floc != -2^63): together |floc| < 2^63 (NaN fails)
-          ok &= dev_fabs<T>(floc) < (T)9223372036854775808.0;
-          const T nn2 = (T)(a.n[d] - 2);
-          // regular.rs:440-442: iloc = floc - 1 clamped to [0, n - 4], in the float domain (exact
-          // integers below 2^31; +-inf clamp; NaN -> 0: that point has failed anyway)
-          T c = floc - (T)1;
-          c = dev_fmax<T>(c, (T)0);
-          c = dev_fmin<T>(c, (T)(a.n[d] - 4));
-          const int l = (int)c;
-          // regular.rs:445-466 on floc = iloc + 1
-          const bool low = floc <= (T)0, high = floc >= nn2;
-          const bool lin = (floc < (T)0 || floc > nn2) && a.linearize != 0;
-          const T index_one_loc = mul_add<false>(a.step[d], c + (T)1, a.start[d]);  // regular.rs:356-360, never fused; (T)(l + 1) == c + 1
-          const T t = (x - index_one_loc) / a.step[d];
-          dim[d].low = low;
-          dim[d].high = high;
-          dim[d].lin = lin;
-          dim[d].tt = low ? -t : (high ? t - (T)1 : t);
-          loc[d] = l;
-          const int f = col_wave_form<T>(dim[d]);  // wave-uniform
-          forms |= (unsigned)f << (2 * d);
-          if (f != kFormNone) cls |= ((low ? 1u : 0u) | (high ? 2u : 0u) | (lin ? 4u : 0u)) << (3 * d);
-        }
-        // footprint rows relative to the sub-column; a point whose exact rows are not all in it is
-        // evaluated from the table below (its LDS reads stay inside the sub-column, result dropped)
-        const int rel2 = loc[2] - (int)row0;
-        const bool in_rows = rel2 >= 0 && rel2 <= row_top;
-        const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
         T res;
-        if (forms == 0) {
-          res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, 0, 0);
-        } else {
-          res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
-        }
-        // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
-        if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
-          const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
-                                 (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
-          CubicDimRegular<T> dcopy[4];
+        bool ok = true;
+        if constexpr (RECT) {
+          CubicDimRect<T> dim[4];
+          int loc[4];
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {  // from the packed classes (all zero where the wave's form is None: sat None, not linearised)
-            dcopy[d].tt = dim[d].tt;
-            dcopy[d].sat = ((cls >> (3 * d)) & 1u) ? kSatLow : (((cls >> (3 * d + 1)) & 1u) ? kSatHigh : kSatNone);
-            dcopy[d].linear = (int)((cls >> (3 * d + 2)) & 1u);
+          for (int d = 0; d < 4; ++d)  // multicubic/rectilinear.rs:366-408 (never fails: NaN takes cell 0 and propagates)
+            loc[d] = cubic_rect_locate<T>(make_axis<T, 4>(a.ax, axis_base, d), rcur[d], a.linearize, /*fma_linear=*/false, dim[d]);
+          const int rel2 = loc[2] - (int)row0;
+          const bool in_rows = rel2 >= 0 && rel2 <= row_top;
+          const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
+          res = col_reduce_rect<T, FMA>(a0, rowpitch, dim);
+          if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {  // only deliberately mis-binned points (bin_scramble): classes are exact here
+            const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
+                                   (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
+            CubicDimRect<T> dcopy[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dcopy[d] = dim[d];
+            res = col_slow_point_rect<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
           }
-          res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
+        } else {
+          ColDim<T> dim[4];
+          int loc[4];
+          unsigned cls = 0;    // per lane: bit 3d low, 3d + 1 high, 3d + 2 linearised (the general forms' input)
+          unsigned forms = 0;  // per wave: the form of dim d in bits 2d, 2d + 1
+  #pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const T x = rcur[d];
+            const T floc = dev_floor<T>((x - a.start[d]) / a.step[d]);        // multicubic/regular.rs:435-438
+            // num-traits <isize as NumCast>::from: Some iff -2^63 <= floc < 2^63, and `floc - 1` must not
+            // overflow isize (floc != -2^63): together |floc| < 2^63 (NaN fails)
+            ok &= dev_fabs<T>(floc) < (T)9223372036854775808.0;
+            const T nn2 = (T)(a.n[d] - 2);
+            // regular.rs:440-442: iloc = floc - 1 clamped to [0, n - 4], in the float domain (exact
+            // integers below 2^31; +-inf clamp; NaN -> 0: that point has failed anyway)
+            T c = floc - (T)1;
+            c = dev_fmax<T>(c, (T)0);
+            c = dev_fmin<T>(c, (T)(a.n[d] - 4));
+            const int l = (int)c;
+            // regular.rs:445-466 on floc = iloc + 1
+            const bool low = floc <= (T)0, high = floc >= nn2;
+            const bool lin = (floc < (T)0 || floc > nn2) && a.linearize != 0;
+            const T index_one_loc = mul_add<false>(a.step[d], c + (T)1, a.start[d]);  // regular.rs:356-360, never fused; (T)(l + 1) == c + 1
+            const T t = (x - index_one_loc) / a.step[d];
+            dim[d].low = low;
+            dim[d].high = high;
+            dim[d].lin = lin;
+            dim[d].tt = low ? -t : (high ? t - (T)1 : t);
+            loc[d] = l;
+            const int f = col_wave_form<T>(dim[d]);  // wave-uniform
+            forms |= (unsigned)f << (2 * d);
+            if (f != kFormNone) cls |= ((low ? 1u : 0u) | (high ? 2u : 0u) | (lin ? 4u : 0u)) << (3 * d);
+          }
+          // footprint rows relative to the sub-column; a point whose exact rows are not all in it is
+          // evaluated from the table below (its LDS reads stay inside the sub-column, result dropped)
+          const int rel2 = loc[2] - (int)row0;
+          const bool in_rows = rel2 >= 0 && rel2 <= row_top;
+          const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
+          if (forms == 0) {
+            res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, 0, 0);
+          } else {
+            res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
+          }
+          // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
+          if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
+            const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
+                                   (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
+            CubicDimRegular<T> dcopy[4];
+  #pragma unroll
+            for (int d = 0; d < 4; ++d) {  // from the packed classes (all zero where the wave's form is None: sat None, not linearised)
+              dcopy[d].tt = dim[d].tt;
+              dcopy[d].sat = ((cls >> (3 * d)) & 1u) ? kSatLow : (((cls >> (3 * d + 1)) & 1u) ? kSatHigh : kSatNone);
+              dcopy[d].linear = (int)((cls >> (3 * d + 2)) & 1u);
+            }
+            res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
+          }
         }
         if (live) {
           if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));

@@ -256,6 +256,13 @@ struct BinPlan {
   int classes = 0;
   int ncell[2] = {0, 0};   // footprint origins per dim: n - 3
   int shift[2] = {0, 0};   // bin = cell >> shift
+  // classes on a RECTILINEAR grid are exact: the sort searches dims 0, 1 like the kernels do
+  // (interpn_device.h::axis_partition_point on the handle's coordinates + bucket tables)
+  int rect = 0;
+  const void* axis_g[2] = {nullptr, nullptr};
+  const unsigned* axis_tab[2] = {nullptr, nullptr};
+  int axis_n[2] = {0, 0}, axis_M[2] = {0, 0};
+  double axis_g0[2] = {0, 0}, axis_scale[2] = {0, 0};
   double start[2] = {0, 0};
   double scale[2] = {0, 0};  // cell ~ floor((x - start) * scale) - 1
 };
@@ -296,6 +303,7 @@ struct ColumnPlan {
   int q3 = 0, sh3 = 0;       // local sort key = class2 * q3 + (class3 >> sh3)
   unsigned sub_bytes = 0;    // LDS bytes of a phase's sub-column
   unsigned group_bytes = 0;  // dynamic LDS of a group: sub-column + local order
+  size_t axes_bytes = 0;     // rectilinear: the axis image behind the groups' regions
   size_t lds_bytes = 0;      // dynamic LDS of a workgroup
 };
 bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan);

@@ -32,6 +32,12 @@ struct BinParams {
   int mult;
   int classes;  // 1: bins are saturation classes (BinPlan::classes), 0: footprint cells >> shift
   int scramble; // testing: every 5th point is put into the NEXT bin (the key is only a locality hint: results must not change)
+  // rectilinear classes (BinPlan::rect): axes 0, 1 as the kernels search them
+  int rect;
+  const void* axis_g[2];
+  const unsigned* axis_tab[2];
+  int axis_n[2], axis_M[2];
+  double axis_g0[2], axis_scale[2];
 };
 
 // ~ footprint origin: clamp(floor((x - start) / step) - 1, 0, n - 4); NaN -> 0.  A locality hint
@@ -50,10 +56,28 @@ __device__ __forceinline__ int bin_class(double x, double start, double scale, i
   return u >= 1.0 ? (u < (double)(nclass - 1) ? (int)u : nclass - 1) : 0;
 }
 
+// exact class on a rectilinear axis (cubic_column.h::col_rect_class)
+template <typename T>
+__device__ __forceinline__ int bin_rect_class(const BinParams& p, int d, T x) {
+  Axis<T> ax;
+  ax.g = static_cast<const T*>(p.axis_g[d]);
+  ax.tab = p.axis_tab[d];
+  ax.n = p.axis_n[d];
+  ax.M = p.axis_M[d];
+  ax.g0 = (T)p.axis_g0[d];
+  ax.scale = (T)p.axis_scale[d];
+  int iloc = axis_partition_point<T>(ax, x) - 2;
+  iloc = iloc < -1 ? -1 : (iloc > ax.n - 3 ? ax.n - 3 : iloc);
+  return iloc + 1;
+}
+
 template <typename T>
 __device__ __forceinline__ int bin_key(const BinParams& p, T x0, T x1) {
   int c0, c1;
-  if (p.classes) {
+  if (p.rect) {
+    c0 = bin_rect_class<T>(p, 0, x0);
+    c1 = bin_rect_class<T>(p, 1, x1);
+  } else if (p.classes) {
     c0 = bin_class((double)x0, p.start[0], p.scale[0], p.ncell[0]);
     c1 = bin_class((double)x1, p.start[1], p.scale[1], p.ncell[1]);
   } else {
@@ -388,7 +412,18 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool cl
   if (g.method != kCubic || g.ndims < 2) return false;
   BinPlan p;
   p.classes = classes ? 1 : 0;
-  if (classes && g.kind != kRegular) return false;
+  if (classes && g.kind != kRegular) {  // rectilinear classes: searched exactly, on axes with a bucket table
+    if (g.axis_buckets[0] <= 0 || g.axis_buckets[1] <= 0 || !g.axis_image) return false;
+    p.rect = 1;
+    for (int d = 0; d < 2; ++d) {
+      p.axis_g[d] = g.grid[d];
+      p.axis_tab[d] = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(g.axis_image) + g.axis_tab_off[d]);
+      p.axis_n[d] = g.n[d];
+      p.axis_M[d] = g.axis_buckets[d];
+      p.axis_g0[d] = g.axis_g0[d];
+      p.axis_scale[d] = g.axis_scale[d];
+    }
+  }
   for (int d = 0; d < 2; ++d) {
     p.ncell[d] = classes ? g.n[d] - 1 : g.n[d] - 3;
     if (p.ncell[d] < 1) return false;
@@ -456,6 +491,15 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.mult = plan.mult;
   p.classes = plan.classes;
   p.scramble = g.cfg.bin_scramble;
+  p.rect = plan.rect;
+  for (int d = 0; d < 2; ++d) {
+    p.axis_g[d] = plan.axis_g[d];
+    p.axis_tab[d] = plan.axis_tab[d];
+    p.axis_n[d] = plan.axis_n[d];
+    p.axis_M[d] = plan.axis_M[d];
+    p.axis_g0[d] = plan.axis_g0[d];
+    p.axis_scale[d] = plan.axis_scale[d];
+  }
 #define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean)
   if (g.dtype == kF64) {
     switch (g.ndims) {

@@ -48,11 +48,17 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   const int t = g.cfg.column_threads;
   p.threads = t <= 256 ? 256 : (t <= 384 ? 384 : 768);
   p.groups = p.threads == 384 ? 1 : (p.threads == 256 ? 2 : (g.cfg.column_groups == 1 ? 1 : 2));
+  if (g.kind == kRectilinear) {  // compiled for the product shape and the small test shape only
+    if (p.threads != 256) { p.threads = 768; p.groups = 1; }
+  }
   const size_t elem = g.dtype == kF64 ? 8 : 4;
   const size_t pitch = 16 * elem + 16;
   const size_t cu_lds = thresholds(g.cfg).column_lds;  // the LDS of a CU: 160 KiB on MI355X
   if (cu_lds < (size_t)p.groups * (kColumnStaticPerGroup + 8192)) return false;
-  const size_t per_group = ((cu_lds - (size_t)p.groups * kColumnStaticPerGroup) / (size_t)p.groups) / 1024 * 1024;
+  // rectilinear: the axis image (coordinates + tables of the four axes) sits behind the groups' regions
+  p.axes_bytes = g.kind == kRectilinear ? ((size_t)g.axis_image_bytes + 15) / 16 * 16 : 0;
+  if (cu_lds < (size_t)p.groups * (kColumnStaticPerGroup + 8192) + p.axes_bytes) return false;
+  const size_t per_group = ((cu_lds - p.axes_bytes - (size_t)p.groups * kColumnStaticPerGroup) / (size_t)p.groups) / 1024 * 1024;
   const int n2 = g.n[2], n3 = g.n[3];
   auto sub_bytes = [&](int rows) { return ((size_t)rows * (size_t)n3 * pitch + 1023) / 1024 * 1024; };
   const int ncls2 = n2 - 1;
@@ -92,13 +98,18 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   p.q3 = q3_of(p.sh3);
   if ((long long)ncls2 * p.q3 > kColKeys) return false;
   p.group_bytes = p.sub_bytes + (unsigned)((2 * (size_t)part + 15) / 16 * 16);
-  p.lds_bytes = (size_t)p.group_bytes * (size_t)p.groups;
+  p.lds_bytes = (size_t)p.group_bytes * (size_t)p.groups + p.axes_bytes;
   *plan = p;
   return true;
 }
 
 bool cubic_column_applies(const GridDesc& g) {
-  if (g.method != kCubic || g.kind != kRegular || g.ndims != 4 || !g.bricks) return false;
+  if (g.method != kCubic || g.ndims != 4 || !g.bricks) return false;
+  if (g.kind == kRectilinear) {  // exact classes need every axis' bucket table (strictly increasing, finite axes)
+    for (int d = 0; d < 4; ++d)
+      if (g.axis_buckets[d] <= 0) return false;
+    if (!g.axis_image || g.axis_image_bytes > 32 * 1024) return false;
+  }
   // the fully overlapped tile table is what the column is filled from
   const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
   if (!main11 && !g.bricks11) return false;
@@ -152,6 +163,17 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.sub_bytes = cp.sub_bytes;
   a.group_bytes = cp.group_bytes;
   a.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)g.cfg.debug_stamps);
+  a.ax.use_lds = 0;
+  a.ax.use_rec = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  a.axes_lds_off = (unsigned)((size_t)cp.group_bytes * (size_t)cp.groups);
+  if (g.kind == kRectilinear) {
+    fill_axis_args<T, 4>(g, a.ax);  // offsets, lengths, bucket tables; the kernel stages the image itself
+    a.ax.use_rec = 0;
+    a.ax.image = static_cast<const unsigned char*>(g.axis_image);
+    a.ax.image_bytes = g.axis_image_bytes;
+  }
   const size_t lds = cp.lds_bytes;
   // persistent: one workgroup per CU (its LDS leaves room for no second one), fewer when there are fewer parts
   size_t wgs = (max_parts + (size_t)cp.groups - 1) / (size_t)cp.groups;
@@ -162,26 +184,32 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
     return column_lds_opt_in(reinterpret_cast<const void*>(kernel), cp.groups, thresholds(g.cfg).column_lds);
   };
   hipError_t e = hipSuccess;
+#define GO_R(RECT, FMA, TH, GR)                                                                                  \
+  do {                                                                                                           \
+    e = prepare(k_cubic_column<T, RECT, FMA, TH, GR>);                                                           \
+    if (e != hipSuccess) return e;                                                                               \
+    g.tag.set("k_cubic_column", {RECT, FMA, TH, GR, 0}, 0b10011u);                                               \
+    hipLaunchKernelGGL((k_cubic_column<T, RECT, FMA, TH, GR>), dim3((unsigned)wgs), dim3(TH), lds, stream, a);   \
+  } while (0)
+  // rectilinear grids: the product shape and the small test shape
 #define GO(FMA, TH, GR)                                                                                          \
   do {                                                                                                           \
-    e = prepare(k_cubic_column<T, FMA, TH, GR>);                                                                 \
-    if (e != hipSuccess) return e;                                                                               \
-    g.tag.set("k_cubic_column", {FMA, TH, GR, 0}, 0b1001u);                                                          \
-    hipLaunchKernelGGL((k_cubic_column<T, FMA, TH, GR>), dim3((unsigned)wgs), dim3(TH), lds, stream, a);         \
+    if (g.kind == kRectilinear) { if (TH == 256) GO_R(true, FMA, 256, 2); else GO_R(true, FMA, 768, 1); }        \
+    else GO_R(false, FMA, TH, GR);                                                                               \
   } while (0)
   // the measurement build (time stamps): the product shapes in f64 only
-  if (a.stamps && sizeof(T) == 8 && g.fma && cp.threads == 768) {
+  if (a.stamps && sizeof(T) == 8 && g.fma && cp.threads == 768 && g.kind == kRegular) {
     if constexpr (sizeof(T) == 8) {
       if (cp.groups == 1) {
-        e = prepare(k_cubic_column<T, true, 768, 1, true>);
+        e = prepare(k_cubic_column<T, false, true, 768, 1, true>);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_cubic_column<T, true, 768, 1, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
+        hipLaunchKernelGGL((k_cubic_column<T, false, true, 768, 1, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
       } else {
-        e = prepare(k_cubic_column<T, true, 768, 2, true>);
+        e = prepare(k_cubic_column<T, false, true, 768, 2, true>);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_cubic_column<T, true, 768, 2, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
+        hipLaunchKernelGGL((k_cubic_column<T, false, true, 768, 2, true>), dim3((unsigned)wgs), dim3(768), lds, stream, a);
       }
-      g.tag.set("k_cubic_column", {1, 768, cp.groups, 1}, 0b1001u);
+      g.tag.set("k_cubic_column", {0, 1, 768, cp.groups, 1}, 0b10011u);
       return hipGetLastError();
     }
   }
@@ -193,6 +221,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   if (g.fma) GO_T(true); else GO_T(false);
 #undef GO_T
 #undef GO
+#undef GO_R
   return hipGetLastError();
 }
 

@@ -1776,8 +1776,9 @@ def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monke
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
 @pytest.mark.parametrize("axis", [[6, 7, 5, 6], [4, 4, 4, 4], [9, 5, 12, 7], [33, 32, 6, 5], [41, 40, 5, 6]], ids=str)
-def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, axis):
+def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, axis, kind):
     """Column evaluation (cubic_column.h): large 4-D multicubic batches on a regular grid are sorted
     by the saturation-class pair of dims 0, 1 and a workgroup evaluates its bin's points out of an
     LDS-resident column of table tiles (cfg4's form).  Forced here at small sizes: batches from one
@@ -1790,7 +1791,10 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     part, some of them empty), and — `bin_scramble` — every fifth point deliberately sorted into
     the wrong bin, so that the kernel's out-of-cell path (the same tree from the table in global
     memory) is exercised: always the oracle's bits.  [41, 40, 5, 6]: 1560 class-pair bins (more than
-    one per thread of the sort's kernels).  src/multicubic/regular.rs:325-623."""
+    one per thread of the sort's kernels).  Rectilinear grids (round 4): the sort and the kernel
+    classify with the reference's own cell search, so no point is ever mis-binned by itself — the
+    scramble option still forces the out-of-cell path; NaN / inf coordinates never fail there and
+    propagate.  src/multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
     import torch
 
     import interpn_amd
@@ -1802,7 +1806,7 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
                                                (40_001, 768, 1, 1, 0), (250_013, 384, 0, 0, 1), (250_013, 768, 0, 0, 0),
                                                (250_014, 768, 3000, 1, 2)):
         lin = bool((nobs + threads) % 2)
-        case = synthetic_case("cubic", "regular", 4, axis, nobs, 9900 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
+        case = synthetic_case("cubic", kind, 4, axis, nobs, 9900 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
                               specials=min(axis) >= 8)
         want = run_oracle(oracle, case, True)
         it = _make_interp(interpn_amd, case)
@@ -1816,9 +1820,22 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
         it.finish()
         assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_column<"), it.kernel_name()
         got = out.cpu().numpy()
-        assert np.array_equal(got, want), (nobs, threads, part, scramble, cpp, int((got != want).sum()))
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert np.all(same), (nobs, threads, part, scramble, cpp, int((~same).sum()))
         assert float(out_full[0]) == -5.0 and float(out_full[-1]) == -5.0  # nothing outside the batch was written
-        if nobs > 1000:
+        if kind == "rectilinear" and nobs > 1000:
+            # rectilinear grids never fail per point: NaN / inf go through the search (cell 0 / last) and propagate
+            odd = [o.clone() for o in obs]
+            odd[2][nobs // 2] = float("nan")
+            odd[0][nobs // 3] = float("inf")
+            sub = [o.cpu().numpy() for o in odd]
+            want_odd = np.zeros(nobs, dtype=dtype)
+            oracle.cubic_rectilinear(case.grids, case.vals, lin, sub, want_odd)
+            res = it.eval_tensors(odd).cpu().numpy()
+            it.finish()
+            same = (res == want_odd) | (np.isnan(res) & np.isnan(want_odd))
+            assert np.all(same), int((~same).sum())
+        if kind == "regular" and nobs > 1000:
             # failing coordinates: the smallest ORIGINAL index is reported; the prefix is right
             bad = [o.clone() for o in obs]
             bad[2][nobs // 2] = float("nan")

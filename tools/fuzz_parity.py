@@ -109,7 +109,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
             # round 3: the LDS-column evaluation of sorted 4-D multicubic points on regular grids (forced where it
             # applies: fully overlapped tiles), its workgroup size / part size, deliberately mis-binned points, short
             # slices; per-bucket search records on or off
-            if method == "cubic" and N == 4 and kind == "regular" and rng.random() < 0.7:
+            if method == "cubic" and N == 4 and rng.random() < 0.7:  # regular and (round 4) rectilinear grids
                 env["INTERPN_HIP_BINNED"] = "1"
                 env["INTERPN_HIP_BRICKS"] = "11"
                 env["INTERPN_HIP_COLUMN"] = str(int(rng.choice([-1, 1, 1, 1, 0])))
