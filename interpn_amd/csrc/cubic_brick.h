@@ -144,8 +144,7 @@ __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const u
   if constexpr (!RECT) {
     // wave-uniform: every lane interior along the dimension -> the select-free node (same bits)
     if (interior & 1u) {
-#pragma unroll
-      for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_regular_node_interior<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0].tt);
+      cubic_tile_dim0_interior<FMA, T>(v, dim[0].tt, w);  // f32: two nodes per packed instruction
     } else {
 #pragma unroll
       for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_regular_node<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
@@ -209,8 +208,7 @@ __device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicD
   T w4[4];
   if constexpr (!RECT) {
     if (interior & 1u) {
-#pragma unroll
-      for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_regular_node_interior<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0].tt);
+      cubic_tile_dim0_interior<FMA, T>(v, dim[0].tt, w4);  // f32: two nodes per packed instruction
     } else {
 #pragma unroll
       for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_regular_node<FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);

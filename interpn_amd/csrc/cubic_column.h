@@ -232,8 +232,12 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const Co
       const unsigned an = k2 < 3 ? ak + (unsigned)(k2 + 1) * rowpitch : ak + PITCH;
       col_take_tile<T>(an, nxt);
       T w[4];
+      if constexpr (F0 == kFormNone) {
+        cubic_tile_dim0_interior<FMA, T>(cur, dim[0].tt, w);  // f32: two nodes per packed instruction (interpn_device.h)
+      } else {
 #pragma unroll
-      for (int ej = 0; ej < 4; ++ej) w[ej] = col_node<FMA, F0, T>(cur[ej], cur[4 + ej], cur[8 + ej], cur[12 + ej], dim[0]);
+        for (int ej = 0; ej < 4; ++ej) w[ej] = col_node<FMA, F0, T>(cur[ej], cur[4 + ej], cur[8 + ej], cur[12 + ej], dim[0]);
+      }
       if constexpr (ALLNONE) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
       else s2[k2] = col_node_rt<FMA, T>(f1, w[0], w[1], w[2], w[3], dim[1]);
 #pragma unroll
