@@ -162,13 +162,14 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   // evaluated out of LDS instead of 16 L2 lines per point.
   bool column = g.cfg.column != 0 && (second || main11) && cubic_column_applies(*use);
   {
-    // automatic mode: a workgroup's rows must be mostly full and its column fills amortised — from
-    // about four rows of the workgroup's lanes per (class pair) bin on (768 threads: 3072 points;
-    // 32^4: 4e6 points 0.53 against 0.63 ms, 2e6 points 0.35 against 0.30; profiles/r03_cfg4_column_sizes.txt)
+    // automatic mode: a part's rows must be mostly full and its column fills amortised — from about
+    // three rows of the workgroup's lanes per (class pair) bin on (768 threads: 2304 points; 32^4,
+    // round 4: 2e6 points 0.30 against 0.30 ms for the tiled kernel on sorted points, 3e6 0.39-0.42
+    // against 0.43-0.47, 4e6 0.46-0.51 against 0.59-0.64, 2e7 1.96-2.02 against 2.66-2.69)
     const size_t slice_max0 = bin_slice_points(g);
     const size_t per_slice = npoints < slice_max0 ? npoints : slice_max0;
     ColumnPlan cp0;
-    const size_t per_bin_min = column && cubic_column_plan(*use, &cp0) ? (size_t)4 * (size_t)cp0.threads : (size_t)3072;
+    const size_t per_bin_min = column && cubic_column_plan(*use, &cp0) ? (size_t)3 * (size_t)cp0.threads : (size_t)2304;
     if (g.cfg.column < 0 && per_slice < per_bin_min * (size_t)(g.n[0] - 1) * (size_t)(g.n[1] - 1)) column = false;
   }
   {

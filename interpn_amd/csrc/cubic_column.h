@@ -86,6 +86,9 @@ constexpr unsigned kColMaxPart = 12288;  // points of a part at most (16-bit loc
 // points per thread of a group of GT threads: 16 for 768 threads, 32 for 384 and fewer
 constexpr int col_per_thread(int gt) { return (int)((kColMaxPart + gt - 1) / gt) < kColPerThread ? (((int)((kColMaxPart + gt - 1) / gt) + 1) / 2 * 2) : kColPerThread; }
 constexpr int kColKeys = 1024;     // keys of the local sort
+#ifndef COL_FILL_AFTER_BATCH
+#define COL_FILL_AFTER_BATCH 1      // the first fill is issued behind both batches of record loads (vmcnt is in order: loads behind the fill would wait for it)
+#endif
 
 // LDS pitch of a tile: its 16 elements + 16 bytes (see the head of this file)
 template <typename T> constexpr unsigned col_pitch() { return 16u * (unsigned)sizeof(T) + 16u; }
@@ -212,8 +215,11 @@ __device__ __forceinline__ int col_wave_form(const ColDim<T>& d) {
 // index = k3 (the reference's order, multicubic/regular.rs:368-421).  `a0` = LDS address of the
 // point's tile (k2, k3) = (0, 0); `rowpitch` = bytes between tile rows (wave-uniform).  The tile of
 // the next plane is requested before this plane's nodes are evaluated (32 more VGPRs).
-// ALLNONE: every dimension of the wave is interior (the common case): no form tests at all.
-template <typename T, bool FMA, int F0, bool ALLNONE = false>
+// NONE01: dims 0 and 1 of the wave are interior (all but the boundary bins: 80 of the 85 nodes of
+// a point belong to them) — their nodes are compiled without form tests; the five nodes of dims 2, 3
+// always go by the wave's form (f2, f3): after the local sort a wave of 64 points spans about six
+// (dim 2, dim 3) class pairs, and a third of all waves touch a boundary class of dim 3.
+template <typename T, bool FMA, int F0, bool NONE01 = false>
 __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const ColDim<T>* dim, int f1, int f2, int f3) {
   constexpr unsigned PITCH = col_pitch<T>();
   T s3[4];
@@ -238,17 +244,15 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const Co
 #pragma unroll
         for (int ej = 0; ej < 4; ++ej) w[ej] = col_node<FMA, F0, T>(cur[ej], cur[4 + ej], cur[8 + ej], cur[12 + ej], dim[0]);
       }
-      if constexpr (ALLNONE) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
+      if constexpr (NONE01) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
       else s2[k2] = col_node_rt<FMA, T>(f1, w[0], w[1], w[2], w[3], dim[1]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) cur[e] = nxt[e];
     }
     ak += PITCH;
-    if constexpr (ALLNONE) s3[k3] = col_node<FMA, kFormNone, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
-    else s3[k3] = col_node_rt<FMA, T>(f2, s2[0], s2[1], s2[2], s2[3], dim[2]);
+    s3[k3] = col_node_rt<FMA, T>(f2, s2[0], s2[1], s2[2], s2[3], dim[2]);
   }
-  if constexpr (ALLNONE) return col_node<FMA, kFormNone, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
-  else return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
+  return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
 }
 
 // The waves that are not interior along every dimension (boundary bins, boundary classes of dims
@@ -529,7 +533,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           if (q < count) atomicAdd(&s_hist[c], 1u);
         }
       }
-      if (h == 0) {  // the first sub-column travels while the second batch and the scan run
+      if (h == COL_FILL_AFTER_BATCH) {  // the first sub-column travels while the scan runs
         unsigned row0, nrows;
         phase_rows(0, &row0, &nrows);
         fill(row0, nrows);
@@ -667,8 +671,8 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           const int rel2 = loc[2] - (int)row0;
           const bool in_rows = rel2 >= 0 && rel2 <= row_top;
           const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
-          if (forms == 0) {
-            res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, 0, 0);
+          if ((forms & 0xFu) == 0) {  // dims 0, 1 interior: the common path, whatever dims 2, 3 are
+            res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
           } else {
             res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
           }
