@@ -9,6 +9,8 @@
 // written by consecutive lanes instead of single scattered elements.  The order of points inside a bin is not
 // deterministic; results do not depend on it (a point's result depends on its coordinates only,
 // src/multicubic/regular.rs:297-313).
+#include <atomic>
+
 #include "interpn_kernels.h"
 
 namespace interpn {
@@ -195,6 +197,7 @@ struct ScatterArgs {
 // the first is used: with 256 threads and one load in flight per lane the kernel was bound by
 // memory latency (0.57..0.73 ms per 1e7 4-D points).
 constexpr int kScatThreads = 1024;
+constexpr size_t kStagedLdsMax = 160 * 1024 - 512;  // dynamic LDS of the staged records scatter at most (a CU's LDS less its few static words)
 
 // CH = points per workgroup.
 template <typename T, int N, int CH>
@@ -346,12 +349,107 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const Scat
   }
 }
 
+// Records scatter with the chunk's records staged in LDS in bin order (round 4).  The direct form
+// above issues one 32-byte store per point to a position nobody else in the wave is near: 1e7
+// record stores + 1e7 index stores reach the fabric as 1.5e7 write requests (profiles/
+// r04_traffic.json: WRITE_SIZE 679 MB for 360 MB of payload), and the kernel runs at that request
+// rate.  Here every point's record goes to LDS at (first local slot of its bin) + (its rank), and
+// the workgroup then copies the staged chunk out linearly: consecutive lanes hold consecutive
+// records of a run, so a run of k records leaves as ~k / 2 + 1 64-byte requests instead of k, and
+// its k index words as one.  One returning LDS atomic per point, one global atomic per non-empty
+// bin, a 1024-counter scan, four barriers; no coordinate is read twice.  LDS: CH x (record + 4)
+// bytes + three counters per bin — for f64 and 4096 points 144 KiB + 12 nbins bytes, one workgroup
+// per CU (opt-in); taken for nbins <= 1024 (the scan is one counter per thread), else the direct form.
+template <typename T, int N, int CH>
+__global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(const ScatterArgs<T, N> a) {
+  constexpr int kIters = CH / kScatThreads;
+  typedef T RV __attribute__((ext_vector_type(N)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_sc[];
+  RV* const lrec = reinterpret_cast<RV*>(smem_sc);                                        // [CH] records in bin order
+  unsigned short* const lsrc = reinterpret_cast<unsigned short*>(smem_sc + (size_t)CH * sizeof(RV));  // [CH] local index of the point
+  unsigned short* const lkey = lsrc + CH;                                                  // [CH] its bin
+  unsigned* const fill = reinterpret_cast<unsigned*>(lkey + CH);                           // [nbins] points per bin
+  const int nbins = a.p.nbins;  // <= kScatThreads
+  unsigned* const lstart = fill + nbins;                                                   // first local slot of a bin
+  unsigned* const base = lstart + nbins;                                                   // first global slot of this chunk's run
+  __shared__ unsigned s_wsum[kScatThreads / 64];
+  const unsigned tid = threadIdx.x;
+  if ((int)tid < nbins) fill[tid] = 0;
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * CH;
+  const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
+  T x[kIters][N];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+#pragma unroll
+    for (int d = 0; d < N; ++d) x[it][d] = l < count ? stream_load(a.obs[d] + first + l) : (T)0;
+  }
+  unsigned short key[kIters], rank[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+    key[it] = 0;
+    rank[it] = 0;
+    if (l < count) {
+      const int k = bin_key_at<T>(a.p, x[it][0], x[it][1], first + l);
+      key[it] = (unsigned short)k;
+      rank[it] = (unsigned short)atomicAdd(&fill[k], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the bin counts (one bin per thread): wave scan + wave totals; one run per non-empty bin
+  {
+    const unsigned mine = (int)tid < nbins ? fill[tid] : 0u;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = (unsigned)__shfl_up((int)incl, off);
+      if ((tid & 63u) >= (unsigned)off) incl += up;
+    }
+    if ((tid & 63u) == 63u) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (unsigned w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+    if ((int)tid < nbins) {
+      lstart[tid] = run;
+      base[tid] = mine ? atomicAdd(&a.cursor[tid], mine) : 0u;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned l = (unsigned)it * kScatThreads + tid;
+    if (l < count) {
+      const unsigned lp = lstart[key[it]] + rank[it];
+      RV r;
+#pragma unroll
+      for (int d = 0; d < N; ++d) r[d] = x[it][d];
+      lrec[lp] = r;
+      lsrc[lp] = (unsigned short)l;
+      lkey[lp] = key[it];
+    }
+  }
+  __syncthreads();
+  RV* __restrict__ recs = reinterpret_cast<RV*>(a.records);
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const unsigned j = (unsigned)it * kScatThreads + tid;
+    if (j < count) {
+      const unsigned k = lkey[j];
+      const unsigned pos = base[k] + (j - lstart[k]);
+      recs[pos] = lrec[j];
+      a.index[pos] = (unsigned)(first + lsrc[j]);
+    }
+  }
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T, int N>
 hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts, void* scratch, const void** binned_obs,
                         const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream, hipEvent_t* stage,
-                        bool totals_clean) {
+                        bool totals_clean, bool staged) {
   unsigned char* base = static_cast<unsigned char*>(scratch);
   unsigned* totals = reinterpret_cast<unsigned*>(base);
   unsigned* cursor = totals + kMaxBins;
@@ -394,7 +492,22 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   if (extras) {
     if constexpr (N == 4) {
       const unsigned blocks = (unsigned)((npts + kRecChunk - 1) / kRecChunk);
-      hipLaunchKernelGGL((k_bin_scatter_records<T, N, (int)kRecChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
+      const size_t staged_lds = kRecChunk * (N * sizeof(T) + 4) + (size_t)3 * (size_t)p.nbins * sizeof(unsigned);
+      if (p.nbins <= kScatThreads && staged && staged_lds <= kStagedLdsMax) {
+        auto kern = k_bin_scatter_records_staged<T, N, (int)kRecChunk>;
+        if (staged_lds > 64 * 1024) {
+          static std::atomic<unsigned long long> opted{0};  // bit per device
+          int dev = 0;
+          if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !((opted.load() >> dev) & 1ull)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLdsMax);
+            if (e != hipSuccess) return e;
+            opted.fetch_or(1ull << dev);
+          }
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(kScatThreads), staged_lds, stream, a);
+      } else {
+        hipLaunchKernelGGL((k_bin_scatter_records<T, N, (int)kRecChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
+      }
     } else {
       return hipErrorInvalidValue;
     }
@@ -500,7 +613,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
     p.axis_g0[d] = plan.axis_g0[d];
     p.axis_scale[d] = plan.axis_scale[d];
   }
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean)
+#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0)
   if (g.dtype == kF64) {
     switch (g.ndims) {
       case 2: GO(double, 2);

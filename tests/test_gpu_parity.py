@@ -1794,7 +1794,8 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     one per thread of the sort's kernels).  Rectilinear grids (round 4): the sort and the kernel
     classify with the reference's own cell search, so no point is ever mis-binned by itself — the
     scramble option still forces the out-of-cell path; NaN / inf coordinates never fail there and
-    propagate.  src/multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
+    propagate.  The sort's scatter runs in both forms (records staged in LDS in bin order and copied
+    out linearly / stored directly; option `scatter_staged`).  src/multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
     import torch
 
     import interpn_amd
@@ -1811,7 +1812,7 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
         want = run_oracle(oracle, case, True)
         it = _make_interp(interpn_amd, case)
         for k, v in (("binned", 1), ("column", 1), ("column_threads", threads), ("column_part", part), ("bin_scramble", scramble),
-                     ("column_cpp", cpp), ("column_groups", 1 + nobs % 2)):
+                     ("column_cpp", cpp), ("column_groups", 1 + nobs % 2), ("scatter_staged", (nobs // 7) % 2)):
             it.set_option(k, v)
         obs = [torch.from_numpy(o).to(dev) for o in case.obs]
         out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)
