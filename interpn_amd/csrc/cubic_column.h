@@ -86,9 +86,7 @@ constexpr unsigned kColMaxPart = 12288;  // points of a part at most (16-bit loc
 // points per thread of a group of GT threads: 16 for 768 threads, 32 for 384 and fewer
 constexpr int col_per_thread(int gt) { return (int)((kColMaxPart + gt - 1) / gt) < kColPerThread ? (((int)((kColMaxPart + gt - 1) / gt) + 1) / 2 * 2) : kColPerThread; }
 constexpr int kColKeys = 1024;     // keys of the local sort
-#ifndef COL_FILL_AFTER_BATCH
-#define COL_FILL_AFTER_BATCH 1      // the first fill is issued behind both batches of record loads (vmcnt is in order: loads behind the fill would wait for it)
-#endif
+
 
 // LDS pitch of a tile: its 16 elements + 16 bytes (see the head of this file)
 template <typename T> constexpr unsigned col_pitch() { return 16u * (unsigned)sizeof(T) + 16u; }
@@ -500,9 +498,10 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     // ---- local sort, pass 1: the (dim 2, dim 3) class pair of each of my points -> histogram,
     // in two batches of 16 loads per thread; the first phase's fill is issued behind the first.
     unsigned cls23[PT / 2];  // two 16-bit keys per register
+    constexpr int NB = PT > 16 ? 2 : 1;  // batches of at most 16 loads per thread (all of a batch in flight together)
+    constexpr int HB = PT / NB;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      constexpr int HB = PT / 2;
+    for (int h = 0; h < NB; ++h) {
       if (h == 1 && (unsigned)HB * (unsigned)GT >= count) {  // group-uniform: nothing in the second batch
 #pragma unroll
         for (int m = 0; m < HB / 2; ++m) cls23[HB / 2 + m] = 0;
@@ -533,7 +532,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           if (q < count) atomicAdd(&s_hist[c], 1u);
         }
       }
-      if (h == COL_FILL_AFTER_BATCH) {  // the first sub-column travels while the scan runs
+      if (h == NB - 1) {  // the first sub-column travels while the scan runs (behind the record loads: vmcnt is in order)
         unsigned row0, nrows;
         phase_rows(0, &row0, &nrows);
         fill(row0, nrows);
