@@ -79,6 +79,8 @@ struct CubicColumnArgs {
   // dynamic LDS.  Classes are then exact (partition_point), not estimates.
   AxisArgs<T, 4> ax;
   unsigned axes_lds_off;
+  // dim 0 by coefficients (see "Coefficient columns" below); 0: every node from the table values
+  int coef;
 };
 
 constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
@@ -209,6 +211,71 @@ __device__ __forceinline__ int col_wave_form(const ColDim<T>& d) {
   return kFormMixed;
 }
 
+// ---- Coefficient columns -----------------------------------------------------------------------
+// All points of a part share the class of dim 0, i.e. the saturation arm of the 64 dim-0 nodes of
+// their footprint, and those nodes' inputs are table values only.  What the reference computes
+// for such a node before it touches t — y0, dy, k0, k1 and the spline's c1, c2, c3
+// (multicubic/regular.rs:495-582, mod.rs:72-81; rectilinear.rs:437-533 with mod.rs:103-117) — is
+// therefore the same for every point of the part: once the sub-column has landed, the group
+// rewrites each tile line (v[ei][ej], ei = 0..3) in place as (y0, c1, c2, c3)[ej], by the
+// reference's own operations in its order, and a point's dim-0 node is Horner's three steps
+// (mod.rs:83-91) on them: 3 instead of 14 instructions (rectilinear: 3 instead of ~40 with two
+// IEEE divisions) for 64 of a point's 85 nodes.  Same operations on the same operands: the same
+// bits.  A point whose own arm is not the part's (a point the sort's estimate put in the wrong
+// bin; a point outside the grid when extrapolation is linearised) is evaluated from the table in
+// global memory like every other point that does not belong to its part.
+constexpr int kFormCoef = 4;  // col_reduce's F0: the tile holds coefficients
+
+template <bool FMA, typename T>
+__device__ __forceinline__ HermiteCoef<T> col_node_coef(int form, T v0, T v1, T v2, T v3) {
+  const T two = (T)2;
+  if (form == kFormNone) {         // regular.rs:495-505
+    const T dy = v2 - v1;
+    const T k0 = (v2 - v0) / two;
+    const T k1 = (v3 - v1) / two;
+    return hermite_coef<T>(v1, dy, k0, k1);
+  } else if (form == kFormLow) {   // regular.rs:507-527
+    const T dy = v0 - v1;
+    const T k0 = -((v2 - v0) / two);
+    const T k1 = two * dy - k0;
+    return hermite_coef<T>(v1, dy, k0, k1);
+  } else {                         // regular.rs:563-582
+    const T dy = v3 - v2;
+    const T k0 = (v3 - v1) / two;
+    const T k1 = two * dy - k0;
+    return hermite_coef<T>(v2, dy, k0, k1);
+  }
+}
+
+// dim 0 of a coefficient tile (c[k * 4 + ej], k = y0, c1, c2, c3) for all four ej: w[ej]
+template <bool FMA, typename T>
+__device__ __forceinline__ void col_tile_dim0_coef(const T (&c)[16], T t, T (&w)[4]) {
+  if constexpr (sizeof(T) == 4) {  // two nodes per packed instruction, lane-wise the scalar operations
+    const float_pair tt = {t, t};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float_pair y0 = {c[2 * p], c[2 * p + 1]}, c1 = {c[4 + 2 * p], c[4 + 2 * p + 1]};
+      const float_pair c2 = {c[8 + 2 * p], c[8 + 2 * p + 1]}, c3 = {c[12 + 2 * p], c[12 + 2 * p + 1]};
+      float_pair r;
+      if constexpr (FMA) {
+        r = __builtin_elementwise_fma(__builtin_elementwise_fma(__builtin_elementwise_fma(c3, tt, c2), tt, c1), tt, y0);
+      } else {
+        const float_pair i0 = tt * c3;
+        const float_pair i1 = c2 + i0;
+        const float_pair i2 = tt * i1;
+        const float_pair i3 = c1 + i2;
+        const float_pair i4 = tt * i3;
+        r = y0 + i4;
+      }
+      w[2 * p] = r.x;
+      w[2 * p + 1] = r.y;
+    }
+  } else {
+#pragma unroll
+    for (int ej = 0; ej < 4; ++ej) w[ej] = hermite_eval<FMA, T>(t, c[ej], c[4 + ej], c[8 + ej], c[12 + ej]);
+  }
+}
+
 // All 16 planes of a point out of the LDS sub-column, dim 0 in form F0: dim 2 index = k2, dim 3
 // index = k3 (the reference's order, multicubic/regular.rs:368-421).  `a0` = LDS address of the
 // point's tile (k2, k3) = (0, 0); `rowpitch` = bytes between tile rows (wave-uniform).  The tile of
@@ -236,7 +303,9 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const Co
       const unsigned an = k2 < 3 ? ak + (unsigned)(k2 + 1) * rowpitch : ak + PITCH;
       col_take_tile<T>(an, nxt);
       T w[4];
-      if constexpr (F0 == kFormNone) {
+      if constexpr (F0 == kFormCoef) {
+        col_tile_dim0_coef<FMA, T>(cur, dim[0].tt, w);
+      } else if constexpr (F0 == kFormNone) {
         cubic_tile_dim0_interior<FMA, T>(cur, dim[0].tt, w);  // f32: two nodes per packed instruction (interpn_device.h)
       } else {
 #pragma unroll
@@ -269,6 +338,7 @@ __device__ __noinline__ T col_reduce_general(unsigned a0, unsigned rowpitch, T t
     dim[d].lin = (cls >> (3 * d + 2)) & 1u;
   }
   const int f0 = forms & 3, f1 = (forms >> 2) & 3, f2 = (forms >> 4) & 3, f3 = (forms >> 6) & 3;
+  if (forms & 0x100) return col_reduce<T, FMA, kFormCoef>(a0, rowpitch, dim, f1, f2, f3);  // coefficient column (group-uniform)
   switch (f0) {  // wave-uniform
     case kFormNone: return col_reduce<T, FMA, kFormNone>(a0, rowpitch, dim, f1, f2, f3);
     case kFormLow: return col_reduce<T, FMA, kFormLow>(a0, rowpitch, dim, f1, f2, f3);
@@ -300,7 +370,7 @@ __device__ __forceinline__ unsigned col_rect_class(const Axis<T>& ax, T x) {
 // All 16 planes of a point on a rectilinear grid out of the LDS sub-column: the reference's tree
 // (multicubic/rectilinear.rs:290-356) with its node (rectilinear.rs:413-545; two IEEE divisions by
 // the spacing ratios per node, which is what this kernel spends its time on: no tile prefetch).
-template <typename T, bool FMA>
+template <typename T, bool FMA, bool COEF = false>
 __device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, const CubicDimRect<T>* dim) {
   constexpr unsigned PITCH = col_pitch<T>();
   T s3[4];
@@ -312,7 +382,13 @@ __device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, con
     for (int k2 = 0; k2 < 4; ++k2) {
       T v[16];
       col_take_tile<T>(ak + (unsigned)k2 * rowpitch, v);
-      s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
+      if constexpr (COEF) {
+        T w[4];
+        col_tile_dim0_coef<FMA, T>(v, dim[0].t, w);
+        s2[k2] = cubic_rect_node<FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+      } else {
+        s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
+      }
     }
     ak += PITCH;
     s3[k3] = cubic_rect_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
@@ -474,6 +550,39 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     const unsigned cell_off = (unsigned)(ci * (int)a.nbj + cj) * 16u * (unsigned)sizeof(T);  // my cell's tile inside a plane, bytes
     const RV* __restrict__ recs = reinterpret_cast<const RV*>(a.records) + begin;
     const unsigned* __restrict__ index = a.index + begin;
+    // dim 0 by coefficients ("Coefficient columns" above)?  xf = the arm every point of the part
+    // shares along dim 0, or -1: the tiles keep the table values.  The saturated classes hold
+    // points inside and outside the grid alike; with linearised extrapolation the outside ones
+    // have no spline, so those parts keep the values.
+    int xf = -1;
+    if (a.coef) {
+      if (c0 > 0 && c0 < a.n[0] - 2) xf = kFormNone;
+      else if (!a.linearize) xf = c0 == 0 ? kFormLow : kFormHigh;
+    }
+    // tile lines (v[ei][ej], ei = 0..3) of `nrows` rows -> (y0, c1, c2, c3)[ej], in place
+    auto to_coef = [&](unsigned nrows) {
+      typedef __attribute__((address_space(3))) T lds_T;
+      CubicDimRect<T> d0;
+      if constexpr (RECT) {
+        d0.sat = xf;  // kForm* == kSat*
+        d0.linear = 0;
+        d0.fma_linear = 0;
+        cubic_rect_dim_setup<T>(make_axis<T, 4>(a.ax, axis_base, 0).g, ci, (T)0, d0);  // d0.t is not used
+      }
+      const unsigned lines = nrows * n3 * 4u;
+      for (unsigned k = gtid; k < lines; k += GT) {
+        const unsigned ad = lds_col + (k >> 2) * PITCH + (k & 3u) * (unsigned)sizeof(T);
+        lds_T* const pv = (lds_T*)(size_t)ad;
+        const T v0 = pv[0], v1 = pv[4], v2 = pv[8], v3 = pv[12];
+        HermiteCoef<T> c;
+        if constexpr (RECT) c = cubic_rect_node_coef<FMA, T>(v0, v1, v2, v3, d0);
+        else c = col_node_coef<FMA, T>(xf, v0, v1, v2, v3);
+        pv[0] = c.y0;
+        pv[4] = c.c1;
+        pv[8] = c.c2;
+        pv[12] = c.c3;
+      }
+    };
 
     // Sub-column fill, row by row: instruction slot j of a row moves the row's 16-byte units
     // 64 j .. 64 j + 63 (1 KiB); unit u = tile l = u / PU, piece u % PU (the last unit of a tile
@@ -588,6 +697,10 @@ k_cubic_column(const CubicColumnArgs<T> a) {
         phase_stretch(0, &ps, &pe);
         if (pe == ps) continue;
       }
+      if (xf >= 0) {  // group-uniform
+        to_coef(nrows);
+        col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+      }
       const int row_top = (int)nrows - 4;  // largest footprint row inside the sub-column
 
       // Rows of 64 slots are handed to the waves as they free up (a shared counter: rows differ in
@@ -623,8 +736,12 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           const int rel2 = loc[2] - (int)row0;
           const bool in_rows = rel2 >= 0 && rel2 <= row_top;
           const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
-          res = col_reduce_rect<T, FMA>(a0, rowpitch, dim);
-          if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {  // only deliberately mis-binned points (bin_scramble): classes are exact here
+          if (xf >= 0) res = col_reduce_rect<T, FMA, true>(a0, rowpitch, dim);
+          else res = col_reduce_rect<T, FMA, false>(a0, rowpitch, dim);
+          // only deliberately mis-binned points (bin_scramble): classes are exact here; in a coefficient
+          // column also the points whose arm along dim 0 is not the part's
+          const bool arm0 = xf < 0 || (dim[0].sat == xf && !dim[0].linear);
+          if (live && (loc[0] != ci || loc[1] != cj || !in_rows || !arm0)) {
             const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
                                    (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
             CubicDimRect<T> dcopy[4];
@@ -670,13 +787,23 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           const int rel2 = loc[2] - (int)row0;
           const bool in_rows = rel2 >= 0 && rel2 <= row_top;
           const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
-          if ((forms & 0xFu) == 0) {  // dims 0, 1 interior: the common path, whatever dims 2, 3 are
+          bool arm0 = true;
+          if (xf >= 0) {  // coefficient column (group-uniform): dim 0 is Horner's steps whatever the wave's form there
+            if ((forms & 0xCu) == 0) {  // dim 1 interior: the common path
+              res = col_reduce<T, FMA, kFormCoef, true>(a0, rowpitch, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
+            } else {
+              res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)(forms | 0x100u));
+            }
+            // my own arm along dim 0 must be the part's
+            arm0 = !dim[0].lin && (xf == kFormNone ? !(dim[0].low || dim[0].high) : (xf == kFormLow ? dim[0].low : dim[0].high));
+          } else if ((forms & 0xFu) == 0) {  // dims 0, 1 interior: the common path, whatever dims 2, 3 are
             res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
           } else {
             res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
           }
-          // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary): from the table
-          if (live && (loc[0] != ci || loc[1] != cj || !in_rows)) {
+          // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary) / not the
+          // part's arm along dim 0: from the table
+          if (live && (loc[0] != ci || loc[1] != cj || !in_rows || !arm0)) {
             const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
                                    (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
             CubicDimRegular<T> dcopy[4];

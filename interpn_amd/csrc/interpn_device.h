@@ -275,13 +275,27 @@ struct LinearTree<T, IdxT, 0, FMA> {
 //   High : t-1,  y0=v2, dy=v3-v2, k0=(v3-v1)/2,  k1=2dy-k0   (Inside/OutsideHigh)
 // `two.mul_add(dy, -k0)` == `two*dy - k0` bit for bit (2*dy is exact).
 // Hermite: src/multicubic/mod.rs:72-91.
-template <bool FMA, typename T>
-__device__ __forceinline__ T hermite(T t, T y0, T dy, T k0, T k1) {
+// The spline in two steps: its coefficients (everything that does not depend on t — the same for
+// every point that shares the node's four values and its saturation arm) and Horner's evaluation.
+// hermite() is the two in sequence, so a kernel that keeps coefficients (cubic_column.h) computes
+// the very operations of the reference, in its order.
+template <typename T>
+struct HermiteCoef { T y0, c1, c2, c3; };
+
+template <typename T>
+__device__ __forceinline__ HermiteCoef<T> hermite_coef(T y0, T dy, T k0, T k1) {
   T a = k0 - dy;
   T b = -k1 + dy;
-  T c1 = dy + a;
-  T c2 = b - (a + a);
-  T c3 = a - b;
+  HermiteCoef<T> c;
+  c.y0 = y0;
+  c.c1 = dy + a;
+  c.c2 = b - (a + a);
+  c.c3 = a - b;
+  return c;
+}
+
+template <bool FMA, typename T>
+__device__ __forceinline__ T hermite_eval(T t, T y0, T c1, T c2, T c3) {
   if constexpr (FMA) {
     return dev_fma<T>(dev_fma<T>(dev_fma<T>(c3, t, c2), t, c1), t, y0);
   } else {
@@ -292,6 +306,12 @@ __device__ __forceinline__ T hermite(T t, T y0, T dy, T k0, T k1) {
     T i4 = t * i3;
     return y0 + i4;
   }
+}
+
+template <bool FMA, typename T>
+__device__ __forceinline__ T hermite(T t, T y0, T dy, T k0, T k1) {
+  const HermiteCoef<T> c = hermite_coef<T>(y0, dy, k0, k1);
+  return hermite_eval<FMA, T>(t, c.y0, c.c1, c.c2, c.c3);
 }
 
 template <typename T>
@@ -487,6 +507,29 @@ __device__ __forceinline__ T cubic_rect_node(T v0, T v1, T v2, T v3, const Cubic
     return y1 + p;  // rectilinear.rs:500,:539 — never fused in the flattened arm
   }
   return hermite<FMA>(d.t, y0, dy, k0, k1);
+}
+
+// The coefficients of the same node (its Hermite arms only: a point that extrapolates linearly
+// does not use them) — cubic_rect_node is hermite_eval(d.t, ...) of these.
+template <bool FMA, typename T>
+__device__ __forceinline__ HermiteCoef<T> cubic_rect_node_coef(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d) {
+  const T two = (T)2;
+  if (d.sat == kSatNone) {
+    T dy = v2 - v1;
+    T k0 = cd_unit_b<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
+    T k1 = cd_unit_a<FMA>(v1, v2, v3, d.r1, d.a1, d.c1);
+    return hermite_coef<T>(v1, dy, k0, k1);
+  }
+  T y0, dy, k0;
+  if (d.sat == kSatLow) {
+    y0 = v1; dy = v0 - v1;
+    k0 = -cd_unit_a<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
+  } else {
+    y0 = v2; dy = v3 - v2;
+    k0 = cd_unit_b<FMA>(v1, v2, v3, d.r0, d.a0, d.c0);
+  }
+  T k1 = two * dy - k0;
+  return hermite_coef<T>(y0, dy, k0, k1);
 }
 
 // Cubic tree on a 4-wide leaf of the last dim; NodeFn(v0..v3, dim) -> T.

@@ -168,6 +168,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   a.axes_lds_off = (unsigned)((size_t)cp.group_bytes * (size_t)cp.groups);
+  a.coef = g.cfg.column_coef;
   if (g.kind == kRectilinear) {
     fill_axis_args<T, 4>(g, a.ax);  // offsets, lengths, bucket tables; the kernel stages the image itself
     a.ax.use_rec = 0;
