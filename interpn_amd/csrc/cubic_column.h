@@ -71,7 +71,8 @@ struct CubicColumnArgs {
   int nphase;                // ceil((n2 - 1) / cpp)
   int q3;                    // local sort key = class of dim 2 * q3 + (class of dim 3 >> sh3); (n2 - 1) * q3 <= 1024
   int sh3;
-  unsigned sub_bytes;        // LDS bytes of a group's sub-column; its local order (16-bit) sits behind them
+  unsigned sub_bytes;        // LDS bytes of a group's sub-column; what of its local order (16-bit) does not fit the tiles' padding sits behind them
+  unsigned perm_pad;         // entries of the local order kept in the padding of the sub-column's tiles (0: bare tiles)
   unsigned group_bytes;      // dynamic LDS bytes per group (sub-column + local order, 16-byte multiple)
   unsigned long long* stamps;  // measurement aid (option debug_stamps): 8 words per part, or null
   // Rectilinear grids (RECT kernels): the handle's axis image (coordinates + bucket tables of all
@@ -81,6 +82,9 @@ struct CubicColumnArgs {
   unsigned axes_lds_off;
   // dim 0 by coefficients (see "Coefficient columns" below); 0: every node from the table values
   int coef;
+  // LDS bytes from tile to tile: the tile + 16 (see the head of this file), or the bare tile where
+  // only that lets the whole column fit (one phase per part instead of two: k_cubic_column.hip)
+  unsigned pitch;
 };
 
 constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
@@ -224,8 +228,6 @@ __device__ __forceinline__ int col_wave_form(const ColDim<T>& d) {
 // bits.  A point whose own arm is not the part's (a point the sort's estimate put in the wrong
 // bin; a point outside the grid when extrapolation is linearised) is evaluated from the table in
 // global memory like every other point that does not belong to its part.
-constexpr int kFormCoef = 4;  // col_reduce's F0: the tile holds coefficients
-
 template <bool FMA, typename T>
 __device__ __forceinline__ HermiteCoef<T> col_node_coef(int form, T v0, T v1, T v2, T v3) {
   const T two = (T)2;
@@ -247,35 +249,6 @@ __device__ __forceinline__ HermiteCoef<T> col_node_coef(int form, T v0, T v1, T 
   }
 }
 
-// dim 0 of a coefficient tile (c[k * 4 + ej], k = y0, c1, c2, c3) for all four ej: w[ej]
-template <bool FMA, typename T>
-__device__ __forceinline__ void col_tile_dim0_coef(const T (&c)[16], T t, T (&w)[4]) {
-  if constexpr (sizeof(T) == 4) {  // two nodes per packed instruction, lane-wise the scalar operations
-    const float_pair tt = {t, t};
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float_pair y0 = {c[2 * p], c[2 * p + 1]}, c1 = {c[4 + 2 * p], c[4 + 2 * p + 1]};
-      const float_pair c2 = {c[8 + 2 * p], c[8 + 2 * p + 1]}, c3 = {c[12 + 2 * p], c[12 + 2 * p + 1]};
-      float_pair r;
-      if constexpr (FMA) {
-        r = __builtin_elementwise_fma(__builtin_elementwise_fma(__builtin_elementwise_fma(c3, tt, c2), tt, c1), tt, y0);
-      } else {
-        const float_pair i0 = tt * c3;
-        const float_pair i1 = c2 + i0;
-        const float_pair i2 = tt * i1;
-        const float_pair i3 = c1 + i2;
-        const float_pair i4 = tt * i3;
-        r = y0 + i4;
-      }
-      w[2 * p] = r.x;
-      w[2 * p + 1] = r.y;
-    }
-  } else {
-#pragma unroll
-    for (int ej = 0; ej < 4; ++ej) w[ej] = hermite_eval<FMA, T>(t, c[ej], c[4 + ej], c[8 + ej], c[12 + ej]);
-  }
-}
-
 // All 16 planes of a point out of the LDS sub-column, dim 0 in form F0: dim 2 index = k2, dim 3
 // index = k3 (the reference's order, multicubic/regular.rs:368-421).  `a0` = LDS address of the
 // point's tile (k2, k3) = (0, 0); `rowpitch` = bytes between tile rows (wave-uniform).  The tile of
@@ -285,8 +258,7 @@ __device__ __forceinline__ void col_tile_dim0_coef(const T (&c)[16], T t, T (&w)
 // always go by the wave's form (f2, f3): after the local sort a wave of 64 points spans about six
 // (dim 2, dim 3) class pairs, and a third of all waves touch a boundary class of dim 3.
 template <typename T, bool FMA, int F0, bool NONE01 = false>
-__device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const ColDim<T>* dim, int f1, int f2, int f3) {
-  constexpr unsigned PITCH = col_pitch<T>();
+__device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, unsigned PITCH, const ColDim<T>* dim, int f1, int f2, int f3) {
   T s3[4];
   T cur[16];
   unsigned ak = a0;  // tile (0, k3)
@@ -303,9 +275,7 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const Co
       const unsigned an = k2 < 3 ? ak + (unsigned)(k2 + 1) * rowpitch : ak + PITCH;
       col_take_tile<T>(an, nxt);
       T w[4];
-      if constexpr (F0 == kFormCoef) {
-        col_tile_dim0_coef<FMA, T>(cur, dim[0].tt, w);
-      } else if constexpr (F0 == kFormNone) {
+      if constexpr (F0 == kFormNone) {
         cubic_tile_dim0_interior<FMA, T>(cur, dim[0].tt, w);  // f32: two nodes per packed instruction (interpn_device.h)
       } else {
 #pragma unroll
@@ -322,12 +292,124 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, const Co
   return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
 }
 
+// ---- all 16 planes of a point out of a COEFFICIENT sub-column -----------------------------------
+// Half a tile at a time in f64: the 16-byte pieces 2k + h (k = y0, c1, c2, c3) hold the
+// coefficients of the lines ej = 2h, 2h + 1, so a half is four loads = 16 registers and feeds two
+// of the tile's four dim-0 nodes; the next half (or the next plane's first) is requested before
+// this half's Horner steps.  32 registers of tile data in flight instead of the 64 of col_reduce:
+// what lets the kernel run four waves per SIMD (128 registers).  An f32 tile is four pieces
+// (piece k = coefficient k of all four lines) and is taken whole.
+template <typename T> struct ColHalf {
+  static constexpr int EP = 16 / (int)sizeof(T);   // elements per piece: 2 / 4
+  static constexpr int H = (int)sizeof(T) == 8 ? 2 : 1;  // halves per tile
+  typedef T TP __attribute__((ext_vector_type(EP), may_alias));
+  typedef __attribute__((address_space(3))) const TP lds_TP;
+  TP c[4];
+  __device__ __forceinline__ void take(unsigned tile_addr, int h) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = *(lds_TP*)(size_t)(tile_addr + (unsigned)(k * H + h) * 16u);
+  }
+  // the dim-0 nodes of my lines: w[h * EP + j]
+  template <bool FMA>
+  __device__ __forceinline__ void horner(T t, int h, T (&w)[4]) const {
+    if constexpr (sizeof(T) == 4) {  // two nodes per packed instruction, lane-wise the scalar operations
+      const float_pair tt = {t, t};
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float_pair y0 = {c[0][2 * p], c[0][2 * p + 1]}, c1 = {c[1][2 * p], c[1][2 * p + 1]};
+        const float_pair c2 = {c[2][2 * p], c[2][2 * p + 1]}, c3 = {c[3][2 * p], c[3][2 * p + 1]};
+        float_pair r;
+        if constexpr (FMA) {
+          r = __builtin_elementwise_fma(__builtin_elementwise_fma(__builtin_elementwise_fma(c3, tt, c2), tt, c1), tt, y0);
+        } else {
+          const float_pair i0 = tt * c3;
+          const float_pair i1 = c2 + i0;
+          const float_pair i2 = tt * i1;
+          const float_pair i3 = c1 + i2;
+          const float_pair i4 = tt * i3;
+          r = y0 + i4;
+        }
+        w[2 * p] = r.x;
+        w[2 * p + 1] = r.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < EP; ++j) w[h * EP + j] = hermite_eval<FMA, T>(t, c[0][j], c[1][j], c[2][j], c[3][j]);
+    }
+  }
+};
+
+// regular grids; NONE1: dim 1 of the wave is interior (its node without form tests); f1..f3: the wave's forms
+template <typename T, bool FMA, bool NONE1>
+__device__ __forceinline__ T col_reduce_coef(unsigned a0, unsigned rowpitch, unsigned PITCH, const ColDim<T>* dim, int f1, int f2, int f3) {
+  constexpr int H = ColHalf<T>::H;
+  T s3[4];
+  unsigned ak = a0;  // tile (0, k3)
+  ColHalf<T> cur;
+  cur.take(ak, 0);
+#pragma unroll 1
+  for (int k3 = 0; k3 < 4; ++k3) {
+    T s2[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const unsigned at = ak + (unsigned)k2 * rowpitch;
+      T w[4];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        // behind the last plane this reads half a tile too many ((0, 4): the next tile of the
+        // point's first row or the first of the next row, still inside the sub-column)
+        ColHalf<T> nxt;
+        if (h + 1 < H) nxt.take(at, h + 1);
+        else nxt.take(k2 < 3 ? at + rowpitch : ak + PITCH, 0);
+        cur.template horner<FMA>(dim[0].tt, h, w);
+        cur = nxt;
+      }
+      if constexpr (NONE1) s2[k2] = col_node<FMA, kFormNone, T>(w[0], w[1], w[2], w[3], dim[1]);
+      else s2[k2] = col_node_rt<FMA, T>(f1, w[0], w[1], w[2], w[3], dim[1]);
+    }
+    ak += PITCH;
+    s3[k3] = col_node_rt<FMA, T>(f2, s2[0], s2[1], s2[2], s2[3], dim[2]);
+  }
+  return col_node_rt<FMA, T>(f3, s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
+// rectilinear grids (the reference's node for dims 1..3: multicubic/rectilinear.rs:413-545)
+template <typename T, bool FMA>
+__device__ __forceinline__ T col_reduce_coef_rect(unsigned a0, unsigned rowpitch, unsigned PITCH, const CubicDimRect<T>* dim) {
+  constexpr int H = ColHalf<T>::H;
+  T s3[4];
+  unsigned ak = a0;
+  ColHalf<T> cur;
+  cur.take(ak, 0);
+#pragma unroll 1
+  for (int k3 = 0; k3 < 4; ++k3) {
+    T s2[4];
+#pragma unroll 1
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const unsigned at = ak + (unsigned)k2 * rowpitch;
+      T w[4];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        ColHalf<T> nxt;
+        if (h + 1 < H) nxt.take(at, h + 1);
+        else nxt.take(k2 < 3 ? at + rowpitch : ak + PITCH, 0);
+        cur.template horner<FMA>(dim[0].t, h, w);
+        cur = nxt;
+      }
+      s2[k2] = cubic_rect_node<FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+    }
+    ak += PITCH;
+    s3[k3] = cubic_rect_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+  }
+  return cubic_rect_node<FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+}
+
 // The waves that are not interior along every dimension (boundary bins, boundary classes of dims
 // 2, 3, extrapolating points): out of line, so that their node forms' registers do not weigh on the
 // allocation of the common path (measured: the inlined switch made the compiler spill 24 registers
 // around every form).
 template <typename T, bool FMA>
-__device__ __noinline__ T col_reduce_general(unsigned a0, unsigned rowpitch, T tt0, T tt1, T tt2, T tt3, unsigned cls, int forms) {
+__device__ __noinline__ T col_reduce_general(unsigned a0, unsigned rowpitch, unsigned pitch, T tt0, T tt1, T tt2, T tt3, unsigned cls, int forms) {
   ColDim<T> dim[4];
   const T tt[4] = {tt0, tt1, tt2, tt3};
 #pragma unroll
@@ -338,12 +420,12 @@ __device__ __noinline__ T col_reduce_general(unsigned a0, unsigned rowpitch, T t
     dim[d].lin = (cls >> (3 * d + 2)) & 1u;
   }
   const int f0 = forms & 3, f1 = (forms >> 2) & 3, f2 = (forms >> 4) & 3, f3 = (forms >> 6) & 3;
-  if (forms & 0x100) return col_reduce<T, FMA, kFormCoef>(a0, rowpitch, dim, f1, f2, f3);  // coefficient column (group-uniform)
+  if (forms & 0x100) return col_reduce_coef<T, FMA, false>(a0, rowpitch, pitch, dim, f1, f2, f3);  // coefficient column (group-uniform)
   switch (f0) {  // wave-uniform
-    case kFormNone: return col_reduce<T, FMA, kFormNone>(a0, rowpitch, dim, f1, f2, f3);
-    case kFormLow: return col_reduce<T, FMA, kFormLow>(a0, rowpitch, dim, f1, f2, f3);
-    case kFormHigh: return col_reduce<T, FMA, kFormHigh>(a0, rowpitch, dim, f1, f2, f3);
-    default: return col_reduce<T, FMA, kFormMixed>(a0, rowpitch, dim, f1, f2, f3);
+    case kFormNone: return col_reduce<T, FMA, kFormNone>(a0, rowpitch, pitch, dim, f1, f2, f3);
+    case kFormLow: return col_reduce<T, FMA, kFormLow>(a0, rowpitch, pitch, dim, f1, f2, f3);
+    case kFormHigh: return col_reduce<T, FMA, kFormHigh>(a0, rowpitch, pitch, dim, f1, f2, f3);
+    default: return col_reduce<T, FMA, kFormMixed>(a0, rowpitch, pitch, dim, f1, f2, f3);
   }
 }
 
@@ -370,9 +452,8 @@ __device__ __forceinline__ unsigned col_rect_class(const Axis<T>& ax, T x) {
 // All 16 planes of a point on a rectilinear grid out of the LDS sub-column: the reference's tree
 // (multicubic/rectilinear.rs:290-356) with its node (rectilinear.rs:413-545; two IEEE divisions by
 // the spacing ratios per node, which is what this kernel spends its time on: no tile prefetch).
-template <typename T, bool FMA, bool COEF = false>
-__device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, const CubicDimRect<T>* dim) {
-  constexpr unsigned PITCH = col_pitch<T>();
+template <typename T, bool FMA>
+__device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, unsigned PITCH, const CubicDimRect<T>* dim) {
   T s3[4];
   unsigned ak = a0;
 #pragma unroll 1
@@ -382,13 +463,7 @@ __device__ __forceinline__ T col_reduce_rect(unsigned a0, unsigned rowpitch, con
     for (int k2 = 0; k2 < 4; ++k2) {
       T v[16];
       col_take_tile<T>(ak + (unsigned)k2 * rowpitch, v);
-      if constexpr (COEF) {
-        T w[4];
-        col_tile_dim0_coef<FMA, T>(v, dim[0].t, w);
-        s2[k2] = cubic_rect_node<FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
-      } else {
-        s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
-      }
+      s2[k2] = reduce_tile<T, true, FMA>(v, dim, 0u);
     }
     ak += PITCH;
     s3[k3] = cubic_rect_node<FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
@@ -448,9 +523,9 @@ k_cubic_column(const CubicColumnArgs<T> a) {
   constexpr int GW = GT / 64;            // its waves
   constexpr int PT = col_per_thread(GT); // points of a part per thread at most
   constexpr int BAR = GW;  // (s_barrier for GROUPS == 1 — BAR = 0 — hangs on the GPU at 32^4 inside this persistent loop: not used)
-  constexpr unsigned PITCH = col_pitch<T>();
-  constexpr unsigned PU = col_pitch_units<T>();
   constexpr unsigned PP = (unsigned)sizeof(T);  // 16-byte pieces of a tile
+  const unsigned PITCH = a.pitch;               // bytes from tile to tile (group-uniform)
+  const unsigned PU = PITCH >> 4;               // ... in 16-byte units
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_col[];
   __shared__ unsigned s_hist_all[GROUPS][kColKeys];  // local sort: points per key, then (after pass 2) the END of every key's stretch
   __shared__ unsigned s_wave_all[GROUPS][GW];
@@ -476,7 +551,17 @@ k_cubic_column(const CubicColumnArgs<T> a) {
   const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(a.tiles, a.table_bytes);
   const unsigned ps2 = a.plane_stride[2] * (unsigned)sizeof(T), ps3 = a.plane_stride[3] * (unsigned)sizeof(T);
   const unsigned lds_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_col + grp * a.group_bytes;
-  unsigned short* const perm = reinterpret_cast<unsigned short*>(smem_col + (size_t)grp * a.group_bytes + a.sub_bytes);  // local order: slot -> point of the part
+  // Local order (slot -> point of the part, 16 bits each): its first a.perm_pad entries sit in the
+  // 16 bytes of padding behind every tile of the sub-column (eight entries per tile: the fills and
+  // the coefficient pass write tile pieces only), the rest behind the sub-column.  That is what
+  // lets cfg4's whole padded column (144 KiB) share the LDS with the order of a 12 288-point part.
+  unsigned char* const grp_base = smem_col + (size_t)grp * a.group_bytes;
+  const unsigned perm_pad = a.perm_pad;
+  auto perm_at = [&](unsigned i) -> unsigned short* {
+    const unsigned in_pad = (i >> 3) * PITCH + 16u * (unsigned)sizeof(T) + (i & 7u) * 2u;
+    const unsigned in_tail = a.sub_bytes + (i - perm_pad) * 2u;
+    return reinterpret_cast<unsigned short*>(grp_base + (i < perm_pad ? in_pad : in_tail));
+  };
   const unsigned rowpitch = n3 * PITCH;  // LDS bytes of a tile row
   typedef T RV __attribute__((ext_vector_type(4)));
 
@@ -594,7 +679,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
       const unsigned slots = (units + 63u) / 64u;
       for (unsigned j = 0; j < slots; ++j) {
         const unsigned u = j * 64u + wl;
-        const unsigned l = u / PU, piece = u - l * PU;
+        const unsigned l = PU == PP ? u / PP : u / (PP + 1u), piece = u - l * PU;  // PU is PP or PP + 1
         const bool valid = l < n3 && piece < PP;
         const unsigned voff = l * ps3 + cell_off + piece * 16u;
         for (unsigned k = gwave; k < nrows; k += GW) {
@@ -675,7 +760,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     for (int m = 0; m < PT; ++m) {
       const unsigned q = (unsigned)m * (unsigned)GT + gtid;
       const unsigned c = (m & 1) ? (cls23[m / 2] >> 16) : (cls23[m / 2] & 0xFFFFu);
-      if (q < count) perm[atomicAdd(&s_hist[c], 1u)] = (unsigned short)q;
+      if (q < count) *perm_at(atomicAdd(&s_hist[c], 1u)) = (unsigned short)q;
     }
     if (STAMPS && gtid == 0) t_stamp[3] = wall_clock64();
 
@@ -714,15 +799,14 @@ k_cubic_column(const CubicColumnArgs<T> a) {
       unsigned jw = ps + draw_row() * 64u;
       if (jw >= pe) continue;
       // dead lanes (the stretch's tail) redo its last point: they keep their wave uniform
-      unsigned q = perm[jw + wl < pe ? jw + wl : pe - 1];
+      unsigned q = *perm_at(jw + wl < pe ? jw + wl : pe - 1);
       RV rec = recs[q];
+      T rcur[4] = {rec[0], rec[1], rec[2], rec[3]};
       for (;;) {
-        const bool live = jw + wl < pe;
         const unsigned orig = index[q];  // used at the very end: its latency hides behind the planes
-        const RV rcur = rec;
         const unsigned jn = ps + draw_row() * 64u;
         if (jn < pe) {  // wave-uniform: next row's record on its way while this row's planes are evaluated
-          q = perm[jn + wl < pe ? jn + wl : pe - 1];
+          q = *perm_at(jn + wl < pe ? jn + wl : pe - 1);
           rec = recs[q];
         }
         T res;
@@ -736,12 +820,12 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           const int rel2 = loc[2] - (int)row0;
           const bool in_rows = rel2 >= 0 && rel2 <= row_top;
           const unsigned a0 = lds_col + ((unsigned)(in_rows ? rel2 : 0) * n3 + (unsigned)loc[3]) * PITCH;
-          if (xf >= 0) res = col_reduce_rect<T, FMA, true>(a0, rowpitch, dim);
-          else res = col_reduce_rect<T, FMA, false>(a0, rowpitch, dim);
+          if (xf >= 0) res = col_reduce_coef_rect<T, FMA>(a0, rowpitch, PITCH, dim);
+          else res = col_reduce_rect<T, FMA>(a0, rowpitch, PITCH, dim);
           // only deliberately mis-binned points (bin_scramble): classes are exact here; in a coefficient
           // column also the points whose arm along dim 0 is not the part's
           const bool arm0 = xf < 0 || (dim[0].sat == xf && !dim[0].linear);
-          if (live && (loc[0] != ci || loc[1] != cj || !in_rows || !arm0)) {
+          if (loc[0] != ci || loc[1] != cj || !in_rows || !arm0) {
             const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
                                    (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
             CubicDimRect<T> dcopy[4];
@@ -761,12 +845,16 @@ k_cubic_column(const CubicColumnArgs<T> a) {
             // num-traits <isize as NumCast>::from: Some iff -2^63 <= floc < 2^63, and `floc - 1` must not
             // overflow isize (floc != -2^63): together |floc| < 2^63 (NaN fails)
             ok &= dev_fabs<T>(floc) < (T)9223372036854775808.0;
-            const T nn2 = (T)(a.n[d] - 2);
+            // (the conversions are redone per row: hoisted out of the persistent loop they sit in
+            // registers the plane loop needs, and spill)
+            int nd = a.n[d];
+            asm volatile("" : "+s"(nd));
+            const T nn2 = (T)(nd - 2);
             // regular.rs:440-442: iloc = floc - 1 clamped to [0, n - 4], in the float domain (exact
             // integers below 2^31; +-inf clamp; NaN -> 0: that point has failed anyway)
             T c = floc - (T)1;
             c = dev_fmax<T>(c, (T)0);
-            c = dev_fmin<T>(c, (T)(a.n[d] - 4));
+            c = dev_fmin<T>(c, (T)(nd - 4));
             const int l = (int)c;
             // regular.rs:445-466 on floc = iloc + 1
             const bool low = floc <= (T)0, high = floc >= nn2;
@@ -790,20 +878,18 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           bool arm0 = true;
           if (xf >= 0) {  // coefficient column (group-uniform): dim 0 is Horner's steps whatever the wave's form there
             if ((forms & 0xCu) == 0) {  // dim 1 interior: the common path
-              res = col_reduce<T, FMA, kFormCoef, true>(a0, rowpitch, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
+              res = col_reduce_coef<T, FMA, true>(a0, rowpitch, PITCH, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
             } else {
-              res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)(forms | 0x100u));
+              res = col_reduce_general<T, FMA>(a0, rowpitch, PITCH, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)(forms | 0x100u));
             }
             // my own arm along dim 0 must be the part's
             arm0 = !dim[0].lin && (xf == kFormNone ? !(dim[0].low || dim[0].high) : (xf == kFormLow ? dim[0].low : dim[0].high));
-          } else if ((forms & 0xFu) == 0) {  // dims 0, 1 interior: the common path, whatever dims 2, 3 are
-            res = col_reduce<T, FMA, kFormNone, true>(a0, rowpitch, dim, 0, (int)((forms >> 4) & 3u), (int)((forms >> 6) & 3u));
-          } else {
-            res = col_reduce_general<T, FMA>(a0, rowpitch, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
+          } else {  // the tiles hold the table values (saturated class of dim 0 under linearised extrapolation; column_coef = 0)
+            res = col_reduce_general<T, FMA>(a0, rowpitch, PITCH, dim[0].tt, dim[1].tt, dim[2].tt, dim[3].tt, cls, (int)forms);
           }
           // not my cell / not my rows (the sorts' estimates and the exact cell disagree on a boundary) / not the
           // part's arm along dim 0: from the table
-          if (live && (loc[0] != ci || loc[1] != cj || !in_rows || !arm0)) {
+          if (loc[0] != ci || loc[1] != cj || !in_rows || !arm0) {
             const unsigned toff = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)loc[3] * a.plane_stride[3] +
                                    (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
             CubicDimRegular<T> dcopy[4];
@@ -816,10 +902,19 @@ k_cubic_column(const CubicColumnArgs<T> a) {
             res = col_slow_point<T, FMA>(rsrc, toff, ps2, ps3, dcopy);
           }
         }
-        if (live) {
-          if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
-          stream_store(a.out + orig, res);
+        if (!ok) atomicMin(a.first_bad, (unsigned long long)(a.index_base + orig));
+        // The next row's record is taken BEFORE this row's results are stored: vmcnt counts in
+        // order, so a wait for the record behind the store would also wait for the 64 scattered
+        // stores to be acknowledged (measured: the waves spent two thirds of a row's time there).
+        // Every lane stores — the dead lanes of the stretch's tail hold copies of its last point
+        // and write the same value to the same address — so that the store is straight-line code
+        // and the compiler can count what is outstanding.
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          rcur[d] = rec[d];
+          asm volatile("" : "+v"(rcur[d]) : : "memory");
         }
+        stream_store(a.out + orig, res);
         if (jn >= pe) break;
         jw = jn;
       }

@@ -41,8 +41,32 @@ hipError_t column_lds_opt_in(const void* kernel, int groups, size_t cu_lds) {
 // of `groups` wave groups; each group keeps the local order of its part (16-bit, 32 points per
 // thread at most) and a sub-column of cpp + 3 tile rows in its share of the CU's LDS.  false: not
 // even one class per phase fits, or the local sort's keys do not.
+static bool column_plan_at_pitch(const GridDesc& g, size_t pitch, ColumnPlan* plan);
+
+// Tiles sit 16 bytes apart in LDS (consecutive tiles on different bank groups: cubic_column.h);
+// where only the bare tile lets a part run in fewer phases — cfg4: the whole 32 x 32 column is
+// 128 KiB bare and 144 KiB padded, beside 24 KiB of local order — the padding goes on rectilinear
+// grids: a phase more costs a fill nothing overlaps, three group barriers and a second ragged end
+// of the row loop; the bank conflicts of sorted points on bare tiles cost LDS cycles.
 bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
+  const size_t elem = g.dtype == kF64 ? 8 : 4;
+  ColumnPlan padded, bare;
+  const bool okp = column_plan_at_pitch(g, 16 * elem + 16, &padded);
+  const bool okb = column_plan_at_pitch(g, 16 * elem, &bare);
+  if (g.cfg.column_pad == 1 && okp) { *plan = padded; return true; }
+  if (g.cfg.column_pad == 0 && okb) { *plan = bare; return true; }
+  // measured (cfg4 shapes, both forms alternating in one process): regular 32^4 0.536 ms padded in
+  // two phases against 0.596 bare in one; rectilinear 0.906 against 0.846 (its nodes cost three
+  // times the arithmetic, the LDS conflicts hide behind it)
+  if (okb && (!okp || (bare.nphase < padded.nphase && g.kind == kRectilinear))) { *plan = bare; return true; }
+  if (okp) { *plan = padded; return true; }
+  return false;
+}
+
+static bool column_plan_at_pitch(const GridDesc& g, size_t pitch, ColumnPlan* plan) {
   ColumnPlan p;
+  p.pitch = (unsigned)pitch;
+  const size_t elem = g.dtype == kF64 ? 8 : 4;
   // compiled shapes: 768 threads as two groups of six waves (the product shape) or as one group;
   // 384 threads as one group; 256 threads as two groups of two waves (tests)
   const int t = g.cfg.column_threads;
@@ -51,8 +75,6 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   if (g.kind == kRectilinear) {  // compiled for the product shape and the small test shape only
     if (p.threads != 256) { p.threads = 768; p.groups = 1; }
   }
-  const size_t elem = g.dtype == kF64 ? 8 : 4;
-  const size_t pitch = 16 * elem + 16;
   const size_t cu_lds = thresholds(g.cfg).column_lds;  // the LDS of a CU: 160 KiB on MI355X
   if (cu_lds < (size_t)p.groups * (kColumnStaticPerGroup + 8192)) return false;
   // rectilinear: the axis image (coordinates + tables of the four axes) sits behind the groups' regions
@@ -67,15 +89,18 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   // at least a quarter of the classes fit a phase (or down to 2048 points)
   unsigned part = (unsigned)(col_per_thread(p.threads / p.groups) * (p.threads / p.groups));
   if (part > kColumnMaxPart) part = kColumnMaxPart;
+  // The local order of a part (16 bits per point) goes into the padding of the sub-column's tiles
+  // first (eight entries per tile; none on bare tiles), what is left behind the sub-column.
+  const size_t pad_entries_per_tile = pitch > 16 * elem ? 8 : 0;
+  auto tail_bytes = [&](int rows, unsigned pts) {
+    const size_t in_pad = (size_t)rows * (size_t)n3 * pad_entries_per_tile;
+    return in_pad >= pts ? (size_t)0 : ((size_t)2 * (pts - in_pad) + 15) / 16 * 16;
+  };
   int rows = 0;
   for (;; part /= 2) {
-    const size_t perm = (2 * (size_t)part + 15) / 16 * 16;
-    rows = 0;
-    if (per_group > perm) {
-      const size_t room = per_group - perm;
-      rows = n2;
-      while (rows >= 4 && sub_bytes(rows) > room) --rows;
-    }
+    rows = n2;
+    while (rows >= 4 && sub_bytes(rows) + tail_bytes(rows, part) > per_group) --rows;
+    if (rows < 4) rows = 0;
     const bool roomy = rows >= n2 || (rows >= 4 && (rows - 3) * 4 >= ncls2);
     if (roomy || part <= 2048) break;
   }
@@ -97,7 +122,8 @@ bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan) {
   while ((long long)ncls2 * q3_of(p.sh3) > kColKeys && p.sh3 < 30) ++p.sh3;
   p.q3 = q3_of(p.sh3);
   if ((long long)ncls2 * p.q3 > kColKeys) return false;
-  p.group_bytes = p.sub_bytes + (unsigned)((2 * (size_t)part + 15) / 16 * 16);
+  p.perm_pad = (unsigned)((size_t)sub_rows * (size_t)n3 * pad_entries_per_tile);
+  p.group_bytes = p.sub_bytes + (unsigned)tail_bytes(sub_rows, part);
   p.lds_bytes = (size_t)p.group_bytes * (size_t)p.groups + p.axes_bytes;
   *plan = p;
   return true;
@@ -169,6 +195,8 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.ax.image_bytes = 0;
   a.axes_lds_off = (unsigned)((size_t)cp.group_bytes * (size_t)cp.groups);
   a.coef = g.cfg.column_coef;
+  a.pitch = cp.pitch;
+  a.perm_pad = cp.perm_pad;
   if (g.kind == kRectilinear) {
     fill_axis_args<T, 4>(g, a.ax);  // offsets, lengths, bucket tables; the kernel stages the image itself
     a.ax.use_rec = 0;

@@ -69,13 +69,17 @@ def main():
         it.set_option("binned", 1)
         it.set_option("column", 1)
         it.set_option("stage_timing", 1)
+        shapes = [int(t) for t in os.environ.get("COEF_THREADS", "768").split(",")]
+        pads = [int(t) for t in os.environ.get("COEF_PAD", "-1").split(",")]
         for rep in range(2):
-            for coef in (0, 1):
+            for coef, threads, pad in ([(0, shapes[0], pads[0])] if "COEF_ONLY" not in os.environ else []) + [(1, t, pd) for t in shapes for pd in pads]:
                 it.set_option("column_coef", coef)
+                it.set_option("column_threads", threads)
+                it.set_option("column_pad", pad)
                 out.fill_(-3.0)
                 ms = timed()
-                st = it.stage_ms() if hasattr(it, "stage_ms") else None
-                print(json.dumps({"n": n, "column_coef": coef, "ms": ms, "stage_ms": st, "kernel": it.kernel_name().replace("interpn::", "")[:60],
+                st = {k: round(v, 4) for k, v in it.stage_ms().items()}
+                print(json.dumps({"n": n, "column_coef": coef, "pad": pad, "ms": ms, "stage_ms": st, "kernel": it.kernel_name().replace("interpn::", "")[:60],
                                   "same": bool(torch.equal(out, ref))}), flush=True)
         it.close()
         del obs, out, ref
