@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint8, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinterpn_hip.so")
+# INTERPN_AMD_LIB: another build of the same library (A/B measurements of compiler flags, tools/)
+LIB_PATH = os.environ.get("INTERPN_AMD_LIB") or os.path.join(_HERE, "libinterpn_hip.so")
 
 # interpn_hip_status (include/interpn_hip.h)
 OK = 0

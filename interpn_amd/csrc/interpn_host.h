@@ -43,6 +43,7 @@ struct LaunchConfig {
   int column_groups = 1;    // column evaluation: independent wave groups inside the workgroup (768 threads: 1 or 2; measured on cfg4: 0.74 ms with one group, 0.79 with two — the set-up two groups hide from each other costs less than the coarser end of the launch; cubic_column.h)
   int scatter_staged = 1;   // column evaluation's sort: stage a chunk's records in LDS in bin order and copy them out linearly (1) or store every record directly (0)
   int column_coef = 1;      // column evaluation: dim 0 by per-part Hermite coefficients (cubic_column.h "Coefficient columns"; 0: every node from the table values, the round-3/4 form)
+  int column_tail = 0x84;   // column evaluation: the last 1 / (v >> 4) of the bins are cut (v & 15) times finer, so that the launch ends in small pieces (0: all bins whole)
   int column_pad = -1;      // column evaluation: LDS tiles 16 bytes apart (1), bare (0), or bare where that saves phases (-1)
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
   long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)

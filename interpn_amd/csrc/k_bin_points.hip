@@ -33,6 +33,7 @@ struct BinParams {
   int nbins;
   int mult;
   int classes;  // 1: bins are saturation classes (BinPlan::classes), 0: footprint cells >> shift
+  int tail_den, tail_div;  // column evaluation: the last 1 / tail_den of the bins are cut tail_div times finer (k_bin_scan)
   int scramble; // testing: every 5th point is put into the NEXT bin (the key is only a locality hint: results must not change)
   // rectilinear classes (BinPlan::rect): axes 0, 1 as the kernels search them
   int rect;
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
 // work list of the column kernel (cubic_column.h): a bin of c points is cut into
 // ceil(c / part_points) parts, part_prefix[b] = parts in front of bin b, part_prefix[nbins] = all.
 __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals, unsigned* __restrict__ cursor, int nbins,
-                                                   unsigned* __restrict__ part_prefix, unsigned part_points) {
+                                                   unsigned* __restrict__ part_prefix, unsigned part_points, int tail_den, int tail_div) {
   constexpr int BPT = kMaxBins / 1024;  // consecutive bins per thread
   __shared__ unsigned s[1024];
   __shared__ unsigned sp[1024];
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals
     // is cut four times finer (never below 1024 points), so that the launch ends in small pieces
     // (a whole bin is 1/4 of a workgroup's share of cfg4: the end of the launch idled 8 % of the CU time).
     unsigned pp = part_points;
-    if (pp && b >= nbins - nbins / 5) pp = pp / 4 > 1024u ? pp / 4 : (pp < 1024u ? pp : 1024u);
+    if (pp && tail_den > 0 && b >= nbins - nbins / tail_den) pp = pp / (unsigned)tail_div > 1024u ? pp / (unsigned)tail_div : (pp < 1024u ? pp : 1024u);
     parts[k] = pp ? (mine[k] + pp - 1u) / pp : 0u;
     sum += mine[k];
     sump += parts[k];
@@ -487,7 +488,7 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
   const unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
   hipLaunchKernelGGL(k_bin_hist<T>, dim3(hblocks), dim3(kBlock), 0, stream, a.obs[0], a.obs[1], npts, p, totals);
   mark(1);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points, p.tail_den, p.tail_div);
   mark(2);
   if (extras) {
     if constexpr (N == 4) {
@@ -604,6 +605,8 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.mult = plan.mult;
   p.classes = plan.classes;
   p.scramble = g.cfg.bin_scramble;
+  p.tail_den = g.cfg.column_tail >> 4;
+  p.tail_div = (g.cfg.column_tail & 15) ? (g.cfg.column_tail & 15) : 1;
   p.rect = plan.rect;
   for (int d = 0; d < 2; ++d) {
     p.axis_g[d] = plan.axis_g[d];
