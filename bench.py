@@ -287,6 +287,15 @@ def cubic4_bound(row, P, kernel_stage_ms, unsorted_ms, spec):
         "l2_line_floor_ms": round(P * 16 / L2_HIT_LINES_PER_S * 1e3, 4),
         "l2_miss_line_floor_ms": round(P * 16 / L2_MISS_LINES_PER_S * 1e3, 4),
         "lds_floor_ms": round(P * gather_bytes / (256 * 256 * 2.35e9) * 1e3, 4),
+        # round 4: the column kernel evaluates the 64 dim-0 nodes of a point from per-part Hermite coefficients
+        # (3 fused steps each; the coefficients are computed once per part and tile line: cubic_column.h), so it
+        # issues fewer instructions than the reference's per-point arithmetic, which the next lines still count
+        "valu_f64_instr_per_point_as_evaluated": (64 * 3 + 21 * node_instr) if column else nodes * node_instr,
+        # what the column kernel is bound by instead (profiles/REJECTED.md, ablation row; r04_traffic.json): fabric
+        # requests — per point one 128-B line read for its 32-B record (gathered in the local sort's order), one
+        # partial write for its result, 0.25 line of the record stream, 0.11 line of column fill: ~2.4
+        "fabric_requests_per_point": 2.4 if column else None,
+        "fabric_request_floor_ms": round(P * 2.4 / L2_MISS_LINES_PER_S * 1e3, 4) if column else None,
         "valu_f64_instr_per_point": nodes * node_instr,
         "valu_flop_per_point": nodes * node_flop,
         "valu_floor_ms": round(P / 64 * nodes * node_instr / issue_peak * 1e3, 4),

@@ -1795,7 +1795,14 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     classify with the reference's own cell search, so no point is ever mis-binned by itself — the
     scramble option still forces the out-of-cell path; NaN / inf coordinates never fail there and
     propagate.  The sort's scatter runs in both forms (records staged in LDS in bin order and copied
-    out linearly / stored directly; option `scatter_staged`).  src/multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
+    out linearly / stored directly; option `scatter_staged`).  Round 4, second session: dim 0 from per-part
+    Hermite coefficients (`column_coef`, the default: parts whose dim-0 class is interior, or saturated
+    without linearised extrapolation, rewrite their tile lines as y0, c1, c2, c3 once and evaluate 64 of a
+    point's 85 nodes by Horner's three steps; points whose own arm is not the part's — mis-binned ones,
+    extrapolating ones under `linearize` — come from the table in global memory) against every node from
+    the table values (`column_coef` 0), LDS tiles padded or bare (`column_pad`: the local order then lives
+    in the padding or behind the column), the bins' tail cut (`column_tail`).
+    src/multicubic/regular.rs:325-623, rectilinear.rs:265-545, mod.rs:72-117."""
     import torch
 
     import interpn_amd
@@ -1803,16 +1810,18 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
     dev = torch.device("cuda:0")
     want_t = torch.float64 if dtype == np.float64 else torch.float32
-    for nobs, threads, part, scramble, cpp in ((1, 768, 0, 0, 0), (700, 384, 0, 0, 2), (5_000, 768, 0, 1, 1), (40_001, 256, 2048, 0, 3),
-                                               (40_001, 768, 1, 1, 0), (250_013, 384, 0, 0, 1), (250_013, 768, 0, 0, 0),
-                                               (250_014, 768, 3000, 1, 2)):
+    for case_no, (nobs, threads, part, scramble, cpp) in enumerate(((1, 768, 0, 0, 0), (700, 384, 0, 0, 2), (5_000, 768, 0, 1, 1),
+                                                                     (40_001, 256, 2048, 0, 3), (40_001, 768, 1, 1, 0), (250_013, 384, 0, 0, 1),
+                                                                     (250_013, 768, 0, 0, 0), (250_014, 768, 3000, 1, 2))):
         lin = bool((nobs + threads) % 2)
         case = synthetic_case("cubic", kind, 4, axis, nobs, 9900 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
                               specials=min(axis) >= 8)
         want = run_oracle(oracle, case, True)
         it = _make_interp(interpn_amd, case)
         for k, v in (("binned", 1), ("column", 1), ("column_threads", threads), ("column_part", part), ("bin_scramble", scramble),
-                     ("column_cpp", cpp), ("column_groups", 1 + nobs % 2), ("scatter_staged", (nobs // 7) % 2)):
+                     ("column_cpp", cpp), ("column_groups", 1 + nobs % 2), ("scatter_staged", (nobs // 7) % 2),
+                     ("column_coef", 0 if case_no in (1, 4) else 1), ("column_pad", (-1, 0, 1)[case_no % 3]),
+                     ("column_tail", (0x84, 0, 0x22)[(case_no + 1) % 3])):
             it.set_option(k, v)
         obs = [torch.from_numpy(o).to(dev) for o in case.obs]
         out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)
@@ -1822,7 +1831,7 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
         assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_column<"), it.kernel_name()
         got = out.cpu().numpy()
         same = (got == want) | (np.isnan(got) & np.isnan(want))
-        assert np.all(same), (nobs, threads, part, scramble, cpp, int((~same).sum()))
+        assert np.all(same), (case_no, nobs, threads, part, scramble, cpp, int((~same).sum()))
         assert float(out_full[0]) == -5.0 and float(out_full[-1]) == -5.0  # nothing outside the batch was written
         if kind == "rectilinear" and nobs > 1000:
             # rectilinear grids never fail per point: NaN / inf go through the search (cell 0 / last) and propagate
