@@ -57,7 +57,12 @@
  *                                       first (auto: large 4-D batches; 1: always, N = 2..4; 0: never)
  *       INTERPN_HIP_COLUMN=-1|0|1       sorted 4-D multicubic on a regular grid: evaluate out of an LDS-resident table
  *                                       column (auto: from ~3000 points per bin; 1: wherever it applies; 0: never);
- *                                       INTERPN_HIP_COLUMN_THREADS=512|768|1024, INTERPN_HIP_COLUMN_PART=n (points per workgroup)
+ *                                       INTERPN_HIP_COLUMN_THREADS=256|384|768, INTERPN_HIP_COLUMN_PART=n (points per part at most),
+ *                                       INTERPN_HIP_COLUMN_GROUPS=1|2, INTERPN_HIP_COLUMN_CPP=n (dim-2 classes per K-range phase),
+ *                                       INTERPN_HIP_COLUMN_COEF=0 (every node from the table values; default 1: dim 0 from
+ *                                       per-part Hermite coefficients, cubic_column.h), INTERPN_HIP_COLUMN_PAD=-1|0|1 (LDS tiles
+ *                                       bare / 16 bytes apart), INTERPN_HIP_COLUMN_TAIL=0xDV (the last 1/D of the bins cut V
+ *                                       times finer; default 0x84), INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
  *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)
