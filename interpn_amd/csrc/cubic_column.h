@@ -33,6 +33,16 @@
 //    piece) fixed per instruction slot and the row in the scalar offset: no per-lane division
 //    (round 3's fill divided by n3 per lane and instruction: 13 % of the kernel's VALU work).
 //
+//  * (second session of round 4) COEFFICIENT COLUMNS: all points of a part share the arm of their
+//    64 dim-0 nodes, whose inputs are table values only — the group rewrites the tile lines of the
+//    resident sub-column as the spline's coefficients once, and a point's dim-0 node is Horner's
+//    three steps (section "Coefficient columns" below; 0.79 -> 0.54 ms for cfg4's kernel,
+//    rectilinear 1.74 -> 0.81).  The tile is taken half at a time in f64; the next row's record is
+//    consumed before this row's results are stored (vmcnt counts in order); the local order lives in
+//    the tiles' padding, so that cfg4's padded column (144 KiB) is resident whole.  The kernel is then
+//    at the fabric's request rate — one 128-byte read per point for its gathered record, one partial
+//    write for its result — and its plane loop is 7 % of it (profiles/REJECTED.md, ablation row).
+//
 // Arithmetic, plane order and reduction tree are those of cubic_brick.h / the reference
 // (src/multicubic/regular.rs:325-623): bit-identical results.  A point whose exact cell is not
 // the part's, or whose exact dim-2 rows are not in the phase's sub-column (the sorts estimate
