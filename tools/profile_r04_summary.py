@@ -88,7 +88,7 @@ print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, 
 with open(OUT + "/cfg4_counters.txt", "w") as f:
     f.write("# cfg4 (4-D multicubic-regular 32^4 f64, 1e7 random points): per-launch counter averages (rocprofv3 --pmc, separate passes), summed over the chip.\n")
     f.write("# default = sorted by saturation-class pair of dims 0,1 (k_bin_hist + k_bin_scan + k_bin_scatter_records) and evaluated by the persistent\n")
-    f.write("# LDS-column kernel (k_cubic_column, K-range phases); binned=0 = the tiled kernel on the points as given\n")
+    f.write("# LDS-column kernel (k_cubic_column, dim 0 from per-part Hermite coefficients); binned=0 = the tiled kernel on the points as given\n")
     for mode in (1, 0):
         per = {}
         for i in (1, 2, 3):
