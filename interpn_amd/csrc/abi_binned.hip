@@ -172,10 +172,13 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     // ... and every K-range phase of a part must still hand each wave a row: one workgroup's lanes per bin
     // and phase (64^4, 1e7 points: 2520 points per bin in six phases, 2.62 ms against 2.17 for the tiled kernel
     // on the sorted points; 48^4: 4527 points in three phases, 1.14 against 1.65)
+    // With coefficient columns (second session) a one-phase column pays from one row of the workgroup's
+    // lanes per bin on (32^4: 5e5 points 0.143 against 0.164 ms in place, 1e6 0.163 against 0.167 sorted + tiled,
+    // 2e6 0.218 against 0.286; 24^4: 1e6 0.145 against 0.160; profiles/r04_column_threshold.txt).
     size_t per_bin_min = 2304;
     if (column && cubic_column_plan(*use, &cp0)) {
-      per_bin_min = (size_t)3 * (size_t)cp0.threads;
-      if ((size_t)cp0.nphase * (size_t)cp0.threads > per_bin_min) per_bin_min = (size_t)cp0.nphase * (size_t)cp0.threads;
+      const size_t rows = cp0.nphase == 1 ? 1 : (cp0.nphase > 3 ? (size_t)cp0.nphase : 3);
+      per_bin_min = rows * (size_t)cp0.threads;
     }
     if (g.cfg.column < 0 && per_slice < per_bin_min * (size_t)(g.n[0] - 1) * (size_t)(g.n[1] - 1)) column = false;
   }

@@ -1545,7 +1545,8 @@ def test_cubic_4d_second_table_for_binned_batches(oracle, kind, dtype):
     if kind == "regular" or dtype == np.float32:
         assert (si, sj) != (1, 1)                       # the in-place table is another layout ...
         assert it.get_option("last_binned") == 1        # ... and this batch ran sorted on the second one
-        assert it.kernel_name().endswith(", 1, 1>"), it.kernel_name()
+        # the tiled kernel on the fully overlapped tiles, or (from one row of its lanes per bin on) the column kernel, which is filled from them
+        assert it.kernel_name().endswith(", 1, 1>") or it.kernel_name().startswith("interpn::k_cubic_column<"), it.kernel_name()
     small = [o[:100_000] for o in obs]
     got_small = it.eval_tensors(small).cpu().numpy()
     it.finish()
@@ -1860,8 +1861,9 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
 
 
 def test_column_evaluation_is_chosen_for_large_batches_only(oracle, monkeypatch):
-    """Automatic mode: the column form needs about 3000 points per bin to pay for its column
-    fills; below that the tiled kernel runs on the sorted points (and below 2^19 points the batch
+    """Automatic mode: the column form needs about one row of its workgroup's lanes (768 points) per
+    bin to pay for its column fills (three, or one per K-range phase, where the column is not resident
+    whole); below that the tiled kernel runs on the sorted points (and below 2^19 points the batch
     is not sorted at all).  Every path gives the same bits."""
     import torch
 
@@ -1876,15 +1878,19 @@ def test_column_evaluation_is_chosen_for_large_batches_only(oracle, monkeypatch)
     a = it.eval_tensors(obs)
     it.finish()
     assert it.kernel_name().startswith("interpn::k_cubic_column<")
-    small = [o[:50_000] for o in obs]   # 1 667 per bin: sorted, tiled kernel
+    small = [o[:15_000] for o in obs]   # 500 per bin: sorted, tiled kernel
     b = it.eval_tensors(small)
     it.finish()
     assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_brick<")
+    mid = [o[:50_000] for o in obs]     # 1 667 per bin: the column kernel (one phase)
+    m = it.eval_tensors(mid)
+    it.finish()
+    assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic_column<")
     it.set_option("binned", 0)
     c = it.eval_tensors(obs)
     it.finish()
     assert it.last_path == "in_place"
-    assert torch.equal(a, c) and torch.equal(b, c[:50_000])
+    assert torch.equal(a, c) and torch.equal(b, c[:15_000]) and torch.equal(m, c[:50_000])
     it.close()
 
 
