@@ -306,9 +306,10 @@ __device__ __forceinline__ T col_reduce(unsigned a0, unsigned rowpitch, unsigned
 // Half a tile at a time in f64: the 16-byte pieces 2k + h (k = y0, c1, c2, c3) hold the
 // coefficients of the lines ej = 2h, 2h + 1, so a half is four loads = 16 registers and feeds two
 // of the tile's four dim-0 nodes; the next half (or the next plane's first) is requested before
-// this half's Horner steps.  32 registers of tile data in flight instead of the 64 of col_reduce:
-// what lets the kernel run four waves per SIMD (128 registers).  An f32 tile is four pieces
-// (piece k = coefficient k of all four lines) and is taken whole.
+// this half's Horner steps.  32 registers of tile data in flight instead of the 64 of col_reduce
+// (146 registers, nothing spilled; a 1024-thread shape at 128 registers was measured and is not
+// built: profiles/REJECTED.md).  An f32 tile is four pieces (piece k = coefficient k of all four
+// lines) and is taken whole.
 template <typename T> struct ColHalf {
   static constexpr int EP = 16 / (int)sizeof(T);   // elements per piece: 2 / 4
   static constexpr int H = (int)sizeof(T) == 8 ? 2 : 1;  // halves per tile
