@@ -73,6 +73,7 @@ def main():
         pads = [int(t) for t in os.environ.get("COEF_PAD", "-1").split(",")]
         tails = [int(t, 0) for t in os.environ.get("COEF_TAIL", "0x84").split(",")]
         parts = [int(t) for t in os.environ.get("COEF_PART", "0").split(",")]
+        it.set_option("column_groups", int(os.environ.get("COEF_GROUPS", "1")))
         for rep in range(2):
             for coef, threads, pad, tail, part in ([(0, shapes[0], pads[0], tails[0], 0)] if "COEF_ONLY" not in os.environ else []) + [(1, t, pd, tl, pt) for t in shapes for pd in pads for tl in tails for pt in parts]:
                 it.set_option("column_coef", coef)
