@@ -62,7 +62,10 @@
  *                                       INTERPN_HIP_COLUMN_COEF=0 (every node from the table values; default 1: dim 0 from
  *                                       per-part Hermite coefficients, cubic_column.h), INTERPN_HIP_COLUMN_PAD=-1|0|1 (LDS tiles
  *                                       bare / 16 bytes apart), INTERPN_HIP_COLUMN_TAIL=0xDV (the last 1/D of the bins cut V
- *                                       times finer; default 0x84), INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
+ *                                       times finer; default 0x84), INTERPN_HIP_COLUMN_KEYS=0 (regular grids: the local sort's keys
+ *                                       from the records instead of from the upper eight bits of the index words, where the sort
+ *                                       leaves them by default — slices are then 2^24 points at most),
+ *                                       INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
  *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)

@@ -193,7 +193,8 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
   if (cs != hipStreamCaptureStatusNone) { *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
-  const size_t slice_max = bin_slice_points(g);
+  size_t slice_max = bin_slice_points(g);
+  if (column && column_keys_in_index(*use) && slice_max > kColumnKeySlicePoints) slice_max = kColumnKeySlicePoints;  // 24-bit indices beside the keys
   const size_t slice = npoints < slice_max ? npoints : slice_max;
   interpn_hip_interp::BinSlot* slot =
       take_bin_slot(h, bin_scratch_bytes(g, slice), stream, !(flags & INTERPN_HIP_EVAL_NO_ALLOC), why);
@@ -226,6 +227,10 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       if (g.cfg.column_part > 0 && (size_t)g.cfg.column_part < q) q = (size_t)g.cfg.column_part;
       const size_t max_parts = 4 * (count / q) + (size_t)plan.nbins + 1;  // upper bound (the scan cuts the last bins finer)
       BinExtras extras;
+      if (column_keys_in_index(*use) && count <= kColumnKeySlicePoints && cplan.q3 * (g.n[2] - 1) <= 256) {
+        extras.key_q3 = cplan.q3;
+        extras.key_sh3 = cplan.sh3;
+      }
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage, slot->totals_clean);
       slot->totals_clean = err == hipSuccess;
       if (err != hipSuccess) break;

@@ -95,6 +95,10 @@ struct CubicColumnArgs {
   // LDS bytes from tile to tile: the tile + 16 (see the head of this file), or the bare tile where
   // only that lets the whole column fit (one phase per part instead of two: k_cubic_column.hip)
   unsigned pitch;
+  // 1: the sort left every point's local sort key in the upper eight bits of its index word
+  // (k_bin_points.hip::column_key; regular grids, slices of at most 2^24 points): the local sort's
+  // first pass reads those 4 bytes per point instead of the 32-byte records
+  int index_keys;
 };
 
 constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
@@ -598,6 +602,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
   };
 
   const unsigned gtid_k = tid - grp * (unsigned)GT;
+  const unsigned index_mask = a.index_keys ? 0x00FFFFFFu : 0xFFFFFFFFu;
   for (;;) {
     // Per-part copies of the thread ids that the optimiser cannot see through: everything derived
     // from them (16 record addresses, fill offsets, ...) is then recomputed per part instead of
@@ -707,7 +712,22 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     constexpr int HB = PT / NB;
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
-      if (h == 1 && (unsigned)HB * (unsigned)GT >= count) {  // group-uniform: nothing in the second batch
+      if (a.index_keys) {  // group-uniform: the keys come with the index words
+        unsigned ck[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+          const unsigned q = (unsigned)(h * HB + m) * (unsigned)GT + gtid;
+          ck[m] = q < count ? index[q] >> 24 : 0u;
+        }
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+          const unsigned q = (unsigned)(h * HB + m) * (unsigned)GT + gtid;
+          const int mm = h * HB + m;
+          if (mm & 1) cls23[mm / 2] |= ck[m] << 16;
+          else cls23[mm / 2] = ck[m];
+          if (q < count) atomicAdd(&s_hist[ck[m]], 1u);
+        }
+      } else if (h == 1 && (unsigned)HB * (unsigned)GT >= count) {  // group-uniform: nothing in the second batch
 #pragma unroll
         for (int m = 0; m < HB / 2; ++m) cls23[HB / 2 + m] = 0;
       } else {
@@ -814,7 +834,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
       RV rec = recs[q];
       T rcur[4] = {rec[0], rec[1], rec[2], rec[3]};
       for (;;) {
-        const unsigned orig = index[q];  // used at the very end: its latency hides behind the planes
+        const unsigned orig = index[q] & index_mask;  // used at the very end: its latency hides behind the planes
         const unsigned jn = ps + draw_row() * 64u;
         if (jn < pe) {  // wave-uniform: next row's record on its way while this row's planes are evaluated
           q = *perm_at(jn + wl < pe ? jn + wl : pe - 1);

@@ -44,6 +44,7 @@ struct LaunchConfig {
   int scatter_staged = 1;   // column evaluation's sort: stage a chunk's records in LDS in bin order and copy them out linearly (1) or store every record directly (0)
   int column_coef = 1;      // column evaluation: dim 0 by per-part Hermite coefficients (cubic_column.h "Coefficient columns"; 0: every node from the table values, the round-3/4 form)
   int column_tail = 0x84;   // column evaluation: the last 1 / (v >> 4) of the bins are cut (v & 15) times finer, so that the launch ends in small pieces (0: all bins whole)
+  int column_keys = 1;      // column evaluation on regular grids: the sort leaves every point's local-sort key (8 bits) in the upper bits of its index word, so that the column kernel's local sort reads 4 bytes per point instead of the 32-byte record (0: keys from the records, 10 bits)
   int column_pad = -1;      // column evaluation: LDS tiles 16 bytes apart (1), bare (0), or bare where that saves phases (-1)
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
   long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)
@@ -279,6 +280,10 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool cl
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points);
 // What the column evaluation (cubic_column.h) gets from the sort.
 struct BinExtras {
+  // in: the column kernel's local sort key of a point, class of dim 2 * key_q3 + (class of dim 3 >> key_sh3)
+  // (ColumnPlan::q3 / sh3, < 256), rides in the upper eight bits of its index word (slices of at most
+  // 2^24 points); key_q3 = 0: plain indices
+  int key_q3 = 0, key_sh3 = 0;
   const void* records = nullptr;          // the slice's points in bin order, one N-element record each
   const unsigned* bin_end = nullptr;      // end of every bin in sorted order
   const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
@@ -313,6 +318,9 @@ struct ColumnPlan {
   size_t lds_bytes = 0;      // dynamic LDS of a workgroup
 };
 bool cubic_column_plan(const GridDesc& g, ColumnPlan* plan);
+// the sort writes the local-sort keys into the index words (regular grids; option column_keys)
+inline bool column_keys_in_index(const GridDesc& g) { return g.cfg.column_keys != 0 && g.kind == kRegular; }
+constexpr size_t kColumnKeySlicePoints = (size_t)1 << 24;  // then an index has 24 bits
 template <typename T>
 hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
                                T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,

@@ -33,6 +33,12 @@ struct BinParams {
   int nbins;
   int mult;
   int classes;  // 1: bins are saturation classes (BinPlan::classes), 0: footprint cells >> shift
+  // the column kernel's local sort key (cubic_column.h; regular grids): class of dim 2 * key_q3 +
+  // (class of dim 3 >> key_sh3) < 256, classes as col_class_hint estimates them; stored in the upper
+  // eight bits of the point's index word.  key_q3 = 0: off.
+  int key_q3, key_sh3;
+  double kstart[2], kscale[2];
+  int kclasses[2];
   int tail_den, tail_div;  // column evaluation: the last 1 / tail_den of the bins are cut tail_div times finer (k_bin_scan)
   int scramble; // testing: every 5th point is put into the NEXT bin (the key is only a locality hint: results must not change)
   // rectilinear classes (BinPlan::rect): axes 0, 1 as the kernels search them
@@ -94,6 +100,14 @@ __device__ __forceinline__ int bin_key(const BinParams& p, T x0, T x1) {
   // evaluation costs differ on rectilinear grids (saturation branches): without the scramble the
   // XCDs holding the first and last rows of cells finished 15 % late.
   return (c0 * p.nb1 + c1) * p.mult % p.nbins;
+}
+
+// local sort key of the column kernel (BinParams::key_q3), < 256
+template <typename T>
+__device__ __forceinline__ unsigned column_key(const BinParams& p, T x2, T x3) {
+  const int h2 = bin_class((double)x2, p.kstart[0], p.kscale[0], p.kclasses[0]);
+  const int h3 = bin_class((double)x3, p.kstart[1], p.kscale[1], p.kclasses[1]);
+  return (unsigned)(h2 * p.key_q3 + (h3 >> p.key_sh3)) & 255u;
 }
 
 // the key the sort uses for point i (testing option `scramble`: see BinParams)
@@ -345,7 +359,11 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const Scat
 #pragma unroll
       for (int d = 0; d < N; ++d) r[d] = x[it][d];
       recs[pos] = r;
-      a.index[pos] = (unsigned)(first + l);
+      unsigned ix = (unsigned)(first + l);
+      if constexpr (N == 4) {
+        if (a.p.key_q3) ix |= column_key<T>(a.p, x[it][2], x[it][3]) << 24;
+      }
+      a.index[pos] = ix;
     }
   }
 }
@@ -366,10 +384,10 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(con
   constexpr int kIters = CH / kScatThreads;
   typedef T RV __attribute__((ext_vector_type(N)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_sc[];
+  static_assert(CH <= 4096 && kScatThreads <= 1024, "meta word: 10 bits of bin, 8 of column key, 12 of local index");
   RV* const lrec = reinterpret_cast<RV*>(smem_sc);                                        // [CH] records in bin order
-  unsigned short* const lsrc = reinterpret_cast<unsigned short*>(smem_sc + (size_t)CH * sizeof(RV));  // [CH] local index of the point
-  unsigned short* const lkey = lsrc + CH;                                                  // [CH] its bin
-  unsigned* const fill = reinterpret_cast<unsigned*>(lkey + CH);                           // [nbins] points per bin
+  unsigned* const lmeta = reinterpret_cast<unsigned*>(smem_sc + (size_t)CH * sizeof(RV)); // [CH] bin | column key << 10 | local index << 20
+  unsigned* const fill = lmeta + CH;                                                       // [nbins] points per bin
   const int nbins = a.p.nbins;  // <= kScatThreads
   unsigned* const lstart = fill + nbins;                                                   // first local slot of a bin
   unsigned* const base = lstart + nbins;                                                   // first global slot of this chunk's run
@@ -427,8 +445,11 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(con
 #pragma unroll
       for (int d = 0; d < N; ++d) r[d] = x[it][d];
       lrec[lp] = r;
-      lsrc[lp] = (unsigned short)l;
-      lkey[lp] = key[it];
+      unsigned ck = 0;
+      if constexpr (N == 4) {
+        if (a.p.key_q3) ck = column_key<T>(a.p, x[it][2], x[it][3]);
+      }
+      lmeta[lp] = (unsigned)key[it] | (ck << 10) | (l << 20);
     }
   }
   __syncthreads();
@@ -437,10 +458,11 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(con
   for (int it = 0; it < kIters; ++it) {
     const unsigned j = (unsigned)it * kScatThreads + tid;
     if (j < count) {
-      const unsigned k = lkey[j];
+      const unsigned m = lmeta[j];
+      const unsigned k = m & 1023u;
       const unsigned pos = base[k] + (j - lstart[k]);
       recs[pos] = lrec[j];
-      a.index[pos] = (unsigned)(first + lsrc[j]);
+      a.index[pos] = (unsigned)(first + (m >> 20)) | (((m >> 10) & 255u) << 24);  // key bits are zero without column keys
     }
   }
 }
@@ -615,6 +637,20 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
     p.axis_M[d] = plan.axis_M[d];
     p.axis_g0[d] = plan.axis_g0[d];
     p.axis_scale[d] = plan.axis_scale[d];
+  }
+  p.key_q3 = 0;
+  p.key_sh3 = 0;
+  for (int d = 0; d < 2; ++d) { p.kstart[d] = 0; p.kscale[d] = 0; p.kclasses[d] = 1; }
+  if (extras && extras->key_q3 > 0 && g.ndims == 4 && g.kind == kRegular && npts <= kColumnKeySlicePoints) {
+    p.key_q3 = extras->key_q3;
+    p.key_sh3 = extras->key_sh3;
+    for (int d = 2; d < 4; ++d) {
+      p.kstart[d - 2] = g.start[d];
+      p.kscale[d - 2] = 1.0 / g.step[d];
+      p.kclasses[d - 2] = g.n[d] - 1;
+    }
+  } else if (extras) {
+    extras->key_q3 = 0;  // tells the launcher: plain indices
   }
 #define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0)
   if (g.dtype == kF64) {

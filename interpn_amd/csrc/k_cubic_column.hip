@@ -119,9 +119,10 @@ static bool column_plan_at_pitch(const GridDesc& g, size_t pitch, ColumnPlan* pl
   // local sort keys: class of dim 2 x (class of dim 3 >> sh3), at most 1024
   p.sh3 = 0;
   auto q3_of = [&](int sh) { return ((n3 - 2) >> sh) + 1; };
-  while ((long long)ncls2 * q3_of(p.sh3) > kColKeys && p.sh3 < 30) ++p.sh3;
+  const long long kmax = column_keys_in_index(g) && ncls2 <= 256 ? 256 : kColKeys;  // 8-bit keys ride in the index words
+  while ((long long)ncls2 * q3_of(p.sh3) > kmax && p.sh3 < 30) ++p.sh3;
   p.q3 = q3_of(p.sh3);
-  if ((long long)ncls2 * p.q3 > kColKeys) return false;
+  if ((long long)ncls2 * p.q3 > kmax) return false;
   p.perm_pad = (unsigned)((size_t)sub_rows * (size_t)n3 * pad_entries_per_tile);
   p.group_bytes = p.sub_bytes + (unsigned)tail_bytes(sub_rows, part);
   p.lds_bytes = (size_t)p.group_bytes * (size_t)p.groups + p.axes_bytes;
@@ -196,6 +197,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.axes_lds_off = (unsigned)((size_t)cp.group_bytes * (size_t)cp.groups);
   a.coef = g.cfg.column_coef;
   a.pitch = cp.pitch;
+  a.index_keys = extras.key_q3 > 0 ? 1 : 0;
   a.perm_pad = cp.perm_pad;
   if (g.kind == kRectilinear) {
     fill_axis_args<T, 4>(g, a.ax);  // offsets, lengths, bucket tables; the kernel stages the image itself

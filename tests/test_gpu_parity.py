@@ -1802,7 +1802,9 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
     point's 85 nodes by Horner's three steps; points whose own arm is not the part's — mis-binned ones,
     extrapolating ones under `linearize` — come from the table in global memory) against every node from
     the table values (`column_coef` 0), LDS tiles padded or bare (`column_pad`: the local order then lives
-    in the padding or behind the column), the bins' tail cut (`column_tail`).
+    in the padding or behind the column), the bins' tail cut (`column_tail`), the local sort's keys taken
+    from the records (10 bits) or from the upper eight bits of the index words, where the sort left them
+    (`column_keys`, regular grids).
     src/multicubic/regular.rs:325-623, rectilinear.rs:265-545, mod.rs:72-117."""
     import torch
 
@@ -1822,7 +1824,7 @@ def test_column_evaluation_of_sorted_4d_multicubic(oracle, monkeypatch, dtype, a
         for k, v in (("binned", 1), ("column", 1), ("column_threads", threads), ("column_part", part), ("bin_scramble", scramble),
                      ("column_cpp", cpp), ("column_groups", 1 + nobs % 2), ("scatter_staged", (nobs // 7) % 2),
                      ("column_coef", 0 if case_no in (1, 4) else 1), ("column_pad", (-1, 0, 1)[case_no % 3]),
-                     ("column_tail", (0x84, 0, 0x22)[(case_no + 1) % 3])):
+                     ("column_tail", (0x84, 0, 0x22)[(case_no + 1) % 3]), ("column_keys", (case_no // 2) % 2)):
             it.set_option(k, v)
         obs = [torch.from_numpy(o).to(dev) for o in case.obs]
         out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)

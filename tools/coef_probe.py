@@ -74,9 +74,11 @@ def main():
         tails = [int(t, 0) for t in os.environ.get("COEF_TAIL", "0x84").split(",")]
         parts = [int(t) for t in os.environ.get("COEF_PART", "0").split(",")]
         it.set_option("column_groups", int(os.environ.get("COEF_GROUPS", "1")))
+        keys = [int(t) for t in os.environ.get("COEF_KEYS", "1").split(",")]
         for rep in range(2):
-            for coef, threads, pad, tail, part in ([(0, shapes[0], pads[0], tails[0], 0)] if "COEF_ONLY" not in os.environ else []) + [(1, t, pd, tl, pt) for t in shapes for pd in pads for tl in tails for pt in parts]:
+            for coef, threads, pad, tail, part, ky in ([(0, shapes[0], pads[0], tails[0], 0, 0)] if "COEF_ONLY" not in os.environ else []) + [(1, t, pd, tl, pt, k) for t in shapes for pd in pads for tl in tails for pt in parts for k in keys]:
                 it.set_option("column_coef", coef)
+                it.set_option("column_keys", ky)
                 it.set_option("column_part", part)
                 it.set_option("column_tail", tail)
                 it.set_option("column_threads", threads)
@@ -84,7 +86,7 @@ def main():
                 out.fill_(-3.0)
                 ms = timed()
                 st = {k: round(v, 4) for k, v in it.stage_ms().items()}
-                print(json.dumps({"n": n, "column_coef": coef, "pad": pad, "tail": hex(tail), "part": part, "ms": ms, "stage_ms": st, "kernel": it.kernel_name().replace("interpn::", "")[:60],
+                print(json.dumps({"n": n, "column_coef": coef, "pad": pad, "tail": hex(tail), "part": part, "keys": ky, "ms": ms, "stage_ms": st, "kernel": it.kernel_name().replace("interpn::", "")[:60],
                                   "same": bool(torch.equal(out, ref))}), flush=True)
         it.close()
         del obs, out, ref

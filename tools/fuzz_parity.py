@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -125,6 +125,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 if rng.random() < 0.25: env["INTERPN_HIP_COLUMN_COEF"] = "0"
                 if rng.random() < 0.5: env["INTERPN_HIP_COLUMN_PAD"] = str(int(rng.integers(0, 2)))
                 if rng.random() < 0.4: env["INTERPN_HIP_COLUMN_TAIL"] = str(int(rng.choice([0, 0x22, 0x54, 0x1f])))
+                if rng.random() < 0.4: env["INTERPN_HIP_COLUMN_KEYS"] = "0"
             if kind == "rectilinear" and rng.random() < 0.3: env["INTERPN_HIP_AXIS_RECORDS"] = "0"
             # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
             if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
