@@ -293,10 +293,10 @@ def cubic4_bound(row, P, kernel_stage_ms, unsorted_ms, spec):
         "valu_f64_instr_per_point_as_evaluated": (64 * 3 + 21 * node_instr) if column else nodes * node_instr,
         # what the column kernel is bound by instead (profiles/REJECTED.md, ablation row; r04_traffic.json): fabric
         # requests — per point one 128-B line read for its 32-B record (gathered in the local sort's order), one
-        # partial write for its result, 0.25 line of the record stream, 0.11 line of column fill: 2.27 measured
-        # (TCC_EA0_RDREQ 1.23e7 + TCC_EA0_WRREQ 1.04e7 per 1e7 points)
-        "fabric_requests_per_point": 2.27 if column else None,
-        "fabric_request_floor_ms": round(P * 2.27 / L2_MISS_LINES_PER_S * 1e3, 4) if column else None,
+        # partial write for its result, 0.11 line of column fill: 2.04 measured
+        # (TCC_EA0_RDREQ 1.00e7 + TCC_EA0_WRREQ 1.03e7 per 1e7 points, profiles/r04_traffic.json)
+        "fabric_requests_per_point": 2.04 if column else None,
+        "fabric_request_floor_ms": round(P * 2.04 / L2_MISS_LINES_PER_S * 1e3, 4) if column else None,
         "valu_f64_instr_per_point": nodes * node_instr,
         "valu_flop_per_point": nodes * node_flop,
         "valu_floor_ms": round(P / 64 * nodes * node_instr / issue_peak * 1e3, 4),
