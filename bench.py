@@ -488,7 +488,14 @@ def committed_config_traffic(row, spec):
                 if row["kernel"].split("::")[-1].split("<")[0] == k:
                     main = {c: d[c] for c in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum",
                                               "TCC_EA0_WRREQ_64B_sum") if c in d}
-            return {"fabric_bytes_per_evaluation": e["fabric_bytes_per_evaluation"],
+            # fabric REQUESTS (128-byte reads, 64-/32-byte writes) of all the evaluation's kernels, and the rate this run's time
+            # makes of them: every BASELINE configuration sits at 5.2-5.8e10 requests/s, the part's random-line rate
+            # (cfg4, whose writes are partial lines: 4e10)
+            reqs = sum(d.get("TCC_EA0_RDREQ_sum", 0.0) + d.get("TCC_EA0_WRREQ_sum", 0.0) for d in e.get("kernels", {}).values())
+            return {"fabric_requests_per_evaluation": round(reqs) if reqs else None,
+                    "fabric_requests_per_point": round(reqs / row["points"], 3) if reqs else None,
+                    "fabric_requests_per_s_at_this_runs_time": round(reqs / (row["kernel_ms"] * 1e-3), -8) if reqs and row.get("kernel_ms") else None,
+                    "fabric_bytes_per_evaluation": e["fabric_bytes_per_evaluation"],
                     "fabric_read_bytes": e["fabric_read_bytes_per_evaluation"], "fabric_write_bytes": e["fabric_write_bytes_per_evaluation"],
                     "algorithmic_bytes": e["algorithmic_bytes"], "ratio_to_algorithmic": e["ratio_to_algorithmic"],
                     "evaluation_kernel_tcc": main, "measured_in_this_run": False,
