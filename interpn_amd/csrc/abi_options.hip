@@ -129,6 +129,18 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
     for (const auto& r : ro)
       if (!strcmp(name, r.nm)) { *value = r.v; return INTERPN_HIP_OK; }
   }
+  if (!strncmp(name, "col_", 4)) {  // read-only: how the column evaluation would run on this grid with the present options (k_cubic_column.hip)
+    ColumnPlan cp;
+    const bool ok = h->desc.method == kCubic && h->desc.ndims == 4 && cubic_column_plan(h->desc, &cp);
+    const struct { const char* nm; long long v; } ro[] = {
+        {"col_applies", ok ? 1 : 0}, {"col_nphase", ok ? cp.nphase : 0}, {"col_cpp", ok ? cp.cpp : 0}, {"col_pitch", ok ? (long long)cp.pitch : 0},
+        {"col_lds_bytes", ok ? (long long)cp.lds_bytes : 0}, {"col_part_points", ok ? (long long)cp.part_points : 0},
+        {"col_perm_pad", ok ? (long long)cp.perm_pad : 0}, {"col_q3", ok ? cp.q3 : 0}, {"col_sh3", ok ? cp.sh3 : 0},
+        {"col_threads", ok ? cp.threads : 0}, {"col_groups", ok ? cp.groups : 0}};
+    for (const auto& r : ro)
+      if (!strcmp(name, r.nm)) { *value = r.v; return INTERPN_HIP_OK; }
+    return INTERPN_HIP_ERR_INVALID_ARGUMENT;
+  }
   if (!strcmp(name, "evals_binned")) { *value = h->evals_binned.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }

@@ -1110,6 +1110,39 @@ def test_thresholds_are_derived_from_the_device(oracle):
     it.close()
 
 
+def test_column_plan_fits_the_lds(oracle):
+    """How the column evaluation lays a grid's (k, l) column of tiles out in LDS (k_cubic_column.hip::
+    cubic_column_plan, read back through the col_* options): never more than a CU's LDS; cfg4's 32 x 32
+    f64 column (144 KiB with 16 bytes of padding per tile) is resident whole — the local order of a
+    12 288-point part sits in the padding (8 entries per tile) and 8 KiB behind the column —; f32 tiles are
+    80 bytes apart; 48^4 takes three K-range phases; bare tiles (column_pad 0) and 8-bit local sort keys."""
+    import interpn_amd
+
+    rng = np.random.default_rng(5)
+    for n, dtype in ((32, np.float64), (32, np.float32), (48, np.float64), (8, np.float64)):
+        g = np.linspace(-1.0, 1.0, n)
+        it = interpn_amd.Interpolator.regular("cubic", [n] * 4, np.full(4, -1.0, dtype=dtype), np.full(4, g[1] - g[0], dtype=dtype),
+                                              rng.uniform(-1, 1, n**4).astype(dtype), False, 0, dtype)
+        assert it.get_option("col_applies") == 1
+        lds_cu = it.get_option("dev_lds_per_cu")
+        elem = 8 if dtype == np.float64 else 4
+        for pad in (-1, 1, 0):
+            it.set_option("column_pad", pad)
+            pitch, nphase, cpp = it.get_option("col_pitch"), it.get_option("col_nphase"), it.get_option("col_cpp")
+            assert it.get_option("col_lds_bytes") + 4352 * it.get_option("col_groups") <= lds_cu
+            assert pitch == (16 * elem if pad == 0 else 16 * elem + 16)
+            assert nphase * cpp >= n - 1 and (nphase - 1) * cpp < n - 1
+            assert it.get_option("col_perm_pad") == (0 if pad == 0 else 8 * n * (n if nphase == 1 else min(n, cpp + 3)))
+            assert it.get_option("col_q3") * (n - 1) <= 256  # keys ride in the index words of regular grids
+        it.set_option("column_pad", -1)
+        if lds_cu == 160 << 10:
+            assert it.get_option("col_nphase") == (3 if n == 48 else 1)
+            assert it.get_option("col_part_points") == 12288
+        it.set_option("column_keys", 0)
+        assert 1 <= it.get_option("col_q3") and it.get_option("col_q3") * (n - 1) <= 1024
+        it.close()
+
+
 @pytest.mark.parametrize("method,kind,axis", [("linear", "regular", [20, 21, 22]), ("linear", "rectilinear", [33, 9, 40]),
                                               ("cubic", "rectilinear", [9, 8, 7]), ("linear", "regular", [9, 8, 7, 6]),
                                               ("nearest", "rectilinear", [300, 40])])
