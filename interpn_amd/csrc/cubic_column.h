@@ -66,6 +66,7 @@ struct CubicColumnArgs {
   const unsigned* bin_end;      // end of bin b in sorted order (the scatter's cursors after the scatter)
   const unsigned* part_prefix;  // parts in front of bin b; [nbins] = total
   unsigned* work;               // next part to hand out (zeroed by the sort's scan kernel)
+  const unsigned* bin_flags;    // linearised extrapolation: one bit per sorted bin, set by the sort if any of its points lies outside the grid along dim 0 (a hint); else null
   int nbins;
   int nb1;                   // classes along dim 1 (n1 - 1)
   unsigned inv_mult;         // sorted bin b holds class pair (b * inv_mult) % nbins
@@ -655,10 +656,14 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     // shares along dim 0, or -1: the tiles keep the table values.  The saturated classes hold
     // points inside and outside the grid alike; with linearised extrapolation the outside ones
     // have no spline, so those parts keep the values.
+    // ... unless the sort saw none of the bin's points outside (a.bin_flags: the usual case, points
+    // inside the grid): then the saturated arm's spline serves all of them; a point that extrapolates
+    // after all (the flag is a hint) goes to the table in global memory like any point off its part's arm.
     int xf = -1;
     if (a.coef) {
       if (c0 > 0 && c0 < a.n[0] - 2) xf = kFormNone;
       else if (!a.linearize) xf = c0 == 0 ? kFormLow : kFormHigh;
+      else if (a.bin_flags && ((a.bin_flags[(unsigned)bin >> 5] >> ((unsigned)bin & 31u)) & 1u) == 0) xf = c0 == 0 ? kFormLow : kFormHigh;
     }
     // tile lines (v[ei][ej], ei = 0..3) of `nrows` rows -> (y0, c1, c2, c3)[ej], in place
     auto to_coef = [&](unsigned nrows) {

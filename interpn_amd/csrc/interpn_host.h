@@ -288,6 +288,7 @@ struct BinExtras {
   const unsigned* bin_end = nullptr;      // end of every bin in sorted order
   const unsigned* part_prefix = nullptr;  // work list: parts in front of every bin, [nbins] = total
   unsigned* work = nullptr;               // the column kernel's part counter (zeroed by the scan)
+  const unsigned* bin_flags = nullptr;    // one bit per bin: some point of it lies outside the grid along dim 0 (written only under linearised extrapolation)
 };
 // Sort `npts` points (one slice) into `scratch`; returns the sorted coordinate arrays and the
 // original indices (within the slice).  `stage` (optional, 4 events): recorded in front of the

@@ -39,6 +39,7 @@ struct BinParams {
   int key_q3, key_sh3;
   double kstart[2], kscale[2];
   int kclasses[2];
+  int flag_outside;  // column evaluation with linearised extrapolation: note per bin whether any of its points lies outside the grid along dim 0 (ScatterArgs::flags)
   int tail_den, tail_div;  // column evaluation: the last 1 / tail_den of the bins are cut tail_div times finer (k_bin_scan)
   int scramble; // testing: every 5th point is put into the NEXT bin (the key is only a locality hint: results must not change)
   // rectilinear classes (BinPlan::rect): axes 0, 1 as the kernels search them
@@ -110,6 +111,14 @@ __device__ __forceinline__ unsigned column_key(const BinParams& p, T x2, T x3) {
   return (unsigned)(h2 * p.key_q3 + (h3 >> p.key_sh3)) & 255u;
 }
 
+// Does x lie outside the grid along dim 0?  A hint (the uniform grid over the axis' span, rounding
+// at the ends): a bin flagged without need keeps the table values in the column kernel, a point
+// missed here goes to the table in global memory there — either way the same bits.  NaN: outside.
+__device__ __forceinline__ bool bin_outside0(const BinParams& p, double x0) {
+  const double u = (x0 - p.start[0]) * p.scale[0];
+  return !(u >= 0.0 && u <= (double)p.ncell[0]);
+}
+
 // the key the sort uses for point i (testing option `scramble`: see BinParams)
 template <typename T>
 __device__ __forceinline__ int bin_key_at(const BinParams& p, T x0, T x1, size_t i) {
@@ -171,6 +180,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan(unsigned* __restrict__ totals
     sump += parts[k];
   }
   if (t == 0) totals[3 * kMaxBins + 16] = 0;  // the column kernel's part counter (cubic_column.h)
+  if (t < kMaxBins / 32) totals[3 * kMaxBins + 64 + t] = 0;  // one bit per bin: points outside the grid along dim 0 (set by the records scatter)
   s[t] = sum;
   sp[t] = sump;
   __syncthreads();
@@ -203,6 +213,7 @@ struct ScatterArgs {
   unsigned* index;
   T* records;      // optional: the sorted points as N-element records (array of structures) instead of `binned`
   unsigned* cursor;
+  unsigned* flags;  // one bit per bin (records forms, BinParams::flag_outside), zeroed by k_bin_scan
   size_t npts;
   BinParams p;
 };
@@ -212,7 +223,7 @@ struct ScatterArgs {
 // the first is used: with 256 threads and one load in flight per lane the kernel was bound by
 // memory latency (0.57..0.73 ms per 1e7 4-D points).
 constexpr int kScatThreads = 1024;
-constexpr size_t kStagedLdsMax = 160 * 1024 - 512;  // dynamic LDS of the staged records scatter at most (a CU's LDS less its few static words)
+constexpr size_t kStagedLdsMax = 160 * 1024 - 1024;  // dynamic LDS of the staged records scatter at most (a CU's LDS less its static words: wave sums, outside flags)
 
 // CH = points per workgroup.
 template <typename T, int N, int CH>
@@ -317,9 +328,11 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const Scat
   constexpr int kIters = CH / kScatThreads;
   __shared__ unsigned fill[kMaxBins];
   __shared__ unsigned base[kMaxBins];
+  __shared__ unsigned s_flags[kMaxBins / 32];
   const int nbins = a.p.nbins;
   const unsigned tid = threadIdx.x;
   for (int b = (int)tid; b < nbins; b += kScatThreads) fill[b] = 0;
+  if (tid < kMaxBins / 32) s_flags[tid] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * CH;
   const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
@@ -340,9 +353,14 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records(const Scat
       const int k = bin_key_at<T>(a.p, x[it][0], x[it][1], first + l);
       key[it] = (unsigned short)k;
       rank[it] = (unsigned short)atomicAdd(&fill[k], 1u);
+      if (a.p.flag_outside && bin_outside0(a.p, (double)x[it][0])) {
+        const unsigned w = (unsigned)k >> 5, bit = 1u << ((unsigned)k & 31u);
+        if (!(s_flags[w] & bit)) atomicOr(&s_flags[w], bit);  // the workgroup's own bits first: outside points crowd into a few bins
+      }
     }
   }
   __syncthreads();
+  if (a.p.flag_outside && tid < kMaxBins / 32 && s_flags[tid]) atomicOr(&a.flags[tid], s_flags[tid]);
   for (int b = (int)tid; b < nbins; b += kScatThreads) {
     const unsigned mine = fill[b];
     base[b] = mine ? atomicAdd(&a.cursor[b], mine) : 0u;  // one run per non-empty bin
@@ -392,8 +410,10 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(con
   unsigned* const lstart = fill + nbins;                                                   // first local slot of a bin
   unsigned* const base = lstart + nbins;                                                   // first global slot of this chunk's run
   __shared__ unsigned s_wsum[kScatThreads / 64];
+  __shared__ unsigned s_flags[kMaxBins / 32];
   const unsigned tid = threadIdx.x;
   if ((int)tid < nbins) fill[tid] = 0;
+  if (tid < kMaxBins / 32) s_flags[tid] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * CH;
   const unsigned count = (unsigned)((a.npts - first) < (size_t)CH ? (a.npts - first) : (size_t)CH);
@@ -414,9 +434,14 @@ __global__ void __launch_bounds__(kScatThreads) k_bin_scatter_records_staged(con
       const int k = bin_key_at<T>(a.p, x[it][0], x[it][1], first + l);
       key[it] = (unsigned short)k;
       rank[it] = (unsigned short)atomicAdd(&fill[k], 1u);
+      if (a.p.flag_outside && bin_outside0(a.p, (double)x[it][0])) {
+        const unsigned w = (unsigned)k >> 5, bit = 1u << ((unsigned)k & 31u);
+        if (!(s_flags[w] & bit)) atomicOr(&s_flags[w], bit);  // the workgroup's own bits first: outside points crowd into a few bins
+      }
     }
   }
   __syncthreads();
+  if (a.p.flag_outside && tid < kMaxBins / 32 && s_flags[tid]) atomicOr(&a.flags[tid], s_flags[tid]);
   // exclusive scan of the bin counts (one bin per thread): wave scan + wave totals; one run per non-empty bin
   {
     const unsigned mine = (int)tid < nbins ? fill[tid] : 0u;
@@ -494,8 +519,10 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     extras->bin_end = cursor;  // after the scatter every cursor stands at the end of its bin
     extras->part_prefix = part_prefix;
     extras->work = totals + 3 * kMaxBins + 16;
+    extras->bin_flags = totals + 3 * kMaxBins + 64;
   }
   a.index = idx;
+  a.flags = totals + 3 * kMaxBins + 64;
   a.cursor = cursor;
   a.npts = npts;
   a.p = p;
@@ -627,6 +654,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   p.mult = plan.mult;
   p.classes = plan.classes;
   p.scramble = g.cfg.bin_scramble;
+  p.flag_outside = (extras && g.linearize) ? 1 : 0;
   p.tail_den = g.cfg.column_tail >> 4;
   p.tail_div = (g.cfg.column_tail & 15) ? (g.cfg.column_tail & 15) : 1;
   p.rect = plan.rect;

@@ -179,6 +179,7 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.bin_end = extras.bin_end;
   a.part_prefix = extras.part_prefix;
   a.work = extras.work;
+  a.bin_flags = g.linearize ? extras.bin_flags : nullptr;
   a.nbins = plan.nbins;
   a.nb1 = plan.nb1;
   a.inv_mult = (unsigned)plan.inv_mult;
