@@ -32,6 +32,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"column_cpp", &c.column_cpp, 0, 1 << 20},
       {"column_coef", &c.column_coef, 0, 1},
       {"column_pad", &c.column_pad, -1, 1},
+      {"hist_wgs_per_cu", &c.hist_wgs_per_cu, 0, 64},
       {"column_keys", &c.column_keys, 0, 1},
       {"column_tail", &c.column_tail, 0, 255},
       {"scatter_staged", &c.scatter_staged, 0, 1},
@@ -71,7 +72,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);

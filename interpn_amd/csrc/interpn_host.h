@@ -45,6 +45,7 @@ struct LaunchConfig {
   int column_coef = 1;      // column evaluation: dim 0 by per-part Hermite coefficients (cubic_column.h "Coefficient columns"; 0: every node from the table values, the round-3/4 form)
   int column_tail = 0x84;   // column evaluation: the last 1 / (v >> 4) of the bins are cut (v & 15) times finer, so that the launch ends in small pieces (0: all bins whole)
   int column_keys = 1;      // column evaluation on regular grids: the sort leaves every point's local-sort key (8 bits) in the upper bits of its index word, so that the column kernel's local sort reads 4 bytes per point instead of the 32-byte record (0: keys from the records, 10 bits)
+  int hist_wgs_per_cu = 4;  // the sort's histogram kernel: persistent workgroups per CU, each flushing its counters once (one global atomic per bin and workgroup): cfg4 0.048 -> 0.041 ms (0: one workgroup per 8192-point chunk)
   int column_pad = -1;      // column evaluation: LDS tiles 16 bytes apart (1), bare (0), or bare where that saves phases (-1)
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
   long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)

@@ -133,7 +133,9 @@ __global__ void __launch_bounds__(kBlock) k_bin_hist(const T* __restrict__ x0, c
   __shared__ unsigned hist[kMaxBins];
   for (int b = threadIdx.x; b < p.nbins; b += kBlock) hist[b] = 0;
   __syncthreads();
-  const size_t first = (size_t)blockIdx.x * kHistChunk;
+  // A workgroup walks chunks blockIdx.x, + gridDim.x, ... and flushes its counters once: the flush is one
+  // global atomic per non-empty bin and workgroup, all workgroups onto the same `nbins` words.
+  for (size_t first = (size_t)blockIdx.x * kHistChunk; first < npts; first += (size_t)gridDim.x * kHistChunk)
   // eight rows at a time, all sixteen loads issued before the first key is computed
   for (int it0 = 0; it0 < kHistIters; it0 += 8) {
     T a0[8], a1[8];
@@ -497,7 +499,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 template <typename T, int N>
 hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts, void* scratch, const void** binned_obs,
                         const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream, hipEvent_t* stage,
-                        bool totals_clean, bool staged) {
+                        bool totals_clean, bool staged, unsigned hist_wgs) {
   unsigned char* base = static_cast<unsigned char*>(scratch);
   unsigned* totals = reinterpret_cast<unsigned*>(base);
   unsigned* cursor = totals + kMaxBins;
@@ -534,7 +536,8 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     e = hipMemsetAsync(totals, 0, kMaxBins * sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
   }
-  const unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
+  unsigned hblocks = (unsigned)((npts + kHistChunk - 1) / kHistChunk);
+  if (hist_wgs > 0 && hblocks > hist_wgs) hblocks = hist_wgs;
   hipLaunchKernelGGL(k_bin_hist<T>, dim3(hblocks), dim3(kBlock), 0, stream, a.obs[0], a.obs[1], npts, p, totals);
   mark(1);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, totals, cursor, p.nbins, part_prefix, part_points, p.tail_den, p.tail_div);
@@ -680,7 +683,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   } else if (extras) {
     extras->key_q3 = 0;  // tells the launcher: plain indices
   }
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0)
+#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0, (unsigned)(g.cfg.hist_wgs_per_cu > 0 ? g.cfg.hist_wgs_per_cu * (g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) : 0))
   if (g.dtype == kF64) {
     switch (g.ndims) {
       case 2: GO(double, 2);
