@@ -35,6 +35,31 @@ def shard_bounds(npoints: int, world: int, rank: int) -> tuple[int, int]:
     return lo, hi
 
 
+def device_for_shard(shard: int, ndevices: int) -> int:
+    """Device of shard / handle `shard` for a ONE-process caller that spreads its handles over the
+    GPUs it can see: round-robin, so that R handles on D devices put ceil(R / D) or floor(R / D) on
+    each and shard r and r + D share one (R <= D: one handle per device).  `ndevices` < 1 (no GPU
+    visible, e.g. the CPU test tier) counts as 1."""
+    if shard < 0:
+        raise ValueError("invalid shard")
+    return int(shard) % max(1, int(ndevices))
+
+
+def replicate_across(first, count: int, ndevices: int | None = None):
+    """`count` interpolators for a one-process multi-GPU evaluation: `first` itself, then clones
+    made device to device (`interpn_hip_replicate`: xGMI between GPUs of a node) on the devices
+    `device_for_shard` names, counted from `first`'s own device.  `ndevices` defaults to what the
+    C ABI reports (`interpn_hip_device_count`)."""
+    if count < 1:
+        raise ValueError("count must be >= 1")
+    if ndevices is None:
+        from . import _lib
+
+        ndevices = _lib.load().interpn_hip_device_count()
+    d0 = first.device()
+    return [first] + [first.replicate((d0 + device_for_shard(r, ndevices)) % max(1, ndevices)) for r in range(1, count)]
+
+
 def broadcast_grid(vals, grids=None, src: int = 0):
     """Replicate the grid from `src` to every rank of the default process group (in place).
 

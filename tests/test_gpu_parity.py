@@ -19,6 +19,14 @@ TOL = {("nearest", np.float64): 0.0, ("nearest", np.float32): 0.0, ("linear", np
        ("cubic", np.float32): 1e-6}
 
 
+def _ndev():
+    """GPUs this process can use, as the C ABI counts them (1 on the pool's test boxes, 8 on a node):
+    every multi-handle test spreads its handles over them (interpn_amd.sharded.device_for_shard)."""
+    import interpn_amd
+
+    return max(1, interpn_amd._lib.load().interpn_hip_device_count())
+
+
 def assert_parity(case, got, want):
     dtype = np.dtype(got.dtype).type
     err = rel_err(got, want)
@@ -488,8 +496,10 @@ def test_eval_host_sharded(oracle, method, kind, nhandles):
 
 def test_eval_host_sharded_eight_handles_cfg5_split(oracle):
     """cfg5's split at 1/100 scale through the single-process entry point: a 128^3 grid on one
-    handle, replicated device to device into seven more (`interpn_hip_replicate`; all eight on this
-    box's one GPU), 8e6 points cut into eight contiguous ranges, one host thread per handle.
+    handle, replicated device to device into seven more (`interpn_hip_replicate`; handle i on device
+    i % device_count: all eight on the one GPU of a 1-GPU box, one per GPU — `hipMemcpyPeer` over
+    xGMI, per-device pools, host threads pinned next to their GPU — on an 8-GPU node), 8e6 points
+    cut into eight contiguous ranges, one host thread per handle.
     Bit-identical to the oracle on a sample; a NaN in the LAST range comes back as its global index
     with everything in front of it written (multilinear/regular.rs:277-280)."""
     import interpn_amd
@@ -497,7 +507,10 @@ def test_eval_host_sharded_eight_handles_cfg5_split(oracle):
     n, nobs = 128, 8_000_000
     case = synthetic_case("linear", "regular", 3, [n, n, n], nobs, 55, np.float64, specials=False)
     first = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
-    hs = [first] + [first.replicate(0) for _ in range(7)]
+    from interpn_amd.sharded import replicate_across
+
+    hs = replicate_across(first, 8)
+    assert [h.device() for h in hs] == [i % _ndev() for i in range(8)]
     try:
         got = interpn_amd.eval_host_sharded(hs, case.obs, np.zeros(nobs))
         rng = np.random.default_rng(7)
@@ -522,24 +535,27 @@ def test_eval_host_sharded_eight_handles_cfg5_split(oracle):
 def test_eval_device_sharded(oracle):
     """Device-resident single-process form (`interpn_hip_eval_device_sharded`): every shard's
     coordinates and results live on its handle's device; all shards are enqueued before the first
-    is waited for.  Three clones on this box's one GPU, uneven shards (one of them empty-ish), 4-D
+    is waited for.  Three handles, handle i on device i % device_count (one GPU: all three on it), uneven shards (one of them empty-ish), 4-D
     multicubic so that one shard is large enough to be sorted first: the oracle's bits; a failing
     point in the last shard is reported with its index in shard order; a clean re-run afterwards."""
     import torch
 
     import interpn_amd
 
-    dev = torch.device("cuda:0")
+    from interpn_amd.sharded import replicate_across
+
     for method, kind, nd, axis in (("linear", "rectilinear", 3, [70, 9, 33]), ("cubic", "regular", 4, [6, 7, 5, 6])):
         sizes = [600_000, 3, 150_001]
         total = sum(sizes)
         case = synthetic_case(method, kind, nd, axis, total, 77, np.float64, extrap=0.1, specials=False)
         want = run_oracle(oracle, case, True)
         first = _make_interp(interpn_amd, case)
-        hs = [first, first.replicate(0), first.replicate(0)]
+        hs = replicate_across(first, 3)
+        assert [h.device() for h in hs] == [i % _ndev() for i in range(3)]
         try:
             shards, lo = [], 0
-            for c in sizes:
+            for h, c in zip(hs, sizes):
+                dev = torch.device("cuda", h.device())
                 shards.append([torch.from_numpy(np.ascontiguousarray(o[lo:lo + c])).to(dev) for o in case.obs])
                 lo += c
             outs = interpn_amd.eval_device_sharded(hs, shards)
@@ -1148,8 +1164,9 @@ def test_column_plan_fits_the_lds(oracle):
                                               ("nearest", "rectilinear", [300, 40])])
 def test_replicate_device_to_device(oracle, method, kind, axis):
     """interpn_hip_replicate clones a handle onto a device with a device-to-device copy of the grid
-    (and of the rectilinear axis image) and rebuilds the re-laid table there.  On a 1-GPU box the
-    target is the same device: the clone must own its memory (the source is destroyed first) and
+    (and of the rectilinear axis image) and rebuilds the re-laid table there.  The target is the LAST
+    visible device (another GPU wherever there is one: the copy then crosses xGMI); on a 1-GPU box
+    it is the same device: the clone must own its memory (the source is destroyed first) and
     give the oracle's bits; the pair then serves interpn_hip_eval_host_sharded."""
     import interpn_amd
     from interpn_amd.handle import eval_host_sharded
@@ -1160,7 +1177,8 @@ def test_replicate_device_to_device(oracle, method, kind, axis):
         it = interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals, True)
     else:
         it = interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals, True)
-    clone = it.replicate(0)
+    clone = it.replicate(_ndev() - 1)
+    assert clone.device() == _ndev() - 1 and it.device() == 0
     both = eval_host_sharded([it, clone], case.obs, np.zeros_like(want))
     assert_parity(case, both, want)
     it.close()

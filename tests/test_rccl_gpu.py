@@ -38,13 +38,36 @@ def _last_json(stdout):
     return json.loads(lines[-1])
 
 
+def _visible_gpus():
+    """GPUs of the box (counting them does not initialise HIP in this process)."""
+    import torch
+
+    return max(1, torch.cuda.device_count())
+
+
+def rccl_world_size(ngpus: int) -> int:
+    """Ranks the RCCL tests spawn on a box with `ngpus` GPUs: one per GPU, at most 8 (1 on the
+    pool's single-GPU boxes; the process guard of the GPU boxes allows 6 processes on ONE card, a
+    rank per card is a different matter)."""
+    return max(1, min(int(ngpus), 8))
+
+
 @pytest.mark.gpu
-def test_sharded_path_over_rccl_world_size_1():
-    p = subprocess.run([sys.executable, "-m", "tests.rccl_child"], cwd=ROOT, env=_env(), capture_output=True,
-                       text=True, timeout=600)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
-    rec = _last_json(p.stdout)
-    assert rec["backend"] == "nccl" and rec["world"] == 1
+def test_sharded_path_over_rccl_one_rank_per_gpu():
+    """`min(device_count, 8)` fresh ranks, rank r on GPU r, over the nccl (= RCCL) backend: world size 1
+    on a single-GPU box (the same calls), a real xGMI broadcast + MIN all-reduce on a multi-GPU node."""
+    world = rccl_world_size(_visible_gpus())
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = _env()
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_PORT": str(port)})
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests.rccl_child"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = _drain_together(procs, 600)
+    assert all(p.returncode == 0 for p in procs), [(o[0][-1000:], o[1][-3000:]) for o in outs]
+    rec = _last_json(outs[0][0])
+    assert rec["backend"] == "nccl" and rec["world"] == world
     assert rec["broadcast"] == {"vals": 24**3, "axes": [24, 24, 24]}
     kinds = {c["kind"]: c for c in rec["cases"]}
     assert set(kinds) == {"regular", "rectilinear"}
@@ -129,3 +152,24 @@ def test_bench_single_process_claims_no_broadcast():
     assert cfg["backend"] is None and cfg["process_group"]["initialised"] is False
     assert cfg["grid_broadcast"] is None
     assert "broadcast" not in cfg["sharding"]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_per_gpu_smoke():
+    """`bench.py --gpus N --steps 2` with N = min(device_count, 8) > 1: the driver's multi-GPU command in
+    its spawned form (N fresh ranks over RCCL, grid broadcast, cfg5 block).  Skipped on a single-GPU box,
+    where `test_bench_force_dist_over_rccl_records_what_happened` runs the same calls with one rank."""
+    n = rccl_world_size(_visible_gpus())
+    if n < 2:
+        pytest.skip("one GPU visible: the one-rank form of this test runs instead")
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-configs", "--no-ablate", "--sustain-seconds", "0.05"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    rec = _last_json(p.stdout)
+    assert rec["n_gpus"] == n and rec["config"]["process_group"]["world_size"] == n
+    assert rec["config"]["grid_broadcast"]["collective"] == "broadcast" and rec["scaling"] == "weak"
+    assert rec["value"] > 0

@@ -113,3 +113,35 @@ def test_sharded_equals_single_process(tmp_path, oracle, world):
 
 def test_first_bad_index_is_global_minimum(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+
+
+def test_device_assignment_with_a_faked_device_count():
+    """Where the single-process multi-GPU callers (and the `-m gpu` tests) put handle i: round-robin over
+    the visible devices, counted from the first handle's device — checked here without a GPU: a fake
+    interpolator records the devices `replicate_across` asks `interpn_hip_replicate` for."""
+    from interpn_amd.sharded import device_for_shard, replicate_across
+    from tests.test_rccl_gpu import rccl_world_size
+
+    assert [device_for_shard(i, 1) for i in range(4)] == [0, 0, 0, 0]
+    assert [device_for_shard(i, 8) for i in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    assert [device_for_shard(i, 0) for i in range(3)] == [0, 0, 0]  # no GPU visible counts as one
+    with pytest.raises(ValueError):
+        device_for_shard(-1, 8)
+
+    class Fake:
+        def __init__(self, dev):
+            self.dev = dev
+
+        def device(self):
+            return self.dev
+
+        def replicate(self, device):
+            return Fake(device)
+
+    assert [h.device() for h in replicate_across(Fake(0), 8, ndevices=8)] == list(range(8))
+    assert [h.device() for h in replicate_across(Fake(0), 8, ndevices=1)] == [0] * 8
+    assert [h.device() for h in replicate_across(Fake(0), 3, ndevices=2)] == [0, 1, 0]
+    assert [h.device() for h in replicate_across(Fake(5), 4, ndevices=8)] == [5, 6, 7, 0]
+    with pytest.raises(ValueError):
+        replicate_across(Fake(0), 0, ndevices=8)
+    assert [rccl_world_size(n) for n in (0, 1, 2, 8, 16)] == [1, 1, 2, 8, 8]

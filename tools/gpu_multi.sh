@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: gpurun -- bash tools/gpu_multi.sh <tag> '<cmd 1>' '<cmd 2>' ...   (each under timeout, joined with &&; output per command under gpurun_out/<tag>/)
-R=$GRAFT_REPO_ROOT; TAG=$1; shift; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=${1:?tag}; shift; OUT="$R/gpurun_out/$TAG"; mkdir -p "$OUT"; cd "$R"
 k=0
 for c in "$@"; do
   k=$((k+1))

@@ -2,9 +2,9 @@
 # One GPU-box session: parity tests, the driver's bench commands, the 2-rank path on one GPU.
 # Usage: gpurun --timeout 2400 -- ./tools/gpu_session.sh [tag]
 TAG=${1:-r02g}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is not set)}
 OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
+mkdir -p "$OUT"
 cd $R
 python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt

@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ / LDS counters of k_cubic_column on coefficient columns (tools/coef_probe.py, COEF_ONLY): usage: gpurun -- bash tools/pmc_coef.sh [probe args]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is not set)}
 OUT=$R/gpurun_out/pmc_coef
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 export COEF_ONLY=1
 i=0
 while read -r line; do

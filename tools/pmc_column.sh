@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ / LDS counters of k_cubic_column (and of the tiled kernel on sorted points) from tools/column_probe.py
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is not set)}
 OUT=$R/gpurun_out/pmc_column
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

@@ -2,8 +2,8 @@
 # SQ-side counters (instruction mix, busy / wait cycles, LDS conflicts) of the 3-D linear kernels,
 # regular (cfg2) against rectilinear (cfg3): where do the extra 0.3 ms of cfg3 go?
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq
-rm -rf $OUT && mkdir -p $OUT
+OUT=${GRAFT_REPO_ROOT:?run under gpurun}/gpurun_out/pmc_sq
+rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

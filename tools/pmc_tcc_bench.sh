@@ -2,8 +2,8 @@
 # L2 (TCC) request / hit / miss counts of the benchmark kernel per channel-cycle: how much of the
 # L2's one-request-per-channel-per-clock budget the product kernel uses.
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_tcc_bench
-rm -rf $OUT && mkdir -p $OUT
+OUT=${GRAFT_REPO_ROOT:?run under gpurun}/gpurun_out/pmc_tcc_bench
+rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

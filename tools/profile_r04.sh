@@ -7,9 +7,9 @@
 #   C. cfg4: SQ / LDS counter passes of the sort kernels and k_cubic_column, and of the tiled kernel in place
 # Every rocprofv3 call is wrapped in `timeout`; PMC passes use --kernel-trace only; the program follows `--` directly.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is not set)}
 OUT=$R/gpurun_out/prof_r04
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 PY=python3
 echo "A" ; date
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PY $R/bench.py --steps 20 --warmup 5 > $OUT/stats_bench.json 2> $OUT/stats.err
