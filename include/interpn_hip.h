@@ -271,14 +271,17 @@ int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_
 /* The same evaluation, telling the caller which path it took.
  *   flags        INTERPN_HIP_EVAL_NO_ALLOC: never allocate (scratch that interpn_hip_reserve has
  *                not provided is then a reason to evaluate in place, reported below).
- *   *path_taken  INTERPN_HIP_PATH_IN_PLACE (one kernel on the points as given) or
- *                INTERPN_HIP_PATH_BINNED (points counting-sorted first: 4 launches per slice).
+ *   *path_taken  INTERPN_HIP_PATH_IN_PLACE (one kernel on the points as given),
+ *                INTERPN_HIP_PATH_BINNED (points counting-sorted first: 4 launches per slice) or
+ *                INTERPN_HIP_PATH_SWEEP (3-D f64 multilinear, large batches: one persistent kernel
+ *                whose waves order their points on chip and walk the table in step; 1.25 KiB of
+ *                scratch per stream).
  *   *why         for IN_PLACE on a handle that could bin: the reason (INTERPN_HIP_WHY_*); else 0.
  * Either pointer may be NULL.  The sorted path needs scratch (36 B per point of a slice for 4-D
  * f64, slices of at most 2^25 points): one block per stream that uses the handle concurrently, at
  * most 4; streams beyond that take turns through events.  After interpn_hip_reserve(h, n, k) no
  * evaluation of at most n points on at most k streams allocates anything. */
-enum { INTERPN_HIP_PATH_IN_PLACE = 0, INTERPN_HIP_PATH_BINNED = 1 };
+enum { INTERPN_HIP_PATH_IN_PLACE = 0, INTERPN_HIP_PATH_BINNED = 1, INTERPN_HIP_PATH_SWEEP = 2 };
 enum { INTERPN_HIP_EVAL_NO_ALLOC = 1 };
 enum {
   INTERPN_HIP_WHY_NONE = 0,          /* binned, or binning never applies to this handle */

@@ -303,7 +303,23 @@ int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, si
     h->sync_device_at_destroy = true;
     return st;
   }
-  if (st < 0) {
+  bool swept = false;
+  if (st < 0 && sweep_applies(h->desc, npoints)) {  // 3-D f64 multilinear: the sweep kernel for large batches (linear_sweep.h)
+    int why_sweep = INTERPN_HIP_WHY_NONE;
+    const int ss = eval_device_sweep(h, obs, out, npoints, static_cast<hipStream_t>(stream), flags, &why_sweep);
+    if (why_out) *why_out = why_sweep;
+    if (ss > 0) {
+      std::lock_guard<std::mutex> lk(h->marks_mu);
+      h->sync_device_at_destroy = true;
+      return ss;
+    }
+    swept = ss == 0;
+  }
+  if (swept) {
+    if (path_taken) *path_taken = INTERPN_HIP_PATH_SWEEP;
+    h->desc.last_binned = 0;
+    h->evals_sweep.fetch_add(1);
+  } else if (st < 0) {
     HIP_TRY(launch_any(h->desc, obs, out, npoints, h->first_bad, static_cast<hipStream_t>(stream)));
     if (binned_applies(h->desc, npoints)) {  // handles that can sort: keep the report field honest
       std::lock_guard<std::mutex> lk(h->bin_mu);

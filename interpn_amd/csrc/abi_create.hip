@@ -376,6 +376,7 @@ int interpn_hip_replicate(const interpn_hip_interp* src, int device, interpn_hip
   g.vals = nullptr;
   g.bricks = nullptr;
   g.bricks11 = nullptr;
+  g.sweep_bricks = nullptr;
   g.brick_cell = 0;
   g.rec1_buckets = 0;
   g.axis_image = nullptr;
@@ -447,6 +448,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
   pool_free(h->device, h->grids_owned);
   pool_free(h->device, h->bricks_owned);
   pool_free(h->device, h->bricks11_owned);
+  pool_free(h->device, h->sweep_owned);
   pool_free(h->device, h->vals_owned);
   delete h;
 }

@@ -101,6 +101,7 @@ struct interpn_hip_interp {
   void* grids_owned = nullptr;  // one device allocation holding all rectilinear axes
   void* bricks_owned = nullptr; // bricked copy of vals (3-D multilinear f64)
   void* bricks11_owned = nullptr;  // 4-D multicubic: fully overlapped tiles for binned evaluation when `bricks` is another layout
+  void* sweep_owned = nullptr;     // 3-D f64 multilinear: the sweep evaluation's table when `bricks` is another layout (desc.sweep_bricks)
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
   unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
   std::mutex finish_mu;
@@ -154,7 +155,7 @@ struct interpn_hip_interp {
   std::vector<BinSlot> bin_slots;  // capacity kMaxBinSlots from the start: evaluations hold pointers to elements outside the lock
   unsigned long long bin_uses = 0;
   interpn_hip_interp() { bin_slots.reserve(kMaxBinSlots); }
-  std::atomic<long long> evals_binned{0}, evals_in_place{0}, scratch_allocs{0};
+  std::atomic<long long> evals_binned{0}, evals_in_place{0}, evals_sweep{0}, scratch_allocs{0};
 };
 
 namespace interpn_abi {
@@ -260,6 +261,11 @@ hipError_t wait_status_word(hipStream_t s, const unsigned long long* word);
 
 // abi_binned.hip
 int binned_applies(const GridDesc& g, size_t npoints);
+interpn_hip_interp::BinSlot* take_bin_slot(interpn_hip_interp* h, size_t need, hipStream_t stream, bool may_alloc, int* why);
+
+// abi_sweep.hip
+int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, size_t npoints, hipStream_t stream,
+                      unsigned flags, int* why);
 
 // abi_host.hip
 int ensure_lane(interpn_hip_interp* h, int which, size_t points);

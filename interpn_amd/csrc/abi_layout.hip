@@ -172,7 +172,6 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   if (env && !strcmp(env, "off")) return INTERPN_HIP_OK;
   int si = 0, sj = 0;
   bool cell = false;
-  const size_t MiB = (size_t)1 << 20;
   const size_t esz = g.dtype == kF64 ? 8 : 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
@@ -251,6 +250,37 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   HIP_TRY(build_bricks(g, h->bricks_owned, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   g.bricks = h->bricks_owned;
+  // The table the sweep evaluation of large device-resident batches runs on (linear_sweep.h): the
+  // one just built where the layouts agree, else a second one (64^3 f64: 10.2 MiB beside 5.2).
+  g.sweep_bricks = nullptr;
+  int wi = 0, wj = 0;
+  if (!(env && !strcmp(env, "off")) && sweep_layout(g, &wi, &wj)) {
+    unsigned nbs[3];
+    size_t bsw = 0;
+    brick_geometry(g, wi, wj, nbs, &bsw);
+    if (g.brick_cell == 0 && g.brick_step[0] == wi && g.brick_step[1] == wj) {
+      g.sweep_bricks = g.bricks;
+    } else if (bsw / esz < 0xFFFFFFFFull && bsw <= free_b / 4 && pool_alloc(h->device, &h->sweep_owned, bsw) == hipSuccess) {
+      GridDesc t = g;
+      t.brick_cell = 0;
+      t.brick_step[0] = wi;
+      t.brick_step[1] = wj;
+      for (int k = 0; k < 3; ++k) t.brick_nb[k] = nbs[k];
+      t.brick_nb[3] = 0;
+      HIP_TRY(build_bricks(t, h->sweep_owned, nullptr));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      g.sweep_bricks = h->sweep_owned;
+    } else {
+      (void)hipGetLastError();
+      h->sweep_owned = nullptr;
+    }
+    if (g.sweep_bricks) {
+      g.sweep_step[0] = wi;
+      g.sweep_step[1] = wj;
+      for (int k = 0; k < 3; ++k) g.sweep_nb[k] = nbs[k];
+      g.sweep_table_bytes = bsw;
+    }
+  }
   return INTERPN_HIP_OK;
 }
 

@@ -39,6 +39,8 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"bin_scramble", &c.bin_scramble, 0, 1},
       {"stage_timing", &c.stage_timing, 0, 1},
       {"axis_records", &c.axis_records, 0, 1},
+      {"sweep", &c.sweep, -1, 1},
+      {"sweep_period", &c.sweep_period, 0, 1000000},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -72,7 +74,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble", "sweep", "sweep_period"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -81,8 +83,8 @@ void latch_env(LaunchConfig& c) {
     const char* env = getenv(var);
     if (!env || !*env) continue;
     char* end = nullptr;
-    long long v = strtoll(env, &end, 10);
-    if (end == env) continue;
+    long long v = strtoll(env, &end, 0);  // decimal, 0x.. or 0.. (INTERPN_HIP_COLUMN_TAIL is documented in hex)
+    if (end == env || *end != 0) continue;  // not a number: ignored
     (void)option_access(c, nm, &v, true);  // out-of-range values are ignored, as before
   }
 }
@@ -144,6 +146,9 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
   }
   if (!strcmp(name, "evals_binned")) { *value = h->evals_binned.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "evals_sweep")) { *value = h->evals_sweep.load(); return INTERPN_HIP_OK; }
+  if (!strcmp(name, "sweep_table_bytes")) { *value = h->desc.sweep_bricks ? (long long)h->desc.sweep_table_bytes : 0; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "sweep_layout")) { *value = h->desc.sweep_bricks ? h->desc.sweep_step[0] * 10 + h->desc.sweep_step[1] : 0; return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_bytes")) {
     interpn_hip_interp* hm = const_cast<interpn_hip_interp*>(h);

@@ -50,6 +50,8 @@ struct LaunchConfig {
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
   long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
+  int sweep = -1;          // 3-D f64 multilinear, device-pointer evaluation: the sweep kernel (linear_sweep.h) -1 where it pays, 0 never, 1 whenever the handle has its table
+  int sweep_period = 0;    // sweep evaluation: ticks of 10 ns per sweep of the leading index (0: what the previous launch measured; 1: no clock, rows in sorted order; tests / tuning)
 };
 
 // What the most recent launch through a handle ran: the kernel template and its arguments in
@@ -131,6 +133,13 @@ struct GridDesc {
   const void* bricks11 = nullptr;
   unsigned bricks11_nb[2] = {0, 0};
   int brick_cell = 0;
+  // 3-D f64 multilinear: the table the sweep evaluation of large device-resident batches runs on
+  // (linear_sweep.h; layout sweep_step, see k_linear_sweep.hip::sweep_layout) — `bricks` itself where
+  // the layouts agree, else a second table the handle owns.  nullptr: the sweep never applies.
+  const void* sweep_bricks = nullptr;
+  int sweep_step[2] = {0, 0};
+  unsigned sweep_nb[3] = {0, 0, 0};
+  size_t sweep_table_bytes = 0;
   // check_bounds limits per dimension, in the element type's arithmetic
   // (multilinear/regular.rs:160-166: starts + steps*(dims-1), min/max; rectilinear.rs:121-123).
   double bound_lo[8] = {0};
@@ -190,6 +199,13 @@ inline Thresholds thresholds(const LaunchConfig& c) {
   t.column_lds = (size_t)c.lds_per_cu;
   return t;
 }
+
+// Sweep evaluation (k_linear_sweep.hip)
+bool sweep_layout(const GridDesc& g, int* si, int* sj);
+int sweep_applies(const GridDesc& g, size_t npts);
+size_t sweep_work_bytes();
+hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
+                               void* work, hipStream_t stream);
 
 template <typename T>
 hipError_t launch_linear_regular(const GridDesc& g, const T* const* obs, T* out, size_t npts,

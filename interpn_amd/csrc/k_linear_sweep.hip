@@ -1,0 +1,150 @@
+// Host side of the sweep evaluation of 3-D multilinear batches (linear_sweep.h): when it applies,
+// which table it runs on, and the launcher.
+#include <atomic>
+
+#include "linear_sweep.h"
+
+namespace interpn {
+
+namespace {
+
+constexpr int kSweepRows = 12;       // rows of 64 points per wave and round: 157 VGPRs, three waves per SIMD
+constexpr int kSweepThreads = 768;   // one workgroup per CU
+// points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
+constexpr size_t kSweepPointsPerCu = (size_t)kSweepRows * kSweepThreads;
+
+size_t brick_lines(const GridDesc& g, int si, int sj) {
+  unsigned nb[3];
+  size_t bytes = 0;
+  brick_geometry(g, si, sj, nb, &bytes);
+  return bytes / 128;
+}
+
+}  // namespace
+
+size_t sweep_work_bytes() { return sizeof(SweepWork); }
+
+// Which brick layout the sweep evaluation of this grid wants: (1,1) while a sweep's window still
+// re-uses its lines (table lines fetched per point and XCD = 8 x lines / window <= 1/2), else
+// (1,2) — half the lines at 1.5 lines per point — while THAT re-uses them, else (1,1) again (no
+// re-use either way: fewest lines per point).  Measured (tools/sweep_clock_probe.py, 1e8 points,
+// f64): 64^3 (1,1) 1.07 against (1,2) 1.19 ms; 80^3 (1,2) 1.25 against (1,1) 1.35.
+// Returns false where the sweep does not apply to the handle at all.
+bool sweep_layout(const GridDesc& g, int* si, int* sj) {
+  if (g.method != kLinear || g.ndims != 3 || g.dtype != kF64 || g.cfg.sweep == 0) return false;
+  if (g.kind == kRectilinear && lane_axes_mode(g) == 0) return false;
+  const size_t window = kSweepPointsPerCu * (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) * 85 / 100;  // ~ the share of a round spent in rows
+  const size_t l11 = brick_lines(g, 1, 1), l12 = brick_lines(g, 1, 2);
+  const int xcds = g.cfg.num_xcds > 0 ? g.cfg.num_xcds : 8;
+  if ((size_t)xcds * l11 * 2 <= window) { *si = 1; *sj = 1; }
+  else if ((size_t)xcds * l12 * 10 <= window * 7) { *si = 1; *sj = 2; }
+  else { *si = 1; *sj = 1; }
+  return true;
+}
+
+// 0 = never for this handle, 1 = not for this batch, 2 = yes.
+int sweep_applies(const GridDesc& g, size_t npts) {
+  if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
+  if (g.cfg.sweep > 0) return 2;
+  // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
+  // must give every wave a few rounds (the period is a round's duration; the launch's start and end
+  // are a round each)
+  if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
+  const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
+  if (npts < 4 * kSweepPointsPerCu * cus) return 1;
+  return 2;
+}
+
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR>
+static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
+  constexpr int K = kSweepRows, TH = kSweepThreads;
+  auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false>;
+  const size_t lds = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup;
+  static std::atomic<unsigned long long> opted{0};  // bit per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !((opted.load() >> dev) & 1ull))) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);
+  }
+  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0}, 0b10000011u);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH), lds, stream, s);
+  return hipGetLastError();
+}
+
+template <typename T, bool RECT, bool FMA, int AXR>
+static hipError_t go_layout(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
+  if (g.sweep_step[0] == 1 && g.sweep_step[1] == 1) return go<T, RECT, FMA, 1, 1, AXR>(g, s, blocks, stream);
+  if (g.sweep_step[0] == 1 && g.sweep_step[1] == 2) return go<T, RECT, FMA, 1, 2, AXR>(g, s, blocks, stream);
+  return hipErrorInvalidValue;
+}
+
+// `work`: a zeroed SweepWork block that no other launch in flight uses (abi_sweep.hip).
+hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
+                               void* work, hipStream_t stream) {
+  typedef double T;
+  if (g.dtype != kF64 || g.ndims != 3 || !g.sweep_bricks || !work || npts == 0) return hipErrorInvalidValue;
+  for (int d = 0; d < 3; ++d)
+    if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)
+  if (reinterpret_cast<uintptr_t>(out) % 16) return hipErrorInvalidValue;
+  SweepArgs<T> s;
+  BrickArgs<T, 3>& a = s.b;
+  a.bricks = static_cast<const T*>(g.sweep_bricks);
+  a.out = static_cast<T*>(out);
+  a.first_bad = first_bad;
+  a.npts = npts;
+  for (int d = 0; d < 3; ++d) {
+    a.obs[d] = static_cast<const T*>(obs[d]);
+    a.start[d] = (T)g.start[d];
+    a.step[d] = (T)g.step[d];
+    a.n[d] = g.n[d];
+  }
+  a.nbj = g.sweep_nb[1];
+  a.nbk = g.sweep_nb[2];
+  a.lead_stride[0] = 0;
+  a.iters = 1;
+  a.ax.use_lds = 0;
+  a.ax.image = nullptr;
+  a.ax.image_bytes = 0;
+  int axr = 0;
+  if (g.kind == kRectilinear) {
+    axr = lane_axes_mode(g);
+    if (axr == 0) return hipErrorInvalidValue;
+    (void)fill_axis_args<T, 3>(g, a.ax, false, /*records=*/false);
+    // the uniform grid over the leading axis' span (bound_lo / bound_hi are g[0] and g[n-1])
+    const double span = g.bound_hi[0] - g.bound_lo[0];
+    s.key_start = (T)g.bound_lo[0];
+    s.key_scale = span > 0 ? (T)((double)(g.n[0] - 1) / span) : (T)0;
+  } else {
+    s.key_start = (T)g.start[0];
+    s.key_scale = (T)(1.0 / g.step[0]);
+  }
+  if (!(s.key_scale > 0) || !(s.key_scale < 1e300)) { s.key_scale = 0; }  // every point in bin 0: still correct
+  s.key_shift = 0;
+  while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;
+  const size_t chunk = (size_t)64 * kSweepRows;
+  const size_t rounds = (npts + chunk - 1) / chunk;
+  if (rounds > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+  s.rounds = (unsigned)rounds;
+  s.per_shard = (s.rounds + 7u) / 8u;
+  s.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
+  s.period_default = 2200;  // 22 us: a round on a 64^3 grid (the first launch through a scratch block; the kernel measures from then on)
+  s.work = static_cast<SweepWork*>(work);
+  s.stamps = nullptr;
+  const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
+  unsigned blocks = cus;
+  const unsigned need = (s.rounds + (kSweepThreads / 64) - 1) / (kSweepThreads / 64);
+  if (blocks > need) blocks = need;
+#define SWEEP_KIND(RECT_, AXR_) (g.fma ? go_layout<T, RECT_, true, AXR_>(g, s, blocks, stream) : go_layout<T, RECT_, false, AXR_>(g, s, blocks, stream))
+  switch (axr) {
+    case 0: return SWEEP_KIND(false, 0);
+    case 1: return SWEEP_KIND(true, 1);
+    case 2: return SWEEP_KIND(true, 2);
+    case 3: return SWEEP_KIND(true, 3);
+  }
+#undef SWEEP_KIND
+  return hipErrorInvalidValue;
+}
+
+}  // namespace interpn

@@ -1,0 +1,344 @@
+// 3-D multilinear on the fully overlapped brick table with the points of every wave ordered by
+// their leading cell index on chip, and all waves of the chip walking that index in step with a
+// clock ("sweep" evaluation; round 5).
+//
+// Why: on a 64^3 f64 grid the one-line-per-cell table (linear_brick.h, steps 1,1) is 10.2 MiB and
+// unordered points miss the 4 MiB L2 of an XCD on 63 % of their lines; the kernel is then bound by
+// the fabric's request rate.  Points ordered by the cell index of
+// dimension 0 inside windows of W points make the workgroups of an XCD sweep the table once per
+// window, and the table lines an XCD fetches per point drop to (lines of the table) / (W / 8):
+// profiles/r05_slab_window_*.jsonl (the brick kernel on window-ordered points) has 1.44 ms per 1e8
+// points unordered, 1.01 ms at W = 2^21, 0.97 at 2^22, 0.91 fully ordered.  W is what the chip can
+// hold at a time, and the points must be back in their own order when the results are stored.
+//
+// How:
+//  * every wave keeps K x 64 points in REGISTERS (the LDS alone would hold 1.7e6 points chip-wide
+//    at 24 bytes each, the register files three times that), counting-sorts them by leading cell
+//    index through LDS — per wave: there is no workgroup barrier and no wait on another wave
+//    anywhere —, evaluates its K rows in that order with linear_brick.h's quad-cooperative gather,
+//    and puts the results back into the points' own order through LDS, so that coordinates are
+//    read and results written exactly as coalesced as in the brick kernel;
+//  * "row k at the same time on every CU of an XCD" cannot come from when waves start (they drift).
+//    It comes from a clock every wave can read, the constant-rate counter s_memrealtime: one sweep
+//    of the leading index takes `period` ticks; a wave that begins its rows at time t begins with
+//    the row (a quantile of its sorted points) that the clock's phase frac(t / period) names and
+//    wraps around.  All waves that gather at a given moment then gather from the same slab of the
+//    table, whenever they started (stamps: tools/sweep_clock_probe.py).  The period that works is
+//    the mean duration of a round; every launch measures it and leaves it for the next one
+//    (SweepWork::period; the first launch of a handle uses a default);
+//  * rounds are dealt on demand from eight counters (one per XCD, a wave steals from the others'
+//    once its own is empty): with a static deal the slowest waves ended 12 % after the mean.
+// A point's result depends on its coordinates only (src/multilinear/regular.rs:276-280) and the
+// arithmetic per point is linear_brick.h's (the reference's operations in its order,
+// regular.rs:296-404): results are bit-identical whatever the order, the period or the deal.
+#pragma once
+
+#include "linear_brick.h"
+
+namespace interpn {
+
+// Work words of the launches through one scratch block (device memory).  Zero before the first
+// launch; the last wave of every launch leaves everything but `period` zero again, so launches that
+// follow each other on a stream need no reset in between.
+struct SweepWork {
+  unsigned head[8][32];        // next round of shard x (one 128-byte line each)
+  unsigned done[32];           // waves that have finished
+  unsigned long long ticks;    // sum over waves of the ticks spent in rounds ...
+  unsigned rounds;             // ... and of the rounds they took
+  unsigned period;             // ticks per sweep for the next launch (0: the launch's default)
+  unsigned pad[28];
+};
+static_assert(sizeof(SweepWork) == 10 * 128, "one line per counter");
+
+template <typename T>
+struct SweepArgs {
+  BrickArgs<T, 3> b;   // bricks (steps SI, SJ), obs, out, first_bad, npts, start, step, n, nbj, nbk
+  T key_start, key_scale;  // the sort key: (x0 - key_start) * key_scale ~ the leading cell index (a locality hint: it need not be the exact cell; rectilinear: the uniform grid over the axis' span)
+  int key_shift;       // leading cell index >> key_shift < 64 bins
+  unsigned rounds;     // 64 * K points each
+  unsigned per_shard;  // rounds per shard (8 shards)
+  unsigned period;     // > 0: ticks per sweep, overriding the measured one; 1: rows in sorted order (no clock)
+  unsigned period_default;  // before anything has been measured
+  SweepWork* work;
+  unsigned long long* stamps;  // STAMPS builds (tools/): 8 words per wave, see the kernel's end
+};
+
+// K rows of 64 points per wave and round; THREADS per workgroup.
+// LDS per wave: a row buffer of K * 512 bytes (sort exchange before the rows, result exchange
+// after them) that shares its bytes with the quad-transposition pieces of linear_brick.h (5 KiB,
+// used by the rows in between), + 64 counters x 2 + 1 KiB of piece offsets.
+template <typename T, int K>
+struct SweepLds {
+  static constexpr unsigned kRowOnly = 64u * K * sizeof(T);
+  static constexpr unsigned kPiece = 64u * kPieceRow * 2u * sizeof(T);
+  static constexpr unsigned kRow = kRowOnly > kPiece ? kRowOnly : kPiece;
+  static constexpr unsigned kCnt = 64u * 4u * 2u;
+  static constexpr unsigned kOff = 64u * 16u;
+  static constexpr unsigned kWave = kRow + kCnt + kOff;
+  static constexpr unsigned kWorkgroup = 16;  // behind the waves' regions: ticks | rounds | waves done | -
+};
+
+// RECT: rectilinear axes of at most 64 coordinates, held one coordinate per lane and searched with
+// cross-lane reads (lane_axes.h; AXR = its mode 1..3), exactly as in the brick kernel.
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false>
+__global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
+  static_assert(K % 2 == 0 && K >= 2 && K <= 32, "rows per wave and round");
+  static_assert(RECT == (AXR != 0), "rectilinear grids: lane-resident axes only");
+  typedef typename LeafVec<T, 2>::type P;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef BrickGeom<T, 0> Geom;
+  constexpr int SK = Geom::SK;
+  typedef SweepLds<T, K> L;
+  const BrickArgs<T, 3>& a = s.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = threadIdx.x >> 6;
+  unsigned char* const mine = smem_raw + wave * L::kWave;
+  T* const row = reinterpret_cast<T*>(mine);                                 // [64 K]
+  typedef unsigned short __attribute__((may_alias)) lds_u16;
+  lds_u16* const row16 = reinterpret_cast<lds_u16*>(mine);                   // [64 K] (the row buffer's bytes, between its uses)
+  P* const lds_piece = reinterpret_cast<P*>(mine);                           // [16 quads][4][kPieceRow] (the same bytes, during the rows)
+  lds_u32* const cnt = reinterpret_cast<lds_u32*>(mine + L::kRow);           // [64] points per bin, then first position per bin at [64..128)
+  lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kCnt);
+  lds_u32* const wg_words = reinterpret_cast<lds_u32*>(smem_raw + (THREADS / 64) * L::kWave);  // ticks | rounds | waves done
+  if (threadIdx.x < 4) wg_words[threadIdx.x] = 0;
+  __syncthreads();  // the only workgroup barrier: before any wave has taken work
+  const unsigned q = lane & 3u;
+  const unsigned quad = lane >> 2;
+  constexpr size_t kChunk = (size_t)64 * K;
+  const unsigned nwaves = gridDim.x * (THREADS / 64);
+  LaneAxes<T, 3> la;
+  if constexpr (RECT) la = load_lane_axes<T, 3, AXR>(a.ax);
+  SweepWork* const work = s.work;
+  unsigned period = s.period;
+  if (period == 0) {
+    period = __hip_atomic_load(&work->period, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (period == 0) period = s.period_default;
+  }
+  period = __builtin_amdgcn_readfirstlane(period);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  unsigned shard = xcc & 7u;
+  // One returning atomic per round and wave, eight counters: 1e8 points are 1.3e5..2e5 rounds per
+  // millisecond, and one word serves ~9e4 returning atomics per millisecond.
+  auto take = [&](unsigned sh) -> unsigned {
+    unsigned v = 0;
+    if (lane == 0) v = atomicAdd(&work->head[sh][0], 1u);
+    return v;  // lane 0 holds the answer; consumed through readfirstlane
+  };
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_mark = t_begin, st_other = 0, st_rows = 0;
+  unsigned st_rot = 0;
+  unsigned my_rounds = 0;
+  unsigned ticket = take(shard);
+  while (true) {
+    unsigned rr = __builtin_amdgcn_readfirstlane(ticket);
+    if (rr >= s.per_shard || shard * s.per_shard + rr >= s.rounds) {  // this shard is empty: the next one that is not
+      // (a look before the returning atomic: at the end of a launch every wave comes through here,
+      // and thousands of read-modify-writes on eight words took 50-100 us; loads do not queue up)
+      bool found = false;
+      for (unsigned c = 1; c < 8 && !found; ++c) {
+        const unsigned sh = (shard + c) & 7u;
+        const unsigned seen = __hip_atomic_load(&work->head[sh][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen < s.per_shard && sh * s.per_shard + seen < s.rounds) { found = true; shard = sh; }
+      }
+      if (!found) break;  // (the counters only grow: a wave that loses the race for a shard's last rounds looks again and ends here)
+      ticket = take(shard);
+      continue;
+    }
+    const unsigned r = shard * s.per_shard + rr;
+    ticket = take(shard);  // the next round's ticket travels while this round's coordinates do
+    ++my_rounds;
+    const size_t base = (size_t)r * kChunk;
+    // -- coordinates: K/2 16-byte loads per dimension, lane l holds points k2*128 + 2l + {0,1}
+    T x[K][3];
+    const bool full = base + kChunk <= a.npts;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int k2 = 0; k2 < K / 2; ++k2) {
+        const size_t i0 = base + (size_t)k2 * 128 + 2 * lane;
+        T2 v;
+        v.x = a.start[d];
+        v.y = a.start[d];
+        if (full || i0 + 1 < a.npts) {
+          v = stream_load(reinterpret_cast<const T2*>(a.obs[d] + i0));
+        } else if (i0 < a.npts) {
+          v.x = stream_load(a.obs[d] + i0);
+        }
+        x[2 * k2][d] = v.x;
+        x[2 * k2 + 1][d] = v.y;
+      }
+    // -- counting sort of the wave's 64 K points by leading cell index (a hint: NaN -> bin 0)
+    cnt[lane] = 0;
+    wave_sync();
+    unsigned bin[K], pos[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const T u = (x[k][0] - s.key_start) * s.key_scale;
+      int c = u >= (T)1 ? (u < (T)(a.n[0] - 2) ? (int)u : a.n[0] - 2) : 0;
+      bin[k] = (unsigned)(c >> s.key_shift);
+      pos[k] = atomicAdd(&cnt[bin[k]], 1u);  // rank inside (wave, bin)
+    }
+    wave_sync();
+    {
+      const unsigned mine_cnt = cnt[lane];
+      unsigned incl = mine_cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, off);
+        if (lane >= (unsigned)off) incl += up;
+      }
+      cnt[64 + lane] = incl - mine_cnt;
+    }
+    wave_sync();
+    // the first row: the one the clock's phase names (see the head of this file)
+    unsigned rot = 0;
+    if (period > 1) {
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+      const unsigned ph = now % period;
+      rot = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)ph * K) / period) * 64u);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      unsigned p = pos[k] + cnt[64 + bin[k]];
+      p = p >= rot ? p - rot : p + (unsigned)(64 * K) - rot;
+      pos[k] = p;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) row[pos[k]] = x[k][d];
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + lane];
+      wave_sync();
+    }
+    unsigned src[K];  // where (inside the chunk) the point in my slot k came from
+#pragma unroll
+    for (int k = 0; k < K; ++k) row16[pos[k]] = (unsigned short)((k >> 1) * 128 + 2 * lane + (k & 1));
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < K; ++k) src[k] = row16[k * 64 + lane];
+    wave_sync();
+    // -- K rows in sorted order
+    if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
+    T res[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // one row at a time ...
+      __builtin_amdgcn_sched_barrier(0);
+      T t[3];
+      int loc[3];
+      if constexpr (RECT) {
+        T xin[1][3], x0_r[1][3], x1_r[1][3];
+        int cell_r[1][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xin[0][d] = x[k][d];
+        lane_axes_locate<T, 3, 1, AXR>(a.ax, la, xin, cell_r, x0_r, x1_r);  // multilinear/rectilinear.rs:353-370
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          t[d] = (x[k][d] - x0_r[0][d]) / (x1_r[0][d] - x0_r[0][d]);        // rectilinear.rs:310-313
+          loc[d] = cell_r[0][d];
+        }
+      } else {
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T floc;
+          ok &= regular_floc<T>(x[k][d], a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
+          const int l = clamp_loc<T>(floc, a.n[d] - 2);                  // regular.rs:420-422
+          const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);       // regular.rs:334-337
+          t[d] = (x[k][d] - izl) / a.step[d];                            // regular.rs:339
+          loc[d] = l;
+        }
+        const size_t gi = base + src[k];
+        if (!ok && gi < a.npts) atomicMin(a.first_bad, (unsigned long long)gi);
+      }
+      const unsigned bk = (unsigned)loc[2] / (unsigned)SK;
+      const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK);
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, 0>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
+      wave_sync();
+      const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
+      const Cell<T> c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
+      T rr2[2];
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {  // reference order (regular.rs:347-403): i first, k last
+        const T c0 = mul_add<FMA>(t[0], c.v[1][0][dk] - c.v[0][0][dk], c.v[0][0][dk]);
+        const T c1 = mul_add<FMA>(t[0], c.v[1][1][dk] - c.v[0][1][dk], c.v[0][1][dk]);
+        rr2[dk] = mul_add<FMA>(t[1], c1 - c0, c0);
+      }
+      res[k] = mul_add<FMA>(t[2], rr2[1] - rr2[0], rr2[0]);
+      // ... and finished before the next begins: the optimiser otherwise sinks a row's divisions and
+      // lerps down to the result exchange and keeps its eight cell values alive (K = 8: 146 spilled
+      // registers at 128; with the two pins: none)
+      asm volatile("" : "+v"(res[k]));
+    }
+    if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
+    // -- results back into the points' own order through LDS
+#pragma unroll
+    for (int k = 0; k < K; ++k) row[src[k]] = res[k];
+    wave_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < K / 2; ++k2) {
+      const size_t i0 = base + (size_t)k2 * 128 + 2 * lane;
+      const T2 v = *reinterpret_cast<const T2*>(&row[k2 * 128 + 2 * lane]);
+      if (full || i0 + 1 < a.npts) {
+        stream_store(reinterpret_cast<T2*>(a.out + i0), v);
+      } else if (i0 < a.npts) {
+        stream_store(a.out + i0, v.x);
+      }
+    }
+    wave_sync();
+  }
+  // -- this wave is done: its share of the period measurement goes to the workgroup's LDS words; the
+  //    workgroup's last wave adds them to the launch's, and the launch's last workgroup turns the
+  //    sums into the next launch's period and leaves the work words zero.  (Every wave adding to the
+  //    launch's words itself: 3 x 3072 read-modify-writes on two lines = 20-65 us at the end of
+  //    every launch, stamps of round 5.)
+  const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    const unsigned my_ticks = (unsigned)(t_end - t_begin);  // < 43 s
+    atomicAdd(&wg_words[0], my_ticks);   // a workgroup's waves together stay below 2^32 ticks for launches under 2.6 s
+    atomicAdd(&wg_words[1], my_rounds);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (atomicAdd(&wg_words[2], 1u) == THREADS / 64 - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const unsigned wg_ticks = wg_words[0], wg_rounds = wg_words[1];
+      if (wg_rounds) {  // returning forms, answers consumed: both have been performed before `done` is touched
+        const unsigned long long r1 = atomicAdd(&work->ticks, (unsigned long long)wg_ticks);
+        const unsigned r2 = atomicAdd(&work->rounds, wg_rounds);
+        asm volatile("" ::"v"(r1), "v"(r2));
+      }
+      const unsigned d = atomicAdd(&work->done[0], 1u);
+      if (d == gridDim.x - 1) {
+        const unsigned long long ticks = atomicAdd(&work->ticks, 0ull);
+        const unsigned rounds = atomicAdd(&work->rounds, 0u);
+        // a launch of few rounds per wave measures its start-up, not a round: keep what there was
+        if (rounds >= 4 * nwaves) {
+          // 0.9 x the mean round: measured optimum (a period a little short of the round spreads the
+          // waves of an XCD over a few rows instead of one, i.e. over more L2 channels; fed back as it
+          // is the mean settles at a longer, slower period)
+          unsigned long long p = ticks * 9 / ((unsigned long long)rounds * 10);
+          p = p < 200 ? 200 : (p > 20000 ? 20000 : p);  // 2 .. 200 us
+          atomicExch(&work->period, (unsigned)p);
+        }
+        for (int x = 0; x < 8; ++x) atomicExch(&work->head[x][0], 0u);
+        atomicExch(&work->ticks, 0ull);
+        atomicExch(&work->rounds, 0u);
+        atomicExch(&work->done[0], 0u);
+      }
+    }
+    if constexpr (STAMPS) {  // start | end | ticks outside the rows | ticks in rows | XCD | last first row | rounds | period
+      if (s.stamps) {
+        unsigned long long* o = s.stamps + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
+        o[0] = t_begin; o[1] = t_end; o[2] = st_other; o[3] = st_rows;
+        o[4] = xcc & 0xFu; o[5] = st_rot / 64u; o[6] = my_rounds; o[7] = period;
+      }
+    }
+  }
+}
+
+}  // namespace interpn

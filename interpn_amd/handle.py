@@ -27,7 +27,7 @@ class Interpolator:
         # Streams that evaluations were enqueued on since the last finish(): raw handle -> the
         # object that owns it (a torch Stream kept alive here; None for a caller-supplied integer).
         self._pending_streams = {}
-        self.last_path = None        # "in_place" | "binned": what the most recent device evaluation did
+        self.last_path = None        # "in_place" | "binned" | "sweep": what the most recent device evaluation did
         self.last_path_reason = ""   # why a handle that can sort its points did not
 
     # -- construction ---------------------------------------------------------------------
@@ -167,7 +167,7 @@ class Interpolator:
 
     def eval_device_ptrs(self, obs_ptrs, out_ptr: int, npoints: int, stream: int = 0, no_alloc: bool = False) -> str:
         """Enqueue one evaluation on device buffers given as raw addresses (asynchronous).
-        Returns the path taken, "in_place" or "binned" (also kept in `.last_path`, with
+        Returns the path taken, "in_place", "binned" or "sweep" (also kept in `.last_path`, with
         `.last_path_reason` saying why a handle that can sort its points evaluated in place)."""
         lib = _lib.load()
         n = len(obs_ptrs)
@@ -178,7 +178,7 @@ class Interpolator:
         st = lib.interpn_hip_eval_device_ex(self._h, vp, n, c_void_p(int(out_ptr)), int(npoints), c_void_p(int(stream)),
                                             _lib.EVAL_NO_ALLOC if no_alloc else 0, ctypes.byref(path), ctypes.byref(why))
         _lib.raise_for_status(st)
-        self.last_path = "binned" if path.value == _lib.PATH_BINNED else "in_place"
+        self.last_path = {_lib.PATH_BINNED: "binned", _lib.PATH_SWEEP: "sweep"}.get(path.value, "in_place")
         self.last_path_reason = _lib.WHY.get(why.value, str(why.value))
         self._pending_streams.setdefault(int(stream), None)
         return self.last_path

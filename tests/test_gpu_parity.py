@@ -2040,3 +2040,128 @@ def test_stage_timing_of_a_sorted_evaluation(oracle, monkeypatch):
     with pytest.raises(ValueError):
         it.stage_ms()
     it.close()
+
+
+def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True):
+    return synthetic_case("linear", kind, 3, axis, nobs, seed, np.float64, extrap=extrap, specials=specials)
+
+
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("kind,axis,env", [("regular", [20, 17, 33], None), ("regular", [64, 9, 12], None),
+                                           ("regular", [130, 6, 7], None),  # leading cell index >> 2 for the 64 bins
+                                           ("rectilinear", [24, 11, 40], None), ("rectilinear", [64, 64, 5], None),
+                                           ("rectilinear", [24, 11, 40], {"axis_regs": 1})],
+                         ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence"])
+def test_sweep_evaluation(oracle, kind, axis, env, fma):
+    """The sweep evaluation of 3-D f64 multilinear batches (linear_sweep.h: every wave sorts 768
+    points by leading cell index on chip and walks its rows in step with a clock) against the oracle
+    and, bit for bit, against the brick kernel: batches of one point, of one round less / plus one
+    point, of many ragged rounds; extrapolated and special points; with the clock (measured period,
+    a fixed one) and without; both cargo flavours (multilinear/regular.rs:296-404, rectilinear.rs:244-370)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = _sweep_case(kind, axis, 300_007, 900 + sum(axis))
+    want = run_oracle(oracle, case, fma)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals, fma=fma)
+    else:
+        it = interpn_amd.Interpolator.rectilinear("linear", case.grids, case.vals, fma=fma)
+    try:
+        for k, v in (env or {}).items():
+            it.set_option(k, v)
+        assert it.get_option("sweep_table_bytes") > 0 and it.get_option("sweep_layout") in (11, 12)
+        full = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (100_003, 0), (300_007, 1), (300_007, 0), (300_007, 0), (300_007, 700)):
+            obs = [t[:count].clone() for t in full]
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert it.kernel_name().startswith("interpn::k_linear_sweep<double, " + ("true" if kind == "rectilinear" else "false")), it.kernel_name()
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place" and it.kernel_name().startswith("interpn::k_linear_brick"), it.kernel_name()
+            it.finish()
+            assert torch.equal(got, ref), (count, period)
+            w = want[:count]
+            g = got.cpu().numpy()
+            same = (g == w) | (np.isnan(g) & np.isnan(w))
+            assert np.all(same), (count, period, int((~same).sum()))
+        assert it.get_option("evals_sweep") == 9
+    finally:
+        it.close()
+
+
+def test_sweep_first_bad_index_alignment_and_streams(oracle):
+    """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
+    multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and
+    batches under the automatic threshold to the brick kernel, and serves two streams on one handle
+    at once (a scratch block with the work words per stream)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = 250_003
+    case = _sweep_case("regular", [33, 30, 31], n, 4242, specials=False)
+    want = run_oracle(oracle, case, True)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    try:
+        it.set_option("sweep", 1)
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        # not 16-byte aligned: the points as they are
+        shifted = [torch.cat([t[:1], t])[1:] for t in obs]
+        assert all(t.data_ptr() % 16 == 8 for t in shifted)
+        got = it.eval_tensors(shifted)
+        assert it.last_path == "in_place"
+        it.finish()
+        assert np.array_equal(got.cpu().numpy(), want)
+        # failing points: the smallest index wins, whichever wave meets it
+        bad = [t.clone() for t in obs]
+        bad[1][200_000] = float("nan")
+        bad[2][77_777] = float("inf")
+        bad[0][77_778] = float("nan")
+        out = it.eval_tensors(bad)
+        assert it.last_path == "sweep"
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            it.finish()
+        assert ei.value.first_bad_index == 77_777
+        assert np.array_equal(out.cpu().numpy()[:77_777], want[:77_777])
+        # two streams at once, several launches each (the blocks' work words come back to zero)
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(3):
+            outs.append((it.eval_tensors(obs, stream=s1), it.eval_tensors(obs, stream=s2)))
+        it.finish()
+        for a, b in outs:
+            assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
+        # automatic mode: this grid's table is L2-sized -> never; a 64^3 grid: only for batches that give every wave a few rounds
+        it.set_option("sweep", -1)
+        it.eval_tensors(obs)
+        assert it.last_path == "in_place"
+        it.finish()
+    finally:
+        it.close()
+    big = _sweep_case("regular", [64, 64, 64], 1000, 7, specials=False)
+    it = interpn_amd.Interpolator.regular("linear", big.dims, big.starts, big.steps, big.vals)
+    try:
+        assert it.get_option("sweep_layout") == 11 and it.table_layout()[1:] == (1, 2)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(11)
+        for count, path in ((1_000_000, "in_place"), (12_000_003, "sweep")):
+            obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
+            got = it.eval_tensors(obs)
+            assert it.last_path == path, (count, it.last_path, it.last_path_reason)
+            it.finish()
+            idx = torch.randint(0, count, (200_000,), device=dev, generator=gen)
+            sub = [o[idx].cpu().numpy() for o in obs]
+            w = np.zeros(idx.numel())
+            oracle.linear_regular(big.dims, big.starts, big.steps, big.vals, sub, w)
+            assert np.array_equal(got[idx].cpu().numpy(), w)
+    finally:
+        it.close()

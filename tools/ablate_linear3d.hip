@@ -12,6 +12,7 @@
 #include <new>
 
 #include "../interpn_amd/csrc/linear_brick.h"
+#include "../interpn_amd/csrc/linear_sweep.h"
 
 using namespace interpn;
 
@@ -20,6 +21,7 @@ namespace {
 struct Ablate {
   double* bricks = nullptr;
   unsigned long long* first_bad = nullptr;
+  SweepWork* work = nullptr;
   int n = 0, si = 0, sj = 0;
   unsigned nb[3] = {0, 0, 0};
   double step = 0;
@@ -60,7 +62,8 @@ void* ablate_create(const double* vals_dev, int n, int si, int sj, double step) 
   h->nb[0] = along(n, si); h->nb[1] = along(n, sj); h->nb[2] = along(n, 3);
   const size_t elems = (size_t)h->nb[0] * h->nb[1] * h->nb[2] * 16;
   if (elems >= 0xFFFFFFFFull || hipMalloc((void**)&h->bricks, elems * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&h->first_bad, 8) != hipSuccess || hipMemset(h->first_bad, 0xFF, 8) != hipSuccess) {
+      hipMalloc((void**)&h->first_bad, 8) != hipSuccess || hipMemset(h->first_bad, 0xFF, 8) != hipSuccess ||
+      hipMalloc((void**)&h->work, sizeof(SweepWork)) != hipSuccess || hipMemset(h->work, 0, sizeof(SweepWork)) != hipSuccess) {
     (void)hipFree(h->bricks); (void)hipFree(h->first_bad);
     delete h;
     return nullptr;
@@ -108,12 +111,82 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
   return (int)go_steps<4>(*h, a, blocks, lds + 4 * 3 * 1024, s);
 }
 
+// The sweep evaluation (linear_sweep.h) on the same table: K rows of 64 points per wave and round,
+// `threads` per workgroup, `wgs` persistent workgroups per CU (0: 1024 / threads).  Returns hipError_t; -1: shape not instantiated.
+static unsigned long long* g_sweep_stamps = nullptr;  // device buffer, 8 words per workgroup (STAMPS build of the kernel)
+void ablate_set_sweep_stamps(unsigned long long* p) { g_sweep_stamps = p; }
+static unsigned g_sweep_clock = 0;  // ticks of 10 ns per sweep of the leading index (0: measured by the previous launch, 1: rows in sorted order)
+void ablate_set_sweep_clock(unsigned ticks) { g_sweep_clock = ticks; }
+
+int ablate_launch_sweep(void* handle, const double* x, const double* y, const double* z, double* out, size_t npts, int K,
+                        int threads, int wgs, void* stream) {
+  const Ablate* h = static_cast<const Ablate*>(handle);
+  if (!h || !x || !y || !z || !out || npts == 0) return (int)hipErrorInvalidValue;
+  for (const void* p : {(const void*)x, (const void*)y, (const void*)z, (const void*)out})
+    if (reinterpret_cast<uintptr_t>(p) % 16) return (int)hipErrorInvalidValue;
+  SweepArgs<double> s;
+  BrickArgs<double, 3>& a = s.b;
+  a.bricks = h->bricks;
+  a.obs[0] = x; a.obs[1] = y; a.obs[2] = z;
+  a.out = out;
+  a.first_bad = h->first_bad;
+  a.npts = npts;
+  for (int d = 0; d < 3; ++d) { a.start[d] = -1.0; a.step[d] = h->step; a.n[d] = h->n; }
+  a.nbj = h->nb[1];
+  a.nbk = h->nb[2];
+  a.lead_stride[0] = 0;
+  a.ax.use_lds = 0; a.ax.image = nullptr; a.ax.image_bytes = 0;
+  a.iters = 1;
+  s.key_start = -1.0;
+  s.key_scale = 1.0 / h->step;
+  s.key_shift = 0;
+  while (((h->n - 2) >> s.key_shift) >= 64) ++s.key_shift;
+  const size_t chunk = (size_t)64 * K;
+  s.rounds = (unsigned)((npts + chunk - 1) / chunk);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  s.per_shard = (s.rounds + 7u) / 8u;
+  s.period = g_sweep_clock;  // 0: what the previous launch measured; 1: no clock
+  s.period_default = 2000;
+  s.work = h->work;
+  s.stamps = g_sweep_stamps;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define SWEEP(SI_, SJ_, K_, TH_)                                                                                          \
+  if (h->si == SI_ && h->sj == SJ_ && K == K_ && threads == TH_) {                                                         \
+    auto kern = g_sweep_stamps ? k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, true> : k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, false>; \
+    const size_t lds = (size_t)SweepLds<double, K_>::kWave * (TH_ / 64) + SweepLds<double, K_>::kWorkgroup;                                                   \
+    if (lds > 64 * 1024) {                                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+    }                                                                                                                     \
+    unsigned blocks = (unsigned)cus * (unsigned)(wgs > 0 ? wgs : (TH_ >= 1024 ? 1 : 1024 / TH_));                         \
+    if (blocks > (s.rounds + (TH_ / 64) - 1) / (TH_ / 64)) blocks = (s.rounds + (TH_ / 64) - 1) / (TH_ / 64);             \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH_), lds, st, s);                                                        \
+    return (int)hipGetLastError();                                                                                        \
+  }
+#define SWEEP_LAYOUTS(K_, TH_) SWEEP(1, 1, K_, TH_) SWEEP(1, 2, K_, TH_)
+  SWEEP_LAYOUTS(8, 1024)
+  SWEEP_LAYOUTS(8, 768)
+  SWEEP_LAYOUTS(12, 768)
+  SWEEP_LAYOUTS(14, 768)
+  SWEEP_LAYOUTS(16, 768)
+  SWEEP_LAYOUTS(20, 512)
+  SWEEP_LAYOUTS(24, 512)
+  SWEEP_LAYOUTS(8, 512)
+  SWEEP_LAYOUTS(16, 512)
+#undef SWEEP_LAYOUTS
+#undef SWEEP
+  return -1;
+}
+
 void ablate_destroy(void* handle) {
   Ablate* h = static_cast<Ablate*>(handle);
   if (!h) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(h->bricks);
   (void)hipFree(h->first_bad);
+  (void)hipFree(h->work);
   delete h;
 }
 
