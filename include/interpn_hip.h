@@ -66,10 +66,18 @@
  *                                       from the records instead of from the upper eight bits of the index words, where the sort
  *                                       leaves them by default — slices are then 2^24 points at most),
  *                                       INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
+ *       INTERPN_HIP_SWEEP=-1|0|1        3-D f64 multilinear, device-pointer evaluation: the sweep kernel (every wave orders 768
+ *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
+ *                                       with a clock; linear_sweep.h): auto (tables beyond the L2, batches of >= 4 rounds per
+ *                                       wave ~ 9.4e6 points), never, or whenever the handle has the table (creation: 0 also
+ *                                       skips building it); INTERPN_HIP_SWEEP_PERIOD=n ticks of 10 ns per sweep (0 = what the
+ *                                       previous launch measured, 1 = no clock)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
  *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)
- *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms)
+ *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms),
+ *                                       "debug_stamps" + "debug_stamps_bytes" (address and size of a device buffer for the column
+ *                                       kernel's time stamps, 64 bytes per part; a launch that needs more writes none)
  *       INTERPN_HIP_POOL_MB=n           device bytes of destroyed handles kept for reuse, per device
  *                                       (process-wide, read once; default 1024; 0 = release
  *                                       everything at destroy)
@@ -130,6 +138,10 @@ const char* interpn_hip_version(void);
 int interpn_hip_set_fma(int enabled);
 /* Number of visible HIP devices (0 when none; never fails). */
 int interpn_hip_device_count(void);
+/* Give back to the driver the device memory of destroyed handles that the library keeps for reuse
+ * on `device` (-1: the current device): cached and parked blocks alike (INTERPN_HIP_POOL_MB).
+ * Waits for the device like hipFree.  *freed_bytes (may be NULL) receives what was released. */
+int interpn_hip_trim(int device, size_t* freed_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot entry points, host pointers — drop-in for the calls made inside the PyO3 bodies.

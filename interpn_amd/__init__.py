@@ -20,7 +20,18 @@ from .handle import Interpolator, eval_device_sharded, eval_host_sharded
 
 __version__ = "0.1.0"
 
+def trim(device: int = -1) -> int:
+    """Release the device memory of destroyed interpolators that the library keeps for reuse on
+    `device` (`interpn_hip_trim`; -1 = the current device).  Returns the bytes released."""
+    import ctypes
+
+    freed = ctypes.c_size_t(0)
+    _lib.raise_for_status(_lib.load().interpn_hip_trim(int(device), ctypes.byref(freed)))
+    return int(freed.value)
+
+
 __all__ = [
+    "trim",
     "eval_host_sharded",
     "eval_device_sharded",
     "__version__",

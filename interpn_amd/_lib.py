@@ -86,6 +86,8 @@ def load() -> ctypes.CDLL:
     lib.interpn_hip_set_fma.argtypes = [c_int]
     lib.interpn_hip_set_fma.restype = c_int
     lib.interpn_hip_device_count.restype = c_int
+    lib.interpn_hip_trim.argtypes = [c_int, POINTER(c_size_t)]
+    lib.interpn_hip_trim.restype = c_int
     for sfx, ct in (("f64", c_double), ("f32", c_float)):
         pp = POINTER(POINTER(ct))
         p = POINTER(ct)

@@ -336,6 +336,18 @@ int interpn_hip_device_count(void) {
   return count;
 }
 
+int interpn_hip_trim(int device, size_t* freed_bytes) {
+  if (freed_bytes) *freed_bytes = 0;
+  int dev;
+  const int st = resolve_device(device, &dev);
+  if (st) return st;
+  DeviceGuard guard(dev);
+  if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+  const size_t freed = pool_trim(dev);
+  if (freed_bytes) *freed_bytes = freed;
+  return INTERPN_HIP_OK;
+}
+
 #define DEFINE_CREATE(T, SUFFIX)                                                                              \
   int interpn_hip_create_regular_##SUFFIX(int method, const size_t* dims, size_t ndims, const T* starts,     \
                                           size_t nstarts, const T* steps, size_t nsteps, const T* vals,      \

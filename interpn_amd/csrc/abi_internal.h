@@ -76,6 +76,7 @@ class DeviceGuard {
 // ---- per-device pool (abi_pool.hip)
 hipError_t pool_alloc(int device, void** out, size_t bytes);  // the current device must be `device`
 void pool_free(int device, void* p);                          // only for blocks no in-flight work still touches
+size_t pool_trim(int device);                                 // frees what the pool holds for `device` (current device = `device`)
 hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** flag_host);
 void pool_return_kit(int device, hipStream_t stream, unsigned long long* flag_host);
 hipError_t pool_take_pinned_word(int device, unsigned long long** word);

@@ -57,6 +57,15 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
     else *value = c.debug_stamps;
     return true;
   }
+  if (!strcmp(name, "debug_stamps_bytes")) {  // capacity of the stamp buffer in bytes (checked at launch)
+    if (set) {
+      if (*value < 0) return false;
+      c.debug_stamps_bytes = *value;
+    } else {
+      *value = c.debug_stamps_bytes;
+    }
+    return true;
+  }
   for (const Opt& o : opts) {
     if (strcmp(name, o.name)) continue;
     if (set) {

@@ -54,7 +54,8 @@ struct DevPool {
   // streams that have nothing to do with the handle being destroyed — but parked here and freed in
   // one go by the next allocation that misses the pool once a quarter of the cap has collected
   // (or when an allocation fails, or at the cap itself).
-  std::vector<void*> parked;
+  // A parked block is still a good block: an allocation of its size class takes it back.
+  std::vector<std::pair<void*, size_t>> parked;  // block, class size
   size_t parked_bytes = 0;
 };
 
@@ -91,11 +92,20 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
       pool.live[*out] = cls;
       return hipSuccess;
     }
+    for (size_t k = pool.parked.size(); k-- > 0;)
+      if (pool.parked[k].second == cls) {
+        *out = pool.parked[k].first;
+        pool.parked[k] = pool.parked.back();
+        pool.parked.pop_back();
+        pool.parked_bytes -= cls;
+        pool.live[*out] = cls;
+        return hipSuccess;
+      }
   }
   {
     // an allocation that misses the pool is a heavyweight moment anyway (handle creation, scratch
     // growth): the place to give back what destroy calls have parked (hipFree waits for the device)
-    std::vector<void*> drop;
+    std::vector<std::pair<void*, size_t>> drop;
     {
       std::lock_guard<std::mutex> lk(pool.mu);
       if (pool.parked_bytes > pool_cap_bytes() / 4) {
@@ -103,7 +113,7 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
         pool.parked_bytes = 0;
       }
     }
-    for (void* b : drop) (void)hipFree(b);
+    for (auto& b : drop) (void)hipFree(b.first);
   }
   hipError_t e = hipMalloc(out, cls);
   if (e != hipSuccess) {
@@ -117,7 +127,7 @@ hipError_t pool_alloc(int device, void** out, size_t bytes) {
         kv.second.clear();
       }
       pool.cached_bytes = 0;
-      for (void* b : pool.parked) drop.push_back(b);
+      for (auto& b : pool.parked) drop.push_back(b.first);
       pool.parked.clear();
       pool.parked_bytes = 0;
     }
@@ -150,16 +160,39 @@ void pool_free(int device, void* p) {
       } else if (pool_cap_bytes() == 0) {
         drop.push_back(p);  // pooling switched off
       } else {  // over the cap: park it; the parked blocks are freed together now and then
-        pool.parked.push_back(p);
+        pool.parked.push_back({p, cls});
         pool.parked_bytes += cls;
         if (pool.parked_bytes > pool_cap_bytes()) {  // hard limit; normally the next allocation that misses the pool frees them
-          drop.swap(pool.parked);
+          for (auto& b : pool.parked) drop.push_back(b.first);
+          pool.parked.clear();
           pool.parked_bytes = 0;
         }
       }
     }
   }
   for (void* b : drop) (void)hipFree(b);
+}
+
+// Give back every cached and parked block of a device (the current device must be `device`); returns the bytes freed.
+size_t pool_trim(int device) {
+  if (!pooled_device(device)) return 0;
+  DevPool& pool = dev_pool(device);
+  std::vector<void*> drop;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    for (auto& kv : pool.free_blocks) {
+      for (void* b : kv.second) drop.push_back(b);
+      kv.second.clear();
+    }
+    bytes = pool.cached_bytes + pool.parked_bytes;
+    pool.cached_bytes = 0;
+    for (auto& b : pool.parked) drop.push_back(b.first);
+    pool.parked.clear();
+    pool.parked_bytes = 0;
+  }
+  for (void* b : drop) (void)hipFree(b);
+  return bytes;
 }
 
 hipError_t pool_take_kit(int device, hipStream_t* stream, unsigned long long** flag_host) {

@@ -538,7 +538,11 @@ k_cubic_column(const CubicColumnArgs<T> a) {
   constexpr int GT = THREADS / GROUPS;   // threads of a group
   constexpr int GW = GT / 64;            // its waves
   constexpr int PT = col_per_thread(GT); // points of a part per thread at most
+#ifdef INTERPN_COLUMN_SBARRIER  // measurement / diagnosis builds only (tools/): the one-group form on s_barrier
+  constexpr int BAR = GROUPS == 1 ? 0 : GW;
+#else
   constexpr int BAR = GW;  // (s_barrier for GROUPS == 1 — BAR = 0 — hangs on the GPU at 32^4 inside this persistent loop: not used)
+#endif
   constexpr unsigned PP = (unsigned)sizeof(T);  // 16-byte pieces of a tile
   const unsigned PITCH = a.pitch;               // bytes from tile to tile (group-uniform)
   const unsigned PU = PITCH >> 4;               // ... in 16-byte units

@@ -48,7 +48,8 @@ struct LaunchConfig {
   int hist_wgs_per_cu = 4;  // the sort's histogram kernel: persistent workgroups per CU, each flushing its counters once (one global atomic per bin and workgroup): cfg4 0.048 -> 0.041 ms (0: one workgroup per 8192-point chunk)
   int column_pad = -1;      // column evaluation: LDS tiles 16 bytes apart (1), bare (0), or bare where that saves phases (-1)
   int column_cpp = 0;       // column evaluation: classes of dim 2 per K-range phase at most (0 = as many as the LDS share holds; tests force several phases on small grids)
-  long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per column workgroup for in-kernel time stamps (0 = off)
+  long long debug_stamps = 0;  // measurement aid: device address of 8 x u64 per part of the column kernel for in-kernel time stamps (0 = off)
+  long long debug_stamps_bytes = 0;  // ... and the size of that buffer: a launch whose parts need more than it holds writes no stamps
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
   int sweep = -1;          // 3-D f64 multilinear, device-pointer evaluation: the sweep kernel (linear_sweep.h) -1 where it pays, 0 never, 1 whenever the handle has its table
   int sweep_period = 0;    // sweep evaluation: ticks of 10 ns per sweep of the leading index (0: what the previous launch measured; 1: no clock, rows in sorted order; tests / tuning)

@@ -499,7 +499,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 template <typename T, int N>
 hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts, void* scratch, const void** binned_obs,
                         const unsigned** index, BinExtras* extras, unsigned part_points, hipStream_t stream, hipEvent_t* stage,
-                        bool totals_clean, bool staged, unsigned hist_wgs) {
+                        bool totals_clean, bool staged, unsigned hist_wgs, size_t lds_per_cu) {
   unsigned char* base = static_cast<unsigned char*>(scratch);
   unsigned* totals = reinterpret_cast<unsigned*>(base);
   unsigned* cursor = totals + kMaxBins;
@@ -546,17 +546,26 @@ hipError_t bin_points_n(const BinParams& p, const void* const* obs, size_t npts,
     if constexpr (N == 4) {
       const unsigned blocks = (unsigned)((npts + kRecChunk - 1) / kRecChunk);
       const size_t staged_lds = kRecChunk * (N * sizeof(T) + 4) + (size_t)3 * (size_t)p.nbins * sizeof(unsigned);
-      if (p.nbins <= kScatThreads && staged && staged_lds <= kStagedLdsMax) {
-        auto kern = k_bin_scatter_records_staged<T, N, (int)kRecChunk>;
-        if (staged_lds > 64 * 1024) {
-          static std::atomic<unsigned long long> opted{0};  // bit per device
-          int dev = 0;
-          if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !((opted.load() >> dev) & 1ull)) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLdsMax);
-            if (e != hipSuccess) return e;
-            opted.fetch_or(1ull << dev);
+      // The staged form needs its chunk in LDS beside the kernel's static words (wave sums, outside
+      // flags: under 1 KiB): only where the device's CU has that much, and opted in to what is
+      // needed, not to the maximum.  A device (or an opt-in) that does not give it takes the direct form.
+      bool use_staged = p.nbins <= kScatThreads && staged && staged_lds <= kStagedLdsMax && staged_lds + 1024 <= lds_per_cu;
+      auto kern = k_bin_scatter_records_staged<T, N, (int)kRecChunk>;
+      if (use_staged && staged_lds > 64 * 1024) {
+        static std::atomic<unsigned long long> opted_bytes[64];  // per device: the largest size opted in to so far
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+        if (dev < 0 || dev >= 64 || opted_bytes[dev].load() < staged_lds) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged_lds) != hipSuccess) {
+            (void)hipGetLastError();
+            use_staged = false;
+          } else if (dev >= 0 && dev < 64) {
+            unsigned long long cur = opted_bytes[dev].load();
+            while (cur < staged_lds && !opted_bytes[dev].compare_exchange_weak(cur, staged_lds)) {}
           }
         }
+      }
+      if (use_staged) {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(kScatThreads), staged_lds, stream, a);
       } else {
         hipLaunchKernelGGL((k_bin_scatter_records<T, N, (int)kRecChunk>), dim3(blocks), dim3(kScatThreads), 0, stream, a);
@@ -683,7 +692,7 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   } else if (extras) {
     extras->key_q3 = 0;  // tells the launcher: plain indices
   }
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0, (unsigned)(g.cfg.hist_wgs_per_cu > 0 ? g.cfg.hist_wgs_per_cu * (g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) : 0))
+#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0, (unsigned)(g.cfg.hist_wgs_per_cu > 0 ? g.cfg.hist_wgs_per_cu * (g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) : 0), (size_t)g.cfg.lds_per_cu)
   if (g.dtype == kF64) {
     switch (g.ndims) {
       case 2: GO(double, 2);

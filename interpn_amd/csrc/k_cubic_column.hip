@@ -190,7 +190,9 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.sh3 = cp.sh3;
   a.sub_bytes = cp.sub_bytes;
   a.group_bytes = cp.group_bytes;
-  a.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)g.cfg.debug_stamps);
+  // time stamps (measurement aid): only into a buffer the caller has declared large enough for this launch's parts
+  a.stamps = (g.cfg.debug_stamps && (unsigned long long)g.cfg.debug_stamps_bytes >= (unsigned long long)max_parts * 64ull)
+                 ? reinterpret_cast<unsigned long long*>((uintptr_t)g.cfg.debug_stamps) : nullptr;
   a.ax.use_lds = 0;
   a.ax.use_rec = 0;
   a.ax.image = nullptr;

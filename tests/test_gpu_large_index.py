@@ -46,9 +46,6 @@ def test_more_than_2_to_32_points_through_eval_device(oracle):
             t[a:b].uniform_(lo[d], hi[d], generator=gen)
         obs.append(t)
     out = torch.full((npts,), -9.0, dtype=torch.float64, device=dev)
-    it.eval_tensors(obs, out)
-    it.finish()
-    assert "k_linear_brick" in it.kernel_name()
     rng = np.random.default_rng(5)
     idx = np.unique(np.concatenate([rng.integers(0, npts, 100_000), np.arange(npts - 1000, npts),
                                     np.arange((1 << 32) - 500, (1 << 32) + 500), np.arange(0, 1000)]))
@@ -56,15 +53,25 @@ def test_more_than_2_to_32_points_through_eval_device(oracle):
     sub = [np.ascontiguousarray(o[tidx].cpu().numpy()) for o in obs]
     want = np.zeros(idx.size)
     oracle.linear_regular(case.dims, case.starts, case.steps, case.vals, sub, want)
-    got = out[tidx].cpu().numpy()
-    assert np.array_equal(got, want)
+    # the sweep kernel (what a batch of this size takes by itself: 5.6e6 rounds of 768 points,
+    # linear_sweep.h) and the brick kernel
+    for sweep, kernel in ((-1, "k_linear_sweep"), (0, "k_linear_brick")):
+        it.set_option("sweep", sweep)
+        out.fill_(-9.0)
+        it.eval_tensors(obs, out)
+        it.finish()
+        assert kernel in it.kernel_name()
+        got = out[tidx].cpu().numpy()
+        assert np.array_equal(got, want), kernel
     bad = (1 << 32) + 7
     obs[1][bad] = float("nan")
     obs[2][npts - 3] = float("inf")  # a later failure must not win
-    it.eval_tensors(obs, out)
-    with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
-        it.finish()
-    assert ei.value.first_bad_index == bad
+    for sweep in (0, -1):
+        it.set_option("sweep", sweep)
+        it.eval_tensors(obs, out)
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            it.finish()
+        assert ei.value.first_bad_index == bad
     it.close()
 
 

@@ -932,6 +932,16 @@ def test_device_tensors_full_size_properties(oracle):
     it = interpn_amd.Interpolator.regular("linear", dims, starts, steps, vals)
     out = it.eval_tensors(obs)
     it.finish()
+    # the headline batch takes the sweep kernel on the one-line table (linear_sweep.h); the brick kernel
+    # on the handle's (1,2) table must give the same bits over the whole batch
+    assert it.last_path == "sweep" and it.kernel_name() == "interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false>", it.kernel_name()
+    it.set_option("sweep", 0)
+    brick = it.eval_tensors(obs)
+    it.finish()
+    assert it.kernel_name() == "interpn::k_linear_brick<double, 3, false, true, 1, 2, 2, 0, 0, 0>", it.kernel_name()
+    assert torch.equal(brick, out)
+    del brick
+    it.set_option("sweep", -1)
     # (a) sampled subset vs oracle
     idx = torch.randint(0, P, (500_000,), device=dev, generator=gen)
     sub = [o[idx].cpu().numpy() for o in obs]
@@ -1001,8 +1011,15 @@ def test_cfg3_full_size_rectilinear(oracle):
     obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
     it = interpn_amd.Interpolator.rectilinear("linear", grids, vals)
     _, name = _full_size_checks(torch, it, obs, lambda sub, want: oracle.linear_rectilinear(grids, vals, sub, want),
-                                500_000, (31_234_567, 47_000_001))
-    assert name.startswith("interpn::k_linear_brick<double, 3, true, true,") and name.endswith(", 2, 2, 0, 0>"), name
+                                500_000, (31_234_567, 47_000_001))  # (_ = the full batch's results)
+    # a batch of this size takes the sweep kernel (axes in lanes, lane tables: AXR = 2); the odd sub-range
+    # of _full_size_checks went through the brick kernel and had to give the same bits
+    assert name == "interpn::k_linear_sweep<double, true, true, 1, 1, 12, 768, 2, false>", name
+    it.set_option("sweep", 0)
+    again = it.eval_tensors([o[:20_000_000] for o in obs])
+    it.finish()
+    assert it.kernel_name().startswith("interpn::k_linear_brick<double, 3, true, true,") and it.kernel_name().endswith(", 2, 2, 0, 0>"), it.kernel_name()
+    assert torch.equal(again, _[:20_000_000])
     it.close()
 
 
@@ -1054,7 +1071,12 @@ def test_cfg5_shard_full_size(oracle):
     _, name = _full_size_checks(torch, it, obs,
                                 lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
                                 500_000, (61_234_567, 77_000_001))
-    assert name == "interpn::k_linear_brick<double, 3, false, true, 1, 1, 2, 0, 0, 0>", name
+    assert name == "interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false>", name
+    it.set_option("sweep", 0)
+    again = it.eval_tensors([o[:20_000_000] for o in obs])
+    it.finish()
+    assert it.kernel_name() == "interpn::k_linear_brick<double, 3, false, true, 1, 1, 2, 0, 0, 0>", it.kernel_name()
+    assert torch.equal(again, _[:20_000_000])
     it.close()
     mesh = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
     lin = np.ascontiguousarray(mesh @ np.array([0.5, -1.25, 2.0]) + 0.75)
@@ -2165,3 +2187,22 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
             assert np.array_equal(got[idx].cpu().numpy(), w)
     finally:
         it.close()
+
+
+def test_pool_trim_releases_what_destroyed_handles_left(oracle):
+    """`interpn_hip_trim`: the blocks of destroyed handles that the per-device pool keeps for reuse go
+    back to the driver on request (no public trim call existed; parked blocks could not be
+    reused).  After a trim a second one finds nothing; a new handle still works."""
+    import interpn_amd
+
+    case = synthetic_case("linear", "regular", 3, [40, 40, 40], 10_000, 31, np.float64, specials=False)
+    want = run_oracle(oracle, case, True)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    assert np.array_equal(it.eval_host(case.obs, np.zeros_like(want)), want)
+    it.close()
+    freed = interpn_amd.trim()
+    assert freed >= 40**3 * 8  # at least the grid's block came back
+    assert interpn_amd.trim() == 0
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    assert np.array_equal(it.eval_host(case.obs, np.zeros_like(want)), want)
+    it.close()

@@ -129,6 +129,7 @@ def main():
         stage = it.stage_ms() if hasattr(it, "stage_ms") else None
         it.set_option("stage_timing", 0)
         stamps.zero_()
+        it.set_option("debug_stamps_bytes", stamps.numel() * stamps.element_size())
         it.set_option("debug_stamps", stamps.data_ptr())
         it.eval_tensors(obs, out)
         it.finish()
