@@ -866,6 +866,21 @@ def worker(args):
                 "launches": len(ms), "seconds": round(float(np.sum(ms)) / 1e3, 3), "kernel_ms": round(sk, 4),
                 "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_max": round(float(np.max(ms)), 4),
                 "achieved": round(P * bpp / (sk * 1e-3) / 1e9, 1), "frac": round(P * bpp / (sk * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            # the same handle with the sweep kernel switched off: the brick kernel on the handle's own table
+            # (what every round before round 5 measured), bit-compared over the whole batch
+            if kernel.startswith("interpn::k_linear_sweep<"):
+                try:
+                    keep = out.clone()
+                    it.set_option("sweep", 0)
+                    msb = time_launches(torch, it, obs, out, seconds=min(0.25, args.sustain_seconds))
+                    rec["roofline"]["brick_kernel"] = {
+                        "kernel": it.kernel_name(), "kernel_ms": round(float(np.mean(msb)), 4), "launches": len(msb),
+                        "frac": round(P * bpp / (float(np.mean(msb)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "table_MiB": round(it.table_layout()[0] / 2**20, 2), "bitwise_equal_to_sweep": bool(torch.equal(out, keep)),
+                        "note": "same handle, option sweep = 0: one pass of 512-point workgroups over unordered points"}
+                    del keep
+                finally:
+                    it.set_option("sweep", -1)
             if not args.no_ablate:
                 try:
                     rec["roofline"]["ablation"] = run_ablation(torch, spec, obs, out, it, 0.25)

@@ -514,8 +514,11 @@ __device__ __noinline__ T col_slow_point_rect(__amdgpu_buffer_rsrc_t rsrc, unsig
 // wave wrote to LDS before its add is visible to every wave that sees the counter complete; the
 // LDS-DMA of a fill is waited for (vmcnt) by the issuing wave before it arrives here.  GW == 0: the
 // group is the whole workgroup (s_barrier).
+// `diag` (diagnosis builds, INTERPN_COLUMN_DIAG): set to non-zero when a wave reaches a barrier with
+// lanes switched off — an s_barrier there would be executed by waves whose EXEC is empty as well.
 template <int GW>
-__device__ __forceinline__ void col_group_barrier(unsigned* ctr, unsigned& epoch, unsigned wl) {
+__device__ __forceinline__ void col_group_barrier(unsigned* ctr, unsigned& epoch, unsigned wl, unsigned* diag = nullptr) {
+  if (diag && __builtin_amdgcn_read_exec() != ~0ull) *diag |= 1u;
   if constexpr (GW == 0) {
     __syncthreads();
   } else {
@@ -608,6 +611,16 @@ k_cubic_column(const CubicColumnArgs<T> a) {
 
   const unsigned gtid_k = tid - grp * (unsigned)GT;
   const unsigned index_mask = a.index_keys ? 0x00FFFFFFu : 0xFFFFFFFFu;
+#ifdef INTERPN_COLUMN_DIAG
+  // Diagnosis build (tools/column_barrier_diag.py): does the source meet s_barrier's contract?  Per part,
+  // every wave reports how many group barriers it went through (they must agree) and whether it ever
+  // reached one with lanes switched off; the words go where the STAMPS build keeps its time stamps.
+  unsigned diag_bits = 0, diag_epoch0 = 0;
+  unsigned diag_prev = ~0u;
+#define COL_DIAG_ARG (&diag_bits)
+#else
+#define COL_DIAG_ARG nullptr
+#endif
   for (;;) {
     // Per-part copies of the thread ids that the optimiser cannot see through: everything derived
     // from them (16 record addresses, fill offsets, ...) is then recomputed per part instead of
@@ -615,10 +628,25 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     unsigned gtid = gtid_k;
     asm volatile("" : "+v"(gtid));
     const unsigned gwave = (unsigned)__builtin_amdgcn_readfirstlane((int)(gtid >> 6)), wl = gtid & 63u;
+#ifdef INTERPN_COLUMN_DIAG
+    if (a.stamps && diag_prev != ~0u && wl == 0) {  // the part just finished: [1] most, [2] fewest barriers of a wave, [3] lanes-off flag
+      unsigned long long* ws = a.stamps + (size_t)diag_prev * 8u;
+      const unsigned long long nbar = (epoch - diag_epoch0) / (unsigned)GW;
+      atomicMax(&ws[1], nbar);
+      atomicMin(&ws[2], nbar);
+      if (diag_bits) atomicOr(&ws[3], 1ull);
+      atomicAdd(&ws[0], 1ull);  // waves that reported
+    }
+    diag_bits = 0;
+#endif
     // ---- next part for this group
     if (gtid == 0) s_ctl[1] = atomicAdd(a.work, 1u);
-    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
     const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[1]);  // group-uniform values go to scalar registers
+#ifdef INTERPN_COLUMN_DIAG
+    diag_prev = w < total_parts ? w : ~0u;
+    diag_epoch0 = epoch;  // barriers of this part: from here to the next part's first one (inclusive)
+#endif
     if (w >= total_parts) break;
     unsigned long long t_stamp[5] = {0, 0, 0, 0, 0};
     if (STAMPS && gtid == 0) t_stamp[0] = wall_clock64();
@@ -643,7 +671,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
     }
     for (unsigned c = gtid; c < (unsigned)kColKeys; c += GT) s_hist[c] = 0;
     if (gtid == 0) s_ctl[5] = 0;
-    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
     const int bin = __builtin_amdgcn_readfirstlane((int)s_ctl[2]);
     const unsigned begin = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[3]), end = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[4]);
     if (begin >= end) continue;          // group-uniform
@@ -772,7 +800,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
         fill(row0, nrows);
       }
     }
-    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
     if (STAMPS && gtid == 0) t_stamp[2] = wall_clock64();
     // exclusive scan of the counters: CPT consecutive counters per thread, wave scan, wave totals
     {
@@ -788,13 +816,13 @@ k_cubic_column(const CubicColumnArgs<T> a) {
         if (wl >= (unsigned)off) incl += up;
       }
       if (wl == 63u) s_wave[gwave] = incl;
-      col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+      col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
       unsigned run = incl - sum;
       for (unsigned ww = 0; ww < gwave; ++ww) run += s_wave[ww];
 #pragma unroll
       for (int c = 0; c < CPT; ++c) { if (gtid * CPT + c < (unsigned)kColKeys) s_hist[gtid * CPT + c] = run; run += mine[c]; }
     }
-    col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+    col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
     // pass 2: slots (each counter ends up at the END of its key's stretch = the start of the next key's)
 #pragma unroll
     for (int m = 0; m < PT; ++m) {
@@ -811,12 +839,12 @@ k_cubic_column(const CubicColumnArgs<T> a) {
       if (r > 0) {
         phase_stretch(r, &ps, &pe);  // final: phase 0's barrier lies behind pass 2
         if (pe == ps) continue;      // group-uniform: nobody needs these rows
-        col_group_barrier<BAR>(&s_ctl[0], epoch, wl);  // every wave has finished with the previous sub-column
+        col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);  // every wave has finished with the previous sub-column
         if (gtid == 0) s_ctl[5] = 0;
         fill(row0, nrows);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the sub-column has landed
-      col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+      col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
       if (r == 0) {
         if (STAMPS && gtid == 0) t_stamp[4] = wall_clock64();
         phase_stretch(0, &ps, &pe);
@@ -824,7 +852,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
       }
       if (xf >= 0) {  // group-uniform
         to_coef(nrows);
-        col_group_barrier<BAR>(&s_ctl[0], epoch, wl);
+        col_group_barrier<BAR>(&s_ctl[0], epoch, wl, COL_DIAG_ARG);
       }
       const int row_top = (int)nrows - 4;  // largest footprint row inside the sub-column
 
@@ -959,6 +987,7 @@ k_cubic_column(const CubicColumnArgs<T> a) {
         jw = jn;
       }
     }
+#ifndef INTERPN_COLUMN_DIAG
     if (STAMPS && a.stamps) {
       // [0..4] thread 0's stamps (part drawn | part known | histogram | local order | first sub-column),
       // [5] the group's LAST wave's end, [6] ids, [7] count | group | bin
@@ -975,7 +1004,9 @@ k_cubic_column(const CubicColumnArgs<T> a) {
         ws[7] = ((unsigned long long)count << 32) | ((unsigned long long)grp << 16) | (unsigned)(bin & 0xFFFF);
       }
     }
+#endif
   }
+#undef COL_DIAG_ARG
 }
 
 }  // namespace interpn

@@ -12,6 +12,9 @@ constexpr int kSweepRows = 12;       // rows of 64 points per wave and round: 15
 constexpr int kSweepThreads = 768;   // one workgroup per CU
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
 constexpr size_t kSweepPointsPerCu = (size_t)kSweepRows * kSweepThreads;
+// LDS the axis image of a rectilinear grid may take beside the waves' regions (92 KiB of a CU's 160): what
+// fill_axis_args allows the brick kernels (20 KiB) — per-bucket records of up to ~500 coordinates per axis
+constexpr size_t kSweepAxisLds = 20 * 1024;
 
 size_t brick_lines(const GridDesc& g, int si, int sj) {
   unsigned nb[3];
@@ -32,7 +35,6 @@ size_t sweep_work_bytes() { return sizeof(SweepWork); }
 // Returns false where the sweep does not apply to the handle at all.
 bool sweep_layout(const GridDesc& g, int* si, int* sj) {
   if (g.method != kLinear || g.ndims != 3 || g.dtype != kF64 || g.cfg.sweep == 0) return false;
-  if (g.kind == kRectilinear && lane_axes_mode(g) == 0) return false;
   const size_t window = kSweepPointsPerCu * (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) * 85 / 100;  // ~ the share of a round spent in rows
   const size_t l11 = brick_lines(g, 1, 1), l12 = brick_lines(g, 1, 2);
   const int xcds = g.cfg.num_xcds > 0 ? g.cfg.num_xcds : 8;
@@ -59,12 +61,14 @@ template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR>
 static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
   constexpr int K = kSweepRows, TH = kSweepThreads;
   auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false>;
-  const size_t lds = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup;
+  const size_t lds = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup + ((RECT && AXR == 4 && s.b.ax.use_lds) ? (size_t)s.b.ax.image_bytes : 0);
   static std::atomic<unsigned long long> opted{0};  // bit per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !((opted.load() >> dev) & 1ull))) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (the largest this instantiation ever asks for: its waves' regions + the axis image budget)
+    const size_t most = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup + (RECT && AXR == 4 ? kSweepAxisLds : 0);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);
   }
@@ -110,8 +114,9 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
   int axr = 0;
   if (g.kind == kRectilinear) {
     axr = lane_axes_mode(g);
-    if (axr == 0) return hipErrorInvalidValue;
-    (void)fill_axis_args<T, 3>(g, a.ax, false, /*records=*/false);
+    if (axr == 0) axr = 4;  // axes longer than a wave: searched in the (LDS-staged) axis image
+    (void)fill_axis_args<T, 3>(g, a.ax, false, /*records=*/axr == 4);
+    if (a.ax.use_lds && a.ax.image_bytes > kSweepAxisLds) a.ax.use_lds = 0;
     // the uniform grid over the leading axis' span (bound_lo / bound_hi are g[0] and g[n-1])
     const double span = g.bound_hi[0] - g.bound_lo[0];
     s.key_start = (T)g.bound_lo[0];
@@ -142,6 +147,7 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
     case 1: return SWEEP_KIND(true, 1);
     case 2: return SWEEP_KIND(true, 2);
     case 3: return SWEEP_KIND(true, 3);
+    case 4: return SWEEP_KIND(true, 4);
   }
 #undef SWEEP_KIND
   return hipErrorInvalidValue;

@@ -78,8 +78,11 @@ struct SweepLds {
   static constexpr unsigned kWorkgroup = 16;  // behind the waves' regions: ticks | rounds | waves done | -
 };
 
-// RECT: rectilinear axes of at most 64 coordinates, held one coordinate per lane and searched with
-// cross-lane reads (lane_axes.h; AXR = its mode 1..3), exactly as in the brick kernel.
+// RECT: rectilinear grids, the cell search exactly as in the brick kernel — axes of at most 64
+// coordinates held one coordinate per lane and searched with cross-lane reads (lane_axes.h; AXR =
+// its mode 1..3); longer axes (AXR = 4) searched with interpn_device.h::axis_cell in the axis image
+// (coordinates + bucket tables, or per-bucket records) that the workgroup stages into LDS behind
+// its waves' regions (a.ax.use_lds), or through L1/L2 where that image is too large.
 template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false>
 __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
   static_assert(K % 2 == 0 && K >= 2 && K <= 32, "rows per wave and round");
@@ -102,13 +105,27 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kCnt);
   lds_u32* const wg_words = reinterpret_cast<lds_u32*>(smem_raw + (THREADS / 64) * L::kWave);  // ticks | rounds | waves done
   if (threadIdx.x < 4) wg_words[threadIdx.x] = 0;
+  if constexpr (RECT && AXR == 4) {
+    if (s.b.ax.use_lds) {
+      const unsigned words = s.b.ax.image_bytes >> 2;
+      const unsigned* src = reinterpret_cast<const unsigned*>(s.b.ax.image);
+      unsigned* dst = reinterpret_cast<unsigned*>(smem_raw + (THREADS / 64) * L::kWave + L::kWorkgroup);
+      for (unsigned k = threadIdx.x; k < words; k += THREADS) dst[k] = src[k];
+    }
+  }
   __syncthreads();  // the only workgroup barrier: before any wave has taken work
   const unsigned q = lane & 3u;
   const unsigned quad = lane >> 2;
   constexpr size_t kChunk = (size_t)64 * K;
   const unsigned nwaves = gridDim.x * (THREADS / 64);
   LaneAxes<T, 3> la;
-  if constexpr (RECT) la = load_lane_axes<T, 3, AXR>(a.ax);
+  if constexpr (RECT && AXR <= 3) la = load_lane_axes<T, 3, AXR>(a.ax);
+  const unsigned char* axis_base = a.ax.image;
+  if constexpr (RECT && AXR == 4) {
+    if (a.ax.use_lds) {  // staged before the workgroup's one barrier (above: wg_words)
+      axis_base = smem_raw + (THREADS / 64) * L::kWave + L::kWorkgroup;
+    }
+  }
   SweepWork* const work = s.work;
   unsigned period = s.period;
   if (period == 0) {
@@ -230,7 +247,15 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       __builtin_amdgcn_sched_barrier(0);
       T t[3];
       int loc[3];
-      if constexpr (RECT) {
+      if constexpr (RECT && AXR == 4) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const Axis<T> ax = make_axis<T, 3>(a.ax, axis_base, d);
+          T x0, x1;
+          loc[d] = axis_cell<T>(ax, x[k][d], &x0, &x1);   // multilinear/rectilinear.rs:353-370, :310-311
+          t[d] = (x[k][d] - x0) / (x1 - x0);              // rectilinear.rs:310-313
+        }
+      } else if constexpr (RECT) {
         T xin[1][3], x0_r[1][3], x1_r[1][3];
         int cell_r[1][3];
 #pragma unroll

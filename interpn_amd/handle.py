@@ -124,7 +124,12 @@ class Interpolator:
         return buf.value.decode()
 
     def table_layout(self):
-        """(bytes, step_i, step_j) of the re-laid grid copy the kernels read; (0, 0, 0) = C order."""
+        """(bytes, step_i, step_j) of the re-laid grid copy the kernels read; (0, 0, 0) = C order.
+        After an evaluation that took the sweep kernel: that kernel's table (a handle may keep two
+        brick tables, e.g. 64^3 f64: (1,2) for the brick kernel, (1,1) for the sweep)."""
+        if self.kernel_name().startswith("interpn::k_linear_sweep<"):
+            lay = self.get_option("sweep_layout")
+            return self.get_option("sweep_table_bytes"), lay // 10, lay % 10
         si, sj = ctypes.c_int(0), ctypes.c_int(0)
         nbytes = _lib.load().interpn_hip_table_bytes(self._h, ctypes.byref(si), ctypes.byref(sj))
         return int(nbytes), int(si.value), int(sj.value)

@@ -2072,8 +2072,13 @@ def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True):
 @pytest.mark.parametrize("kind,axis,env", [("regular", [20, 17, 33], None), ("regular", [64, 9, 12], None),
                                            ("regular", [130, 6, 7], None),  # leading cell index >> 2 for the 64 bins
                                            ("rectilinear", [24, 11, 40], None), ("rectilinear", [64, 64, 5], None),
-                                           ("rectilinear", [24, 11, 40], {"axis_regs": 1})],
-                         ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence"])
+                                           ("rectilinear", [24, 11, 40], {"axis_regs": 1}),
+                                           # axes longer than a wave: searched in the LDS-staged axis image (records, or
+                                           # coordinates + tables), or through L1/L2 where it exceeds the sweep's 20 KiB
+                                           ("rectilinear", [70, 33, 90], None), ("rectilinear", [70, 33, 90], {"axis_records": 0}),
+                                           ("rectilinear", [900, 12, 9], None), ("rectilinear", [33, 30, 31], {"axis_regs": 0})],
+                         ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence", "rect_long", "rect_long_tables",
+                              "rect_900", "rect_lds_forced"])
 def test_sweep_evaluation(oracle, kind, axis, env, fma):
     """The sweep evaluation of 3-D f64 multilinear batches (linear_sweep.h: every wave sorts 768
     points by leading cell index on chip and walks its rows in step with a clock) against the oracle

@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -34,12 +34,14 @@ def run_device(case, rng, dtype, fma=None):
     try:
         nobs = case.obs[0].size
         obs_t = []
+        # (the sweep kernel takes 16-byte aligned streams only: mostly even element offsets when it is forced)
+        sweep = os.environ.get("INTERPN_HIP_SWEEP") == "1"
         for o in case.obs:
-            off = int(rng.integers(0, 4))
+            off = int(rng.choice([0, 2, 0, 2, 1])) if sweep else int(rng.integers(0, 4))
             t = torch.empty(nobs + off, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
             t[off:].copy_(torch.from_numpy(np.ascontiguousarray(o)))
             obs_t.append(t[off:])
-        off = int(rng.integers(0, 4))
+        off = int(rng.choice([0, 2, 0, 2, 3])) if sweep else int(rng.integers(0, 4))
         out_full = torch.full((nobs + off,), -777.0, dtype=obs_t[0].dtype, device="cuda")
         out_t = out_full[off:]
         it.eval_tensors(obs_t, out_t)
@@ -126,6 +128,12 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 if rng.random() < 0.5: env["INTERPN_HIP_COLUMN_PAD"] = str(int(rng.integers(0, 2)))
                 if rng.random() < 0.4: env["INTERPN_HIP_COLUMN_TAIL"] = str(int(rng.choice([0, 0x22, 0x54, 0x1f])))
                 if rng.random() < 0.4: env["INTERPN_HIP_COLUMN_KEYS"] = "0"
+            # round 5: the sweep evaluation of 3-D f64 multilinear batches (device entry point), forced on batches of
+            # any size, with the measured period, a fixed one, or no clock
+            if method == "linear" and N == 3 and dtype == np.float64 and rng.random() < 0.7:
+                env["INTERPN_HIP_SWEEP"] = "1"
+                env["INTERPN_HIP_SWEEP_PERIOD"] = str(int(rng.choice([0, 0, 1, 300, 2500])))
+                env.pop("INTERPN_HIP_FORCE_GENERIC", None)
             if kind == "rectilinear" and rng.random() < 0.3: env["INTERPN_HIP_AXIS_RECORDS"] = "0"
             # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
             if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
@@ -153,7 +161,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 run_oracle(pyoracle, case, fma, out=want)
             except AssertionError as e:
                 err_o = str(e)
-            device_path = rng.random() < 0.3 or "INTERPN_HIP_COLUMN" in env
+            device_path = rng.random() < 0.3 or "INTERPN_HIP_COLUMN" in env or "INTERPN_HIP_SWEEP" in env
             # per-handle flavour (round 3): on the device path half of the cases pass the flavour to the handle while the
             # process default says the opposite
             fma_arg = None
