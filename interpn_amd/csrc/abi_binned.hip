@@ -32,8 +32,10 @@ int binned_applies(const GridDesc& g, size_t npoints) {
   const bool main11 = g.brick_step[0] == 1 && g.brick_step[1] == 1;
   const bool second = !main11 && g.bricks11 != nullptr;
   if (g.cfg.binned < 0) {
-    if (g.ndims != 4) return 0;
+    if (g.ndims != 4 && g.ndims != 3) return 0;
     if (!main11 && !second) return 0;
+    if (g.ndims == 3) return 0;  // 3-D: never by itself — measured (round 5, 64^3 f64, 1e7 points): sort 0.35 + column kernel 0.55 ms
+                                 // against 0.65 in place (four miss lines per point); option "binned" = 1 takes it (cubic3_column.h)
     if (main11) {
       unsigned nb[2];
       size_t table = 0;
@@ -157,10 +159,13 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     use = &second_desc;
   }
   BinPlan plan;
+  bool column3_go = false;
   // Column evaluation (cubic_column.h): 4-D regular grids whose (k, l) column of tiles fits the LDS
   // and whose (i, j) cells fit one bin each — cfg4.  The sorted points of a cell are then
   // evaluated out of LDS instead of 16 L2 lines per point.
   bool column = g.cfg.column != 0 && (second || main11) && cubic_column_applies(*use);
+  const bool column3 = g.ndims == 3 && g.cfg.column != 0 && (second || main11) && cubic3_column_applies(*use);
+  if (g.ndims == 3 && g.cfg.binned < 0 && !column3) { *why = INTERPN_HIP_WHY_NONE; return -1; }
   {
     // automatic mode: a part's rows must be mostly full and its column fills amortised — from about
     // three rows of the workgroup's lanes per (class pair) bin on (768 threads: 2304 points; 32^4,
@@ -187,8 +192,14 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     size_t tbytes = 0;  // of the table the sorted points will be evaluated on
     if (second || main11) cubic_tile_geometry(g, 1, 1, nbt, &tbytes);
     else cubic_tile_geometry(g, g.brick_step[0], g.brick_step[1], nbt, &tbytes);
-    if (column && !make_bin_plan(g, tbytes, &plan, /*classes=*/true)) column = false;
-    if (!column && !make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
+    bool have_plan = false;
+    if (column3) have_plan = make_bin_plan(g, tbytes, &plan, /*classes=*/true);
+    if (column3 && !have_plan && g.cfg.binned < 0) { *why = INTERPN_HIP_WHY_NONE; return -1; }
+    if (!have_plan) {
+      if (column && !make_bin_plan(g, tbytes, &plan, /*classes=*/true)) column = false;
+      if (!column && !make_bin_plan(g, tbytes, &plan)) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
+    }
+    column3_go = column3 && have_plan;
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
@@ -217,6 +228,19 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     for (int d = 0; d < g.ndims; ++d) src[d] = static_cast<const char*>(obs[d]) + begin * elem;
     const unsigned* index = nullptr;
     char* dst = static_cast<char*>(out) + begin * elem;
+    if (column3_go) {  // 3-D: the cell's column of n2 tiles (cubic3_column.h)
+      const size_t q3 = cubic3_column_part_points();
+      const size_t max_parts3 = 4 * (count / q3) + (size_t)plan.nbins + 1;
+      BinExtras extras3;
+      err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras3, (unsigned)q3, stage, slot->totals_clean);
+      slot->totals_clean = err == hipSuccess;
+      if (err != hipSuccess) break;
+      if (g.dtype == kF64)
+        err = launch_cubic3_column<double>(*use, plan, extras3, index, reinterpret_cast<double*>(dst), count, max_parts3, h->first_bad, begin, stream);
+      else
+        err = launch_cubic3_column<float>(*use, plan, extras3, index, reinterpret_cast<float*>(dst), count, max_parts3, h->first_bad, begin, stream);
+      continue;
+    }
     if (column) {
       // a bin is cut into equal parts of at most 16 points per thread of the column workgroup (the
       // registers of its local sort); two such workgroups share a CU, the dispatcher hands parts

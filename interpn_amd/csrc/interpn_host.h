@@ -344,6 +344,13 @@ template <typename T>
 hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
                                T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,
                                hipStream_t stream);
+// The same for sorted 3-D points (cubic3_column.h): the cell's column of n2 tiles in LDS, 256-thread workgroups.
+bool cubic3_column_applies(const GridDesc& g);
+unsigned cubic3_column_part_points();
+template <typename T>
+hipError_t launch_cubic3_column(const GridDesc& g, const BinPlan& plan, const BinExtras& extras, const unsigned* index,
+                                T* out, size_t npts, size_t max_parts, unsigned long long* first_bad, size_t index_base,
+                                hipStream_t stream);
 
 // Bucket table of one axis (device): tab[0..M] from the coordinates g[0..n).
 template <typename T>

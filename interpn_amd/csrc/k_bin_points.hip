@@ -644,15 +644,19 @@ bool make_bin_plan(const GridDesc& g, size_t table_bytes, BinPlan* plan, bool cl
 
 size_t bin_scratch_bytes(const GridDesc& g, size_t slice_points) {
   const size_t elem = g.dtype == kF64 ? 8 : 4;
+  const size_t arrays = g.ndims == 3 ? 4 : (size_t)g.ndims;  // 3-D records take the 4-D form (bin_points)
   size_t b = align_up(kCounterBytes, 256) + align_up(slice_points * sizeof(unsigned), 256) +
-             (size_t)g.ndims * align_up(slice_points * elem, 256);
+             arrays * align_up(slice_points * elem, 256);
   return b;
 }
 
 hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const* obs, size_t npts, void* scratch,
                       const void** binned_obs, const unsigned** index, hipStream_t stream, BinExtras* extras,
                       unsigned part_points, hipEvent_t* stage, bool totals_clean) {
-  if (extras && g.ndims != 4) return hipErrorInvalidValue;
+  if (extras && g.ndims != 4 && g.ndims != 3) return hipErrorInvalidValue;
+  // 3-D points sorted into records (cubic3_column.h) take the 4-D record form with dim 2 twice: (x0, x1, x2, x2)
+  const void* obs4[4] = {obs[0], obs[1], g.ndims > 2 ? obs[2] : nullptr, g.ndims > 3 ? obs[3] : (g.ndims > 2 ? obs[2] : nullptr)};
+  const bool as4 = extras && g.ndims == 3;
   if (npts == 0 || npts > kBinSlicePoints) return hipErrorInvalidValue;
   BinParams p;
   for (int d = 0; d < 2; ++d) {
@@ -692,15 +696,15 @@ hipError_t bin_points(const GridDesc& g, const BinPlan& plan, const void* const*
   } else if (extras) {
     extras->key_q3 = 0;  // tells the launcher: plain indices
   }
-#define GO(T, N) return bin_points_n<T, N>(p, obs, npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0, (unsigned)(g.cfg.hist_wgs_per_cu > 0 ? g.cfg.hist_wgs_per_cu * (g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) : 0), (size_t)g.cfg.lds_per_cu)
+#define GO(T, N) return bin_points_n<T, N>(p, (as4 ? obs4 : obs), npts, scratch, binned_obs, index, extras, part_points, stream, stage, totals_clean, g.cfg.scatter_staged != 0, (unsigned)(g.cfg.hist_wgs_per_cu > 0 ? g.cfg.hist_wgs_per_cu * (g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) : 0), (size_t)g.cfg.lds_per_cu)
   if (g.dtype == kF64) {
-    switch (g.ndims) {
+    switch (as4 ? 4 : g.ndims) {
       case 2: GO(double, 2);
       case 3: GO(double, 3);
       case 4: GO(double, 4);
     }
   } else {
-    switch (g.ndims) {
+    switch (as4 ? 4 : g.ndims) {
       case 2: GO(float, 2);
       case 3: GO(float, 3);
       case 4: GO(float, 4);

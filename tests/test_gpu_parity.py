@@ -2211,3 +2211,104 @@ def test_pool_trim_releases_what_destroyed_handles_left(oracle):
     it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
     assert np.array_equal(it.eval_host(case.obs, np.zeros_like(want)), want)
     it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+@pytest.mark.parametrize("axis", [[6, 7, 5], [4, 4, 4], [20, 17, 33], [64, 64, 9], [33, 12, 130]], ids=str)
+def test_column_evaluation_of_sorted_3d_multicubic(oracle, monkeypatch, dtype, axis, kind):
+    """Column evaluation for N = 3 (cubic3_column.h): large 3-D multicubic batches are sorted by the
+    saturation-class pair of dims 0, 1 (the 4-D sort with dim 2 twice in the record) and a 256-thread
+    workgroup evaluates its bin's points out of the cell's column of n2 tiles in LDS.  Forced here at
+    small sizes: batches from one point to several parts per bin with ragged tails, ~30 % of the points
+    extrapolating (every node form), both `linearize_extrapolation` values, every fifth point sorted into
+    the wrong bin (`bin_scramble`: the out-of-cell path, the same tree from the table in global memory),
+    the scatter staged or direct, NaN / inf coordinates (regular: the first failing ORIGINAL index;
+    rectilinear: they propagate): always the oracle's bits.  [64, 64, 9]: 3969 class-pair bins; [33, 12, 130]:
+    a column of 130 tiles.  src/multicubic/regular.rs:325-623, rectilinear.rs:265-545."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    want_t = torch.float64 if dtype == np.float64 else torch.float32
+    for case_no, (nobs, scramble) in enumerate(((1, 0), (700, 0), (5_000, 1), (40_001, 0), (250_013, 1), (250_014, 0))):
+        lin = bool((nobs + case_no) % 2)
+        case = synthetic_case("cubic", kind, 3, axis, nobs, 8800 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
+                              specials=min(axis) >= 8)
+        want = run_oracle(oracle, case, True)
+        it = _make_interp(interpn_amd, case)
+        for k, v in (("binned", 1), ("column", 1), ("bin_scramble", scramble), ("scatter_staged", case_no % 2)):
+            it.set_option(k, v)
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        out_full = torch.full((nobs + 2,), -5.0, dtype=want_t, device=dev)
+        out = out_full[1:1 + nobs]
+        it.eval_tensors(obs, out)
+        it.finish()
+        assert it.last_path == "binned" and it.kernel_name().startswith("interpn::k_cubic3_column<"), it.kernel_name()
+        got = out.cpu().numpy()
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert np.all(same), (case_no, nobs, scramble, int((~same).sum()))
+        assert float(out_full[0]) == -5.0 and float(out_full[-1]) == -5.0  # nothing outside the batch was written
+        if nobs > 1000:
+            odd = [o.clone() for o in obs]
+            odd[2][nobs // 2] = float("nan")
+            odd[0][nobs // 2 + 17] = float("inf")
+            if kind == "rectilinear":  # never fails per point: NaN / inf go through the search and propagate
+                ocase = synthetic_case("cubic", kind, 3, axis, nobs, 8800 + sum(axis) + nobs, dtype, linearize=lin, extrap=0.3,
+                                       specials=min(axis) >= 8)
+                ocase.obs[2][nobs // 2] = np.nan
+                ocase.obs[0][nobs // 2 + 17] = np.inf
+                owant = run_oracle(oracle, ocase, True)
+                og = it.eval_tensors(odd).cpu().numpy()
+                it.finish()
+                assert np.all((og == owant) | (np.isnan(og) & np.isnan(owant)))
+            else:
+                it.eval_tensors(odd, out)
+                with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                    it.finish()
+                assert ei.value.first_bad_index == nobs // 2
+        # the same handle with the points evaluated in place: the same bits
+        it.set_option("binned", 0)
+        ref = it.eval_tensors(obs)
+        it.finish()
+        rg = ref.cpu().numpy()
+        assert it.last_path == "in_place" and np.all((rg == got) | (np.isnan(rg) & np.isnan(got)))
+        it.close()
+
+
+def test_column_evaluation_3d_only_on_request(oracle, monkeypatch):
+    """The 3-D column path is never taken by itself (64^3 f64 at 1e7 points: sort 0.35 ms + kernel 0.55 against
+    0.65 in place, profiles/REJECTED.md round 5); a handle created with INTERPN_HIP_BINNED=1 keeps the fully
+    overlapped tile table beside its in-place layout and takes it: the oracle's bits either way."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = 64
+    g = np.linspace(-1.0, 1.0, n)
+    dims, starts, steps = [n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0])
+    vals = np.random.default_rng(31).uniform(-1, 1, n**3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(32)
+    count = 4_000_000
+    obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
+    idx = torch.randint(0, count, (100_000,), device=dev, generator=gen)
+    sub = [o[idx].cpu().numpy() for o in obs]
+    w = np.zeros(idx.numel())
+    oracle.cubic_regular(dims, starts, steps, vals, True, sub, w)
+    for env, path in ((None, "in_place"), ("1", "binned")):
+        if env:
+            monkeypatch.setenv("INTERPN_HIP_BINNED", env)
+        it = interpn_amd.Interpolator.regular("cubic", dims, starts, steps, vals, linearize_extrapolation=True)
+        try:
+            got = it.eval_tensors(obs)
+            assert it.last_path == path, (it.last_path, it.last_path_reason)
+            if path == "binned":
+                assert it.kernel_name().startswith("interpn::k_cubic3_column<double, false, true>"), it.kernel_name()
+            it.finish()
+            assert np.array_equal(got[idx].cpu().numpy(), w)
+        finally:
+            it.close()
