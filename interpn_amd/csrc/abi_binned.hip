@@ -387,11 +387,13 @@ int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {
   if (!h || nstreams < 0) return INTERPN_HIP_ERR_INVALID_ARGUMENT;
   if ((size_t)nstreams > interpn_hip_interp::kMaxBinSlots) nstreams = (int)interpn_hip_interp::kMaxBinSlots;
   const GridDesc& g = h->desc;
-  if (npoints == 0 || nstreams == 0 || binned_applies(g, npoints) < 2) return INTERPN_HIP_OK;  // nothing to provide
+  const bool sorts = binned_applies(g, npoints) >= 2, sweeps = sweep_applies(g, npoints) >= 2;
+  if (npoints == 0 || nstreams == 0 || (!sorts && !sweeps)) return INTERPN_HIP_OK;  // nothing to provide
   DeviceGuard guard(h->device);
   if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
   const size_t slice_max = bin_slice_points(g);
-  const size_t need = bin_scratch_bytes(g, npoints < slice_max ? npoints : slice_max);
+  // the sorted path's slice, or the sweep kernel's work words (linear_sweep.h: 1.25 KiB per stream)
+  const size_t need = sorts ? bin_scratch_bytes(g, npoints < slice_max ? npoints : slice_max) : sweep_work_bytes();
   std::lock_guard<std::mutex> lk(h->bin_mu);
   int have = 0;
   for (auto& sl : h->bin_slots)

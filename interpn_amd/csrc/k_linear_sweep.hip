@@ -50,10 +50,11 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if (g.cfg.sweep > 0) return 2;
   // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
   // must give every wave a few rounds (the period is a round's duration; the launch's start and end
-  // are a round each)
+  // cost ~35 us more than the brick kernel's).  Measured crossover (profiles/r05_sweep_threshold.jsonl):
+  // 64^3 at 1.4e7 points, 80^3 at 6e6, 128^3 at 1e7; six rounds per wave = 1.42e7 points is never slower.
   if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
-  if (npts < 4 * kSweepPointsPerCu * cus) return 1;
+  if (npts < 6 * kSweepPointsPerCu * cus) return 1;
   return 2;
 }
 

@@ -2167,6 +2167,14 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
         it.finish()
         for a, b in outs:
             assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
+        # scratch reserved up front: no allocation on the launch path, also when allocation is forbidden
+        it.reserve(n, 2)
+        allocs = it.get_option("scratch_allocs")
+        a = it.eval_tensors(obs, stream=s1, no_alloc=True)
+        b = it.eval_tensors(obs, stream=s2, no_alloc=True)
+        assert it.last_path == "sweep" and it.get_option("scratch_allocs") == allocs
+        it.finish()
+        assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
         # automatic mode: this grid's table is L2-sized -> never; a 64^3 grid: only for batches that give every wave a few rounds
         it.set_option("sweep", -1)
         it.eval_tensors(obs)
@@ -2180,7 +2188,7 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
         assert it.get_option("sweep_layout") == 11 and it.table_layout()[1:] == (1, 2)
         gen = torch.Generator(device=dev)
         gen.manual_seed(11)
-        for count, path in ((1_000_000, "in_place"), (12_000_003, "sweep")):
+        for count, path in ((1_000_000, "in_place"), (15_000_003, "sweep")):
             obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
             got = it.eval_tensors(obs)
             assert it.last_path == path, (count, it.last_path, it.last_path_reason)

@@ -10,7 +10,8 @@ import os
 import re
 
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-OUT = R + "/gpurun_out/prof_r04"
+TAG = os.environ.get("PROF_TAG", "prof_r04")  # tools/profile_r05.sh: prof_r05
+OUT = R + "/gpurun_out/" + TAG
 
 
 def rows(pattern):
@@ -48,7 +49,7 @@ res = {"fetch_correction": fetch_corr, "write_correction": write_corr,
                             if cal.get("FETCH_SIZE") else "MI355X_MICROARCH.md section HBM (calibration kernel not run)",
        "configs": {}}
 main_kernel = {"cfg2": "k_linear_brick", "cfg3": "k_linear_brick", "cfg5": "k_linear_brick", "cfg4": None}
-for key in ("cfg2", "cfg3", "cfg5", "cfg4"):
+for key in ("cfg2", "cfg3", "cfg5", "cfg4", "cfg2brick"):
     t = last_json(f"{OUT}/{key}.time")
     if not t:
         continue
@@ -60,7 +61,7 @@ for key in ("cfg2", "cfg3", "cfg5", "cfg4"):
              "ndims": t["ndims"], "ms_unprofiled": t["ms"], "algorithmic_bytes": t["algorithmic_bytes"], "kernels": {}}
     tot_rd = tot_wr = 0.0
     for k, d in per.items():
-        if not (k.startswith("k_linear") or k.startswith("k_cubic") or k.startswith("k_bin")):
+        if not (k.startswith("k_linear") or k.startswith("k_cubic") or k.startswith("k_bin")):  # (k_linear_sweep included)
             continue
         rd = d.get("FETCH_SIZE", 0.0) * 1024 * fetch_corr
         wr = d.get("WRITE_SIZE", 0.0) * 1024 * write_corr
@@ -79,8 +80,8 @@ if c2:
     res.update(hbm_read_bytes_per_launch=c2["fabric_read_bytes_per_evaluation"], hbm_write_bytes_per_launch=c2["fabric_write_bytes_per_evaluation"],
                hbm_bytes_per_launch=c2["fabric_bytes_per_evaluation"], points=c2["points"], grid=c2["grid"], kernel=c2["kernel"],
                table_bytes=c2["table_bytes"])
-res["source"] = ("profiles/r04_traffic.json: FETCH_SIZE / WRITE_SIZE / TCC counters from separate rocprofv3 --pmc passes of "
-                 "tools/bench_configs.py per configuration (tools/profile_r04.sh), read side corrected by the factor measured on a stream "
+res["source"] = ("profiles/" + TAG.replace("prof_", "") + "_traffic.json: FETCH_SIZE / WRITE_SIZE / TCC counters from separate rocprofv3 --pmc passes of "
+                 "tools/bench_configs.py per configuration (tools/profile_" + TAG.replace("prof_", "") + ".sh), read side corrected by the factor measured on a stream "
                  "kernel of known byte count; fabric-side bytes of the L2, Infinity-Cache hits included")
 json.dump(res, open(OUT + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in res["configs"].items()}, indent=1))
