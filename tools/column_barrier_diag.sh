@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 V="$R/tools/_variants/diag"
 mkdir -p "$V/build" "$R/gpurun_out/column_barrier_diag"
 cd "$R/interpn_amd/csrc" || exit 1
+[ -f build/abi_create.o ] || make -j8 > /dev/null || exit 1   # the object files do not travel with gpurun (.gpurunignore)
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wno-unused-function"
 if [ ! -f "$V/libinterpn_hip.so" ] || [ cubic_column.h -nt "$V/libinterpn_hip.so" ]; then
   /opt/rocm/bin/hipcc $FLAGS -DINTERPN_COLUMN_DIAG -c k_cubic_column.hip -o "$V/build/k_cubic_column.o" || exit 1
