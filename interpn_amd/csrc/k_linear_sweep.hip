@@ -47,6 +47,10 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj) {
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
 int sweep_applies(const GridDesc& g, size_t npts) {
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
+  // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
+  const size_t lds = (size_t)SweepLds<double, kSweepRows>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows>::kWorkgroup +
+                     (g.kind == kRectilinear ? kSweepAxisLds : 0);
+  if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
   // must give every wave a few rounds (the period is a round's duration; the launch's start and end
