@@ -66,7 +66,7 @@
  *                                       from the records instead of from the upper eight bits of the index words, where the sort
  *                                       leaves them by default — slices are then 2^24 points at most),
  *                                       INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
- *       INTERPN_HIP_SWEEP=-1|0|1        3-D f64 multilinear, device-pointer evaluation: the sweep kernel (every wave orders 768
+ *       INTERPN_HIP_SWEEP=-1|0|1        3-D multilinear (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 768 / 1536
  *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
  *                                       with a clock; linear_sweep.h): auto (tables beyond the L2, batches of >= 6 rounds per
  *                                       wave ~ 1.4e7 points), never, or whenever the handle has the table (creation: 0 also
@@ -285,7 +285,7 @@ int interpn_hip_eval_device(interpn_hip_interp* h, const void* const* obs, size_
  *                not provided is then a reason to evaluate in place, reported below).
  *   *path_taken  INTERPN_HIP_PATH_IN_PLACE (one kernel on the points as given),
  *                INTERPN_HIP_PATH_BINNED (points counting-sorted first: 4 launches per slice) or
- *                INTERPN_HIP_PATH_SWEEP (3-D f64 multilinear, large batches: one persistent kernel
+ *                INTERPN_HIP_PATH_SWEEP (3-D multilinear, large batches: one persistent kernel
  *                whose waves order their points on chip and walk the table in step; 1.25 KiB of
  *                scratch per stream).
  *   *why         for IN_PLACE on a handle that could bin: the reason (INTERPN_HIP_WHY_*); else 0.

@@ -256,16 +256,17 @@ int maybe_build_bricks(interpn_hip_interp* h) {
   // The table the sweep evaluation of large device-resident batches runs on (linear_sweep.h): the
   // one just built where the layouts agree, else a second one (64^3 f64: 10.2 MiB beside 5.2).
   g.sweep_bricks = nullptr;
-  int wi = 0, wj = 0;
-  if (!(env && !strcmp(env, "off")) && sweep_layout(g, &wi, &wj)) {
+  int wi = 0, wj = 0, wcell = 0;
+  if (!(env && !strcmp(env, "off")) && sweep_layout(g, &wi, &wj, &wcell)) {
     unsigned nbs[3];
     size_t bsw = 0;
-    brick_geometry(g, wi, wj, nbs, &bsw);
-    if (g.brick_cell == 0 && g.brick_step[0] == wi && g.brick_step[1] == wj) {
+    if (wcell == 2) brick_j4_geometry(g, nbs, &bsw);
+    else brick_geometry(g, wi, wj, nbs, &bsw);
+    if (g.brick_cell == wcell && g.brick_step[0] == wi && g.brick_step[1] == wj) {
       g.sweep_bricks = g.bricks;
     } else if (bsw / esz < 0xFFFFFFFFull && bsw <= free_b / 4 && pool_alloc(h->device, &h->sweep_owned, bsw) == hipSuccess) {
       GridDesc t = g;
-      t.brick_cell = 0;
+      t.brick_cell = wcell;
       t.brick_step[0] = wi;
       t.brick_step[1] = wj;
       for (int k = 0; k < 3; ++k) t.brick_nb[k] = nbs[k];
@@ -280,6 +281,7 @@ int maybe_build_bricks(interpn_hip_interp* h) {
     if (g.sweep_bricks) {
       g.sweep_step[0] = wi;
       g.sweep_step[1] = wj;
+      g.sweep_cell = wcell;
       for (int k = 0; k < 3; ++k) g.sweep_nb[k] = nbs[k];
       g.sweep_table_bytes = bsw;
     }

@@ -134,11 +134,12 @@ struct GridDesc {
   const void* bricks11 = nullptr;
   unsigned bricks11_nb[2] = {0, 0};
   int brick_cell = 0;
-  // 3-D f64 multilinear: the table the sweep evaluation of large device-resident batches runs on
+  // 3-D multilinear: the table the sweep evaluation of large device-resident batches runs on
   // (linear_sweep.h; layout sweep_step, see k_linear_sweep.hip::sweep_layout) — `bricks` itself where
   // the layouts agree, else a second table the handle owns.  nullptr: the sweep never applies.
   const void* sweep_bricks = nullptr;
   int sweep_step[2] = {0, 0};
+  int sweep_cell = 0;  // 0: 2 x 2 x KW bricks stepped sweep_step; 2 (f32): 2 x 4 x 4 bricks
   unsigned sweep_nb[3] = {0, 0, 0};
   size_t sweep_table_bytes = 0;
   // check_bounds limits per dimension, in the element type's arithmetic
@@ -202,7 +203,7 @@ inline Thresholds thresholds(const LaunchConfig& c) {
 }
 
 // Sweep evaluation (k_linear_sweep.hip)
-bool sweep_layout(const GridDesc& g, int* si, int* sj);
+bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell);
 int sweep_applies(const GridDesc& g, size_t npts);
 size_t sweep_work_bytes();
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,

@@ -8,10 +8,14 @@ namespace interpn {
 
 namespace {
 
-constexpr int kSweepRows = 12;       // rows of 64 points per wave and round: 157 VGPRs, three waves per SIMD
+constexpr int kSweepRows = 12;       // f64: rows of 64 points per wave and round: 157 VGPRs, three waves per SIMD
+constexpr int kSweepRowsF32 = 24;    // f32: half the registers per point
 constexpr int kSweepThreads = 768;   // one workgroup per CU
+constexpr int kSweepRowsF32Rect = 20;  // ... less the registers of the cell search (24 rows spill 6-29 VGPRs there)
+template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? kSweepRows : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
 constexpr size_t kSweepPointsPerCu = (size_t)kSweepRows * kSweepThreads;
+constexpr size_t kSweepPointsPerCuF32 = (size_t)kSweepRowsF32 * kSweepThreads;
 // LDS the axis image of a rectilinear grid may take beside the waves' regions (92 KiB of a CU's 160): what
 // fill_axis_args allows the brick kernels (20 KiB) — per-bucket records of up to ~500 coordinates per axis
 constexpr size_t kSweepAxisLds = 20 * 1024;
@@ -33,8 +37,13 @@ size_t sweep_work_bytes() { return sizeof(SweepWork); }
 // re-use either way: fewest lines per point).  Measured (tools/sweep_clock_probe.py, 1e8 points,
 // f64): 64^3 (1,1) 1.07 against (1,2) 1.19 ms; 80^3 (1,2) 1.25 against (1,1) 1.35.
 // Returns false where the sweep does not apply to the handle at all.
-bool sweep_layout(const GridDesc& g, int* si, int* sj) {
-  if (g.method != kLinear || g.ndims != 3 || g.dtype != kF64 || g.cfg.sweep == 0) return false;
+bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
+  if (g.method != kLinear || g.ndims != 3 || g.cfg.sweep == 0) return false;
+  *cell = 0;
+  if (g.dtype == kF32) {  // f32: the 2 x 4 x 4 bricks (one line per cell at 3.56x the grid; linear_brick.h CELL == 2)
+    *si = 1; *sj = 1; *cell = 2;
+    return true;
+  }
   const size_t window = kSweepPointsPerCu * (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) * 85 / 100;  // ~ the share of a round spent in rows
   const size_t l11 = brick_lines(g, 1, 1), l12 = brick_lines(g, 1, 2);
   const int xcds = g.cfg.num_xcds > 0 ? g.cfg.num_xcds : 8;
@@ -49,7 +58,7 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
   const size_t lds = (size_t)SweepLds<double, kSweepRows>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows>::kWorkgroup +
-                     (g.kind == kRectilinear ? kSweepAxisLds : 0);
+                     (g.kind == kRectilinear ? kSweepAxisLds : 0);  // (the f32 shape needs no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
@@ -58,14 +67,14 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   // 64^3 at 1.4e7 points, 80^3 at 6e6, 128^3 at 1e7; six rounds per wave = 1.42e7 points is never slower.
   if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
-  if (npts < 6 * kSweepPointsPerCu * cus) return 1;
+  if (npts < 6 * (g.dtype == kF64 ? kSweepPointsPerCu : kSweepPointsPerCuF32) * cus) return 1;
   return 2;
 }
 
-template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR>
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR, int CELL = 0>
 static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
-  constexpr int K = kSweepRows, TH = kSweepThreads;
-  auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false>;
+  constexpr int K = sweep_rows<T, RECT>(), TH = kSweepThreads;
+  auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false, CELL>;
   const size_t lds = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup + ((RECT && AXR == 4 && s.b.ax.use_lds) ? (size_t)s.b.ax.image_bytes : 0);
   static std::atomic<unsigned long long> opted{0};  // bit per device
   int dev = 0;
@@ -77,26 +86,28 @@ static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, 
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);
   }
-  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0}, 0b10000011u);
+  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0, CELL}, 0b010000011u);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH), lds, stream, s);
   return hipGetLastError();
 }
 
 template <typename T, bool RECT, bool FMA, int AXR>
 static hipError_t go_layout(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
-  if (g.sweep_step[0] == 1 && g.sweep_step[1] == 1) return go<T, RECT, FMA, 1, 1, AXR>(g, s, blocks, stream);
-  if (g.sweep_step[0] == 1 && g.sweep_step[1] == 2) return go<T, RECT, FMA, 1, 2, AXR>(g, s, blocks, stream);
-  return hipErrorInvalidValue;
+  if constexpr (sizeof(T) == 4) {
+    if (g.sweep_cell == 2) return go<T, RECT, FMA, 1, 1, AXR, 2>(g, s, blocks, stream);
+    return hipErrorInvalidValue;
+  } else {
+    if (g.sweep_cell != 0) return hipErrorInvalidValue;
+    if (g.sweep_step[0] == 1 && g.sweep_step[1] == 1) return go<T, RECT, FMA, 1, 1, AXR>(g, s, blocks, stream);
+    if (g.sweep_step[0] == 1 && g.sweep_step[1] == 2) return go<T, RECT, FMA, 1, 2, AXR>(g, s, blocks, stream);
+    return hipErrorInvalidValue;
+  }
 }
 
 // `work`: a zeroed SweepWork block that no other launch in flight uses (abi_sweep.hip).
-hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                               void* work, hipStream_t stream) {
-  typedef double T;
-  if (g.dtype != kF64 || g.ndims != 3 || !g.sweep_bricks || !work || npts == 0) return hipErrorInvalidValue;
-  for (int d = 0; d < 3; ++d)
-    if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)
-  if (reinterpret_cast<uintptr_t>(out) % 16) return hipErrorInvalidValue;
+template <typename T>
+static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
+                           void* work, hipStream_t stream) {
   SweepArgs<T> s;
   BrickArgs<T, 3>& a = s.b;
   a.bricks = static_cast<const T*>(g.sweep_bricks);
@@ -130,16 +141,16 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
     s.key_start = (T)g.start[0];
     s.key_scale = (T)(1.0 / g.step[0]);
   }
-  if (!(s.key_scale > 0) || !(s.key_scale < 1e300)) { s.key_scale = 0; }  // every point in bin 0: still correct
+  if (!(s.key_scale > 0) || !(s.key_scale < (T)1e30)) { s.key_scale = 0; }  // every point in bin 0: still correct
   s.key_shift = 0;
   while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;
-  const size_t chunk = (size_t)64 * kSweepRows;
+  const size_t chunk = (size_t)64 * (g.kind == kRectilinear ? sweep_rows<T, true>() : sweep_rows<T, false>());
   const size_t rounds = (npts + chunk - 1) / chunk;
   if (rounds > 0xFFFFFFF0ull) return hipErrorInvalidValue;
   s.rounds = (unsigned)rounds;
   s.per_shard = (s.rounds + 7u) / 8u;
   s.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
-  s.period_default = 2200;  // 22 us: a round on a 64^3 grid (the first launch through a scratch block; the kernel measures from then on)
+  s.period_default = 2200;  // 22 us: a round on a 64^3 f64 grid (the first launch through a scratch block; the kernel measures from then on)
   s.work = static_cast<SweepWork*>(work);
   s.stamps = nullptr;
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
@@ -156,6 +167,16 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
   }
 #undef SWEEP_KIND
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
+                               void* work, hipStream_t stream) {
+  if (g.ndims != 3 || !g.sweep_bricks || !work || npts == 0) return hipErrorInvalidValue;
+  for (int d = 0; d < 3; ++d)
+    if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)
+  if (reinterpret_cast<uintptr_t>(out) % 16) return hipErrorInvalidValue;
+  if (g.dtype == kF64) return launch_t<double>(g, obs, out, npts, first_bad, work, stream);
+  return launch_t<float>(g, obs, out, npts, first_bad, work, stream);
 }
 
 }  // namespace interpn

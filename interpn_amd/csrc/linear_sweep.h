@@ -83,13 +83,16 @@ struct SweepLds {
 // its mode 1..3); longer axes (AXR = 4) searched with interpn_device.h::axis_cell in the axis image
 // (coordinates + bucket tables, or per-bucket records) that the workgroup stages into LDS behind
 // its waves' regions (a.ax.use_lds), or through L1/L2 where that image is too large.
-template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false>
+// CELL: the brick form (linear_brick.h) — 0: 2 x 2 x KW bricks stepped (SI, SJ); 2 (f32): 2 x 4 x 4 bricks, one line per cell.
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false, int CELL = 0>
 __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
-  static_assert(K % 2 == 0 && K >= 2 && K <= 32, "rows per wave and round");
+  constexpr int PPV = 16 / (int)sizeof(T);  // points per 16-byte stream access: 2 (f64) or 4 (f32)
+  static_assert(K % PPV == 0 && K >= PPV && K <= 32, "rows per wave and round");
+  static_assert(CELL == 0 || (CELL == 2 && sizeof(T) == 4 && SI == 1 && SJ == 1), "2 x 4 x 4 bricks: f32");
   static_assert(RECT == (AXR != 0), "rectilinear grids: lane-resident axes only");
   typedef typename LeafVec<T, 2>::type P;
-  typedef T T2 __attribute__((ext_vector_type(2)));
-  typedef BrickGeom<T, 0> Geom;
+  typedef T TV __attribute__((ext_vector_type(PPV)));
+  typedef BrickGeom<T, CELL> Geom;
   constexpr int SK = Geom::SK;
   typedef SweepLds<T, K> L;
   const BrickArgs<T, 3>& a = s.b;
@@ -167,24 +170,26 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     ticket = take(shard);  // the next round's ticket travels while this round's coordinates do
     ++my_rounds;
     const size_t base = (size_t)r * kChunk;
-    // -- coordinates: K/2 16-byte loads per dimension, lane l holds points k2*128 + 2l + {0,1}
+    // -- coordinates: K / PPV 16-byte loads per dimension, lane l holds points kv * 64 PPV + PPV l + {0 .. PPV - 1}
     T x[K][3];
     const bool full = base + kChunk <= a.npts;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int k2 = 0; k2 < K / 2; ++k2) {
-        const size_t i0 = base + (size_t)k2 * 128 + 2 * lane;
-        T2 v;
-        v.x = a.start[d];
-        v.y = a.start[d];
-        if (full || i0 + 1 < a.npts) {
-          v = stream_load(reinterpret_cast<const T2*>(a.obs[d] + i0));
-        } else if (i0 < a.npts) {
-          v.x = stream_load(a.obs[d] + i0);
+      for (int kv = 0; kv < K / PPV; ++kv) {
+        const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
+        TV v;
+#pragma unroll
+        for (int h = 0; h < PPV; ++h) v[h] = a.start[d];
+        if (full || i0 + PPV - 1 < a.npts) {
+          v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + i0));
+        } else {
+#pragma unroll
+          for (int h = 0; h < PPV; ++h)
+            if (i0 + h < a.npts) v[h] = stream_load(a.obs[d] + i0 + h);
         }
-        x[2 * k2][d] = v.x;
-        x[2 * k2 + 1][d] = v.y;
+#pragma unroll
+        for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
       }
     // -- counting sort of the wave's 64 K points by leading cell index (a hint: NaN -> bin 0)
     cnt[lane] = 0;
@@ -233,7 +238,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     }
     unsigned src[K];  // where (inside the chunk) the point in my slot k came from
 #pragma unroll
-    for (int k = 0; k < K; ++k) row16[pos[k]] = (unsigned short)((k >> 1) * 128 + 2 * lane + (k & 1));
+    for (int k = 0; k < K; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
     wave_sync();
 #pragma unroll
     for (int k = 0; k < K; ++k) src[k] = row16[k * 64 + lane];
@@ -284,7 +289,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK);
 #pragma unroll
       for (int p = 0; p < 4; ++p)
-        lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, 0>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
+        lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
       wave_sync();
       const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
       const Cell<T> c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
@@ -307,13 +312,15 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     for (int k = 0; k < K; ++k) row[src[k]] = res[k];
     wave_sync();
 #pragma unroll
-    for (int k2 = 0; k2 < K / 2; ++k2) {
-      const size_t i0 = base + (size_t)k2 * 128 + 2 * lane;
-      const T2 v = *reinterpret_cast<const T2*>(&row[k2 * 128 + 2 * lane]);
-      if (full || i0 + 1 < a.npts) {
-        stream_store(reinterpret_cast<T2*>(a.out + i0), v);
-      } else if (i0 < a.npts) {
-        stream_store(a.out + i0, v.x);
+    for (int kv = 0; kv < K / PPV; ++kv) {
+      const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
+      const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * lane]);
+      if (full || i0 + PPV - 1 < a.npts) {
+        stream_store(reinterpret_cast<TV*>(a.out + i0), v);
+      } else {
+#pragma unroll
+        for (int h = 0; h < PPV; ++h)
+          if (i0 + h < a.npts) stream_store(a.out + i0 + h, v[h]);
       }
     }
     wave_sync();

@@ -2064,10 +2064,11 @@ def test_stage_timing_of_a_sorted_evaluation(oracle, monkeypatch):
     it.close()
 
 
-def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True):
-    return synthetic_case("linear", kind, 3, axis, nobs, seed, np.float64, extrap=extrap, specials=specials)
+def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True, dtype=np.float64):
+    return synthetic_case("linear", kind, 3, axis, nobs, seed, dtype, extrap=extrap, specials=specials)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
 @pytest.mark.parametrize("kind,axis,env", [("regular", [20, 17, 33], None), ("regular", [64, 9, 12], None),
                                            ("regular", [130, 6, 7], None),  # leading cell index >> 2 for the 64 bins
@@ -2079,9 +2080,10 @@ def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True):
                                            ("rectilinear", [900, 12, 9], None), ("rectilinear", [33, 30, 31], {"axis_regs": 0})],
                          ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence", "rect_long", "rect_long_tables",
                               "rect_900", "rect_lds_forced"])
-def test_sweep_evaluation(oracle, kind, axis, env, fma):
-    """The sweep evaluation of 3-D f64 multilinear batches (linear_sweep.h: every wave sorts 768
-    points by leading cell index on chip and walks its rows in step with a clock) against the oracle
+def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
+    """The sweep evaluation of 3-D multilinear batches (linear_sweep.h: every wave sorts 768 (f64) /
+    1536 (f32; 1280 on rectilinear grids) points by leading cell index on chip and walks its rows in
+    step with a clock; f32 on its 2 x 4 x 4 bricks) against the oracle
     and, bit for bit, against the brick kernel: batches of one point, of one round less / plus one
     point, of many ragged rounds; extrapolated and special points; with the clock (measured period,
     a fixed one) and without; both cargo flavours (multilinear/regular.rs:296-404, rectilinear.rs:244-370)."""
@@ -2090,8 +2092,9 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma):
     import interpn_amd
 
     dev = torch.device("cuda:0")
-    case = _sweep_case(kind, axis, 300_007, 900 + sum(axis))
+    case = _sweep_case(kind, axis, 300_007, 900 + sum(axis), dtype=dtype)
     want = run_oracle(oracle, case, fma)
+    tname = "double" if dtype == np.float64 else "float"
     if kind == "regular":
         it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals, fma=fma)
     else:
@@ -2101,13 +2104,14 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma):
             it.set_option(k, v)
         assert it.get_option("sweep_table_bytes") > 0 and it.get_option("sweep_layout") in (11, 12)
         full = [torch.from_numpy(o).to(dev) for o in case.obs]
-        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (100_003, 0), (300_007, 1), (300_007, 0), (300_007, 0), (300_007, 700)):
+        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (1279, 0), (1280, 0), (1281, 1), (1535, 0), (1537, 0), (100_003, 0),
+                              (300_007, 1), (300_007, 0), (300_007, 0), (300_007, 700)):
             obs = [t[:count].clone() for t in full]
             it.set_option("sweep", 1)
             it.set_option("sweep_period", period)
             got = it.eval_tensors(obs)
             assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
-            assert it.kernel_name().startswith("interpn::k_linear_sweep<double, " + ("true" if kind == "rectilinear" else "false")), it.kernel_name()
+            assert it.kernel_name().startswith(f"interpn::k_linear_sweep<{tname}, " + ("true" if kind == "rectilinear" else "false")), it.kernel_name()
             it.finish()
             it.set_option("sweep", 0)
             ref = it.eval_tensors(obs)
@@ -2118,7 +2122,7 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma):
             g = got.cpu().numpy()
             same = (g == w) | (np.isnan(g) & np.isnan(w))
             assert np.all(same), (count, period, int((~same).sum()))
-        assert it.get_option("evals_sweep") == 9
+        assert it.get_option("evals_sweep") == 14
     finally:
         it.close()
 

@@ -9,13 +9,27 @@ import interpn_amd
 
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev); gen.manual_seed(3)
-for n in [int(v) for v in sys.argv[1:]] or [64, 80, 128]:
+dtype = np.float32 if "f32" in sys.argv else np.float64
+tdt = torch.float32 if dtype == np.float32 else torch.float64
+rect = "rect" in sys.argv
+SIZES = (500_000, 1_000_000, 2_000_000, 4_000_000, 6_000_000, 8_000_000, 12_000_000, 16_000_000, 32_000_000, 100_000_000)
+if "big" in sys.argv:
+    SIZES = (32_000_000, 100_000_000)
+for n in [int(v) for v in sys.argv[1:] if v.isdigit()] or [64, 80, 128]:
     g = np.linspace(-1.0, 1.0, n)
-    vals = np.random.default_rng(n).uniform(-1, 1, n ** 3)
-    it = interpn_amd.Interpolator.regular("linear", [n] * 3, np.full(3, -1.0), np.full(3, g[1] - g[0]), vals)
-    for P in (500_000, 1_000_000, 2_000_000, 4_000_000, 6_000_000, 8_000_000, 12_000_000, 16_000_000, 32_000_000, 100_000_000):
-        obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(3)]
-        out = torch.empty(P, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(n)
+    vals = rng.uniform(-1, 1, n ** 3).astype(dtype)
+    if rect:
+        grids = []
+        for _ in range(3):
+            j = (rng.random(n) - 0.5) * 0.5 * (g[1] - g[0]); j[0] = j[-1] = 0.0
+            grids.append((g + j).astype(dtype))
+        it = interpn_amd.Interpolator.rectilinear("linear", grids, vals)
+    else:
+        it = interpn_amd.Interpolator.regular("linear", [n] * 3, np.full(3, -1.0, dtype), np.full(3, g[1] - g[0], dtype), vals)
+    for P in SIZES:
+        obs = [(torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0).to(tdt) for _ in range(3)]
+        out = torch.empty(P, dtype=tdt, device=dev)
         res = {}
         for mode in (0, 1, 0, 1):
             it.set_option("sweep", mode)
@@ -27,7 +41,7 @@ for n in [int(v) for v in sys.argv[1:]] or [64, 80, 128]:
             res.setdefault(mode, []).extend(a.elapsed_time(b) for a, b in ev[4:])
         it.set_option("sweep", -1)
         it.eval_tensors(obs, out); it.finish()
-        print(json.dumps({"grid": n, "points": P, "brick_us": round(float(np.median(res[0])) * 1e3, 1), "sweep_us": round(float(np.median(res[1])) * 1e3, 1),
+        print(json.dumps({"grid": n, "dtype": np.dtype(dtype).name, "kind": "rectilinear" if rect else "regular", "points": P, "brick_us": round(float(np.median(res[0])) * 1e3, 1), "sweep_us": round(float(np.median(res[1])) * 1e3, 1),
                           "ratio": round(float(np.median(res[1]) / np.median(res[0])), 3), "automatic_path": it.last_path}), flush=True)
         del obs, out
     it.close()
