@@ -130,7 +130,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 if rng.random() < 0.4: env["INTERPN_HIP_COLUMN_KEYS"] = "0"
             # round 5: the sweep evaluation of 3-D f64 multilinear batches (device entry point), forced on batches of
             # any size, with the measured period, a fixed one, or no clock
-            if method == "linear" and N == 3 and dtype == np.float64 and rng.random() < 0.7:
+            if method == "linear" and N == 3 and rng.random() < 0.7:  # f64 and (second session) f32
                 env["INTERPN_HIP_SWEEP"] = "1"
                 env["INTERPN_HIP_SWEEP_PERIOD"] = str(int(rng.choice([0, 0, 1, 300, 2500])))
                 env.pop("INTERPN_HIP_FORCE_GENERIC", None)
