@@ -69,7 +69,7 @@
  *       INTERPN_HIP_SWEEP=-1|0|1        3-D multilinear (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 768 / 1536
  *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
  *                                       with a clock; linear_sweep.h): auto (tables beyond the L2, batches of >= 6 rounds per
- *                                       wave ~ 1.4e7 points), never, or whenever the handle has the table (creation: 0 also
+ *                                       wave ~ 1.65e7 points in f64), never, or whenever the handle has the table (creation: 0 also
  *                                       skips building it); INTERPN_HIP_SWEEP_PERIOD=n ticks of 10 ns per sweep (0 = what the
  *                                       previous launch measured, 1 = no clock)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block

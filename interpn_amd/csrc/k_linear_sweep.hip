@@ -8,13 +8,16 @@ namespace interpn {
 
 namespace {
 
-constexpr int kSweepRows = 12;       // f64: rows of 64 points per wave and round: 157 VGPRs, three waves per SIMD
+constexpr int kSweepRows = 12;       // f64: rows of 64 points per wave and round in registers: three waves per SIMD at 168 VGPRs ...
+constexpr int kSweepParked = 2;      // ... + rows parked in LDS between the sort and their turn (linear_sweep.h KL): 1.08 -> 1.055 ms at 64^3
 constexpr int kSweepRowsF32 = 24;    // f32: half the registers per point
 constexpr int kSweepThreads = 768;   // one workgroup per CU
 constexpr int kSweepRowsF32Rect = 20;  // ... less the registers of the cell search (24 rows spill 6-29 VGPRs there)
 template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? kSweepRows : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
+// (regular f64 grids only: with the registers of a cell search beside them the two rows more spill 7-20 VGPRs)
+template <typename T, bool RECT = false> constexpr int sweep_parked() { return (sizeof(T) == 8 && !RECT) ? kSweepParked : 0; }
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
-constexpr size_t kSweepPointsPerCu = (size_t)kSweepRows * kSweepThreads;
+constexpr size_t kSweepPointsPerCu = (size_t)(kSweepRows + kSweepParked) * kSweepThreads;
 constexpr size_t kSweepPointsPerCuF32 = (size_t)kSweepRowsF32 * kSweepThreads;
 // LDS the axis image of a rectilinear grid may take beside the waves' regions (92 KiB of a CU's 160): what
 // fill_axis_args allows the brick kernels (20 KiB) — per-bucket records of up to ~500 coordinates per axis
@@ -57,14 +60,14 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
 int sweep_applies(const GridDesc& g, size_t npts) {
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
-  const size_t lds = (size_t)SweepLds<double, kSweepRows>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows>::kWorkgroup +
+  const size_t lds = (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup +
                      (g.kind == kRectilinear ? kSweepAxisLds : 0);  // (the f32 shape needs no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
   // must give every wave a few rounds (the period is a round's duration; the launch's start and end
   // cost ~35 us more than the brick kernel's).  Measured crossover (profiles/r05_sweep_threshold.jsonl):
-  // 64^3 at 1.4e7 points, 80^3 at 6e6, 128^3 at 1e7; six rounds per wave = 1.42e7 points is never slower.
+  // 64^3 at 1.4e7 points, 80^3 at 6e6, 128^3 at 1e7; six rounds per wave = 1.65e7 points (regular f64) is never slower.
   if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   if (npts < 6 * (g.dtype == kF64 ? kSweepPointsPerCu : kSweepPointsPerCuF32) * cus) return 1;
@@ -73,20 +76,20 @@ int sweep_applies(const GridDesc& g, size_t npts) {
 
 template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR, int CELL = 0>
 static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
-  constexpr int K = sweep_rows<T, RECT>(), TH = kSweepThreads;
-  auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false, CELL>;
-  const size_t lds = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup + ((RECT && AXR == 4 && s.b.ax.use_lds) ? (size_t)s.b.ax.image_bytes : 0);
+  constexpr int K = sweep_rows<T, RECT>(), KL = sweep_parked<T, RECT>(), TH = kSweepThreads;
+  auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false, CELL, KL>;
+  const size_t lds = (size_t)SweepLds<T, K, KL>::kWave * (TH / 64) + SweepLds<T, K, KL>::kWorkgroup + ((RECT && AXR == 4 && s.b.ax.use_lds) ? (size_t)s.b.ax.image_bytes : 0);
   static std::atomic<unsigned long long> opted{0};  // bit per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !((opted.load() >> dev) & 1ull))) {
     // (the largest this instantiation ever asks for: its waves' regions + the axis image budget)
-    const size_t most = (size_t)SweepLds<T, K>::kWave * (TH / 64) + SweepLds<T, K>::kWorkgroup + (RECT && AXR == 4 ? kSweepAxisLds : 0);
+    const size_t most = (size_t)SweepLds<T, K, KL>::kWave * (TH / 64) + SweepLds<T, K, KL>::kWorkgroup + (RECT && AXR == 4 ? kSweepAxisLds : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);
   }
-  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0, CELL}, 0b010000011u);
+  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0, CELL, KL}, 0b0010000011u);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH), lds, stream, s);
   return hipGetLastError();
 }
@@ -144,7 +147,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
   if (!(s.key_scale > 0) || !(s.key_scale < (T)1e30)) { s.key_scale = 0; }  // every point in bin 0: still correct
   s.key_shift = 0;
   while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;
-  const size_t chunk = (size_t)64 * (g.kind == kRectilinear ? sweep_rows<T, true>() : sweep_rows<T, false>());
+  const size_t chunk = (size_t)64 * (g.kind == kRectilinear ? sweep_rows<T, true>() + sweep_parked<T, true>() : sweep_rows<T, false>() + sweep_parked<T, false>());
   const size_t rounds = (npts + chunk - 1) / chunk;
   if (rounds > 0xFFFFFFF0ull) return hipErrorInvalidValue;
   s.rounds = (unsigned)rounds;

@@ -67,14 +67,15 @@ struct SweepArgs {
 // LDS per wave: a row buffer of K * 512 bytes (sort exchange before the rows, result exchange
 // after them) that shares its bytes with the quad-transposition pieces of linear_brick.h (5 KiB,
 // used by the rows in between), + 64 counters x 2 + 1 KiB of piece offsets.
-template <typename T, int K>
+template <typename T, int K, int KL = 0>
 struct SweepLds {
-  static constexpr unsigned kRowOnly = 64u * K * sizeof(T);
+  static constexpr unsigned kRowOnly = 64u * (K + KL) * sizeof(T);
   static constexpr unsigned kPiece = 64u * kPieceRow * 2u * sizeof(T);
   static constexpr unsigned kRow = kRowOnly > kPiece ? kRowOnly : kPiece;
+  static constexpr unsigned kPark = 64u * KL * 3u * sizeof(T);   // the KL rows whose coordinates wait in LDS instead of registers
   static constexpr unsigned kCnt = 64u * 4u * 2u;
   static constexpr unsigned kOff = 64u * 16u;
-  static constexpr unsigned kWave = kRow + kCnt + kOff;
+  static constexpr unsigned kWave = kRow + kPark + kCnt + kOff;
   static constexpr unsigned kWorkgroup = 16;  // behind the waves' regions: ticks | rounds | waves done | -
 };
 
@@ -84,17 +85,21 @@ struct SweepLds {
 // (coordinates + bucket tables, or per-bucket records) that the workgroup stages into LDS behind
 // its waves' regions (a.ax.use_lds), or through L1/L2 where that image is too large.
 // CELL: the brick form (linear_brick.h) — 0: 2 x 2 x KW bricks stepped (SI, SJ); 2 (f32): 2 x 4 x 4 bricks, one line per cell.
-template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false, int CELL = 0>
+// KL: rows per wave and round BESIDE the K in registers, their coordinates parked in LDS between the sort and their
+//     turn (the kernel leaves 68 KiB of a CU's LDS unused at K = 12; the window is what bounds the table misses:
+//     table lines x 8 / points held chip-wide).
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false, int CELL = 0, int KL = 0>
 __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
   constexpr int PPV = 16 / (int)sizeof(T);  // points per 16-byte stream access: 2 (f64) or 4 (f32)
-  static_assert(K % PPV == 0 && K >= PPV && K <= 32, "rows per wave and round");
+  constexpr int KT = K + KL;                // rows per wave and round
+  static_assert(KT % PPV == 0 && K >= PPV && KT <= 32 && KL >= 0, "rows per wave and round");
   static_assert(CELL == 0 || (CELL == 2 && sizeof(T) == 4 && SI == 1 && SJ == 1), "2 x 4 x 4 bricks: f32");
   static_assert(RECT == (AXR != 0), "rectilinear grids: lane-resident axes only");
   typedef typename LeafVec<T, 2>::type P;
   typedef T TV __attribute__((ext_vector_type(PPV)));
   typedef BrickGeom<T, CELL> Geom;
   constexpr int SK = Geom::SK;
-  typedef SweepLds<T, K> L;
+  typedef SweepLds<T, K, KL> L;
   const BrickArgs<T, 3>& a = s.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const unsigned lane = threadIdx.x & 63u;
@@ -104,8 +109,9 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   typedef unsigned short __attribute__((may_alias)) lds_u16;
   lds_u16* const row16 = reinterpret_cast<lds_u16*>(mine);                   // [64 K] (the row buffer's bytes, between its uses)
   P* const lds_piece = reinterpret_cast<P*>(mine);                           // [16 quads][4][kPieceRow] (the same bytes, during the rows)
-  lds_u32* const cnt = reinterpret_cast<lds_u32*>(mine + L::kRow);           // [64] points per bin, then first position per bin at [64..128)
-  lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kCnt);
+  T* const park = reinterpret_cast<T*>(mine + L::kRow);                      // [KL][3][64] coordinates of the rows beyond the registers
+  lds_u32* const cnt = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark);  // [64] points per bin, then first position per bin at [64..128)
+  lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark + L::kCnt);
   lds_u32* const wg_words = reinterpret_cast<lds_u32*>(smem_raw + (THREADS / 64) * L::kWave);  // ticks | rounds | waves done
   if (threadIdx.x < 4) wg_words[threadIdx.x] = 0;
   if constexpr (RECT && AXR == 4) {
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   __syncthreads();  // the only workgroup barrier: before any wave has taken work
   const unsigned q = lane & 3u;
   const unsigned quad = lane >> 2;
-  constexpr size_t kChunk = (size_t)64 * K;
+  constexpr size_t kChunk = (size_t)64 * KT;
   const unsigned nwaves = gridDim.x * (THREADS / 64);
   LaneAxes<T, 3> la;
   if constexpr (RECT && AXR <= 3) la = load_lane_axes<T, 3, AXR>(a.ax);
@@ -171,12 +177,12 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     ++my_rounds;
     const size_t base = (size_t)r * kChunk;
     // -- coordinates: K / PPV 16-byte loads per dimension, lane l holds points kv * 64 PPV + PPV l + {0 .. PPV - 1}
-    T x[K][3];
+    T x[KT][3];
     const bool full = base + kChunk <= a.npts;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int kv = 0; kv < K / PPV; ++kv) {
+      for (int kv = 0; kv < KT / PPV; ++kv) {
         const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
         TV v;
 #pragma unroll
@@ -194,9 +200,9 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     // -- counting sort of the wave's 64 K points by leading cell index (a hint: NaN -> bin 0)
     cnt[lane] = 0;
     wave_sync();
-    unsigned bin[K], pos[K];
+    unsigned bin[KT], pos[KT];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KT; ++k) {
       const T u = (x[k][0] - s.key_start) * s.key_scale;
       int c = u >= (T)1 ? (u < (T)(a.n[0] - 2) ? (int)u : a.n[0] - 2) : 0;
       bin[k] = (unsigned)(c >> s.key_shift);
@@ -219,37 +225,42 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     if (period > 1) {
       const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
       const unsigned ph = now % period;
-      rot = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)ph * K) / period) * 64u);
+      rot = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)ph * KT) / period) * 64u);
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KT; ++k) {
       unsigned p = pos[k] + cnt[64 + bin[k]];
-      p = p >= rot ? p - rot : p + (unsigned)(64 * K) - rot;
+      p = p >= rot ? p - rot : p + (unsigned)(64 * KT) - rot;
       pos[k] = p;
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) row[pos[k]] = x[k][d];
+      for (int k = 0; k < KT; ++k) row[pos[k]] = x[k][d];
       wave_sync();
 #pragma unroll
       for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + lane];
+#pragma unroll
+      for (int k = K; k < KT; ++k) park[((k - K) * 3 + d) * 64 + lane] = row[k * 64 + lane];  // (a lane reads back what it parked: no exchange)
       wave_sync();
     }
-    unsigned src[K];  // where (inside the chunk) the point in my slot k came from
+    unsigned src[KT];  // where (inside the chunk) the point in my slot k came from
 #pragma unroll
-    for (int k = 0; k < K; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
+    for (int k = 0; k < KT; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < K; ++k) src[k] = row16[k * 64 + lane];
+    for (int k = 0; k < KT; ++k) src[k] = row16[k * 64 + lane];
     wave_sync();
     // -- K rows in sorted order
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
-    T res[K];
+    T res[KT];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KT; ++k) {
       // one row at a time ...
       __builtin_amdgcn_sched_barrier(0);
+      T xr[3];  // this row's point: from the registers, or from where the sort parked it
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[((k - K) * 3 + d) * 64 + lane];
       T t[3];
       int loc[3];
       if constexpr (RECT && AXR == 4) {
@@ -257,18 +268,18 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         for (int d = 0; d < 3; ++d) {
           const Axis<T> ax = make_axis<T, 3>(a.ax, axis_base, d);
           T x0, x1;
-          loc[d] = axis_cell<T>(ax, x[k][d], &x0, &x1);   // multilinear/rectilinear.rs:353-370, :310-311
-          t[d] = (x[k][d] - x0) / (x1 - x0);              // rectilinear.rs:310-313
+          loc[d] = axis_cell<T>(ax, xr[d], &x0, &x1);   // multilinear/rectilinear.rs:353-370, :310-311
+          t[d] = (xr[d] - x0) / (x1 - x0);              // rectilinear.rs:310-313
         }
       } else if constexpr (RECT) {
         T xin[1][3], x0_r[1][3], x1_r[1][3];
         int cell_r[1][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xin[0][d] = x[k][d];
+        for (int d = 0; d < 3; ++d) xin[0][d] = xr[d];
         lane_axes_locate<T, 3, 1, AXR>(a.ax, la, xin, cell_r, x0_r, x1_r);  // multilinear/rectilinear.rs:353-370
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          t[d] = (x[k][d] - x0_r[0][d]) / (x1_r[0][d] - x0_r[0][d]);        // rectilinear.rs:310-313
+          t[d] = (xr[d] - x0_r[0][d]) / (x1_r[0][d] - x0_r[0][d]);        // rectilinear.rs:310-313
           loc[d] = cell_r[0][d];
         }
       } else {
@@ -276,10 +287,10 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           T floc;
-          ok &= regular_floc<T>(x[k][d], a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
+          ok &= regular_floc<T>(xr[d], a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
           const int l = clamp_loc<T>(floc, a.n[d] - 2);                  // regular.rs:420-422
           const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);       // regular.rs:334-337
-          t[d] = (x[k][d] - izl) / a.step[d];                            // regular.rs:339
+          t[d] = (xr[d] - izl) / a.step[d];                            // regular.rs:339
           loc[d] = l;
         }
         const size_t gi = base + src[k];
@@ -309,10 +320,10 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
     // -- results back into the points' own order through LDS
 #pragma unroll
-    for (int k = 0; k < K; ++k) row[src[k]] = res[k];
+    for (int k = 0; k < KT; ++k) row[src[k]] = res[k];
     wave_sync();
 #pragma unroll
-    for (int kv = 0; kv < K / PPV; ++kv) {
+    for (int kv = 0; kv < KT / PPV; ++kv) {
       const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
       const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * lane]);
       if (full || i0 + PPV - 1 < a.npts) {

@@ -934,7 +934,7 @@ def test_device_tensors_full_size_properties(oracle):
     it.finish()
     # the headline batch takes the sweep kernel on the one-line table (linear_sweep.h); the brick kernel
     # on the handle's (1,2) table must give the same bits over the whole batch
-    assert it.last_path == "sweep" and it.kernel_name() == "interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false>", it.kernel_name()
+    assert it.last_path == "sweep" and it.kernel_name().startswith("interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false"), it.kernel_name()
     it.set_option("sweep", 0)
     brick = it.eval_tensors(obs)
     it.finish()
@@ -1014,7 +1014,7 @@ def test_cfg3_full_size_rectilinear(oracle):
                                 500_000, (31_234_567, 47_000_001))  # (_ = the full batch's results)
     # a batch of this size takes the sweep kernel (axes in lanes, lane tables: AXR = 2); the odd sub-range
     # of _full_size_checks went through the brick kernel and had to give the same bits
-    assert name == "interpn::k_linear_sweep<double, true, true, 1, 1, 12, 768, 2, false>", name
+    assert name.startswith("interpn::k_linear_sweep<double, true, true, 1, 1, 12, 768, 2, false"), name
     it.set_option("sweep", 0)
     again = it.eval_tensors([o[:20_000_000] for o in obs])
     it.finish()
@@ -1071,7 +1071,7 @@ def test_cfg5_shard_full_size(oracle):
     _, name = _full_size_checks(torch, it, obs,
                                 lambda sub, want: oracle.linear_regular(dims, starts, steps, vals, sub, want),
                                 500_000, (61_234_567, 77_000_001))
-    assert name == "interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false>", name
+    assert name.startswith("interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false"), name
     it.set_option("sweep", 0)
     again = it.eval_tensors([o[:20_000_000] for o in obs])
     it.finish()
@@ -2081,8 +2081,8 @@ def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True, dtype=np.floa
                          ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence", "rect_long", "rect_long_tables",
                               "rect_900", "rect_lds_forced"])
 def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
-    """The sweep evaluation of 3-D multilinear batches (linear_sweep.h: every wave sorts 768 (f64) /
-    1536 (f32; 1280 on rectilinear grids) points by leading cell index on chip and walks its rows in
+    """The sweep evaluation of 3-D multilinear batches (linear_sweep.h: every wave sorts 896 (f64 regular: 12 rows
+    in registers + 2 parked in LDS) / 768 (f64 rectilinear) / 1536 (f32; 1280 on rectilinear grids) points by leading cell index on chip and walks its rows in
     step with a clock; f32 on its 2 x 4 x 4 bricks) against the oracle
     and, bit for bit, against the brick kernel: batches of one point, of one round less / plus one
     point, of many ragged rounds; extrapolated and special points; with the clock (measured period,
@@ -2104,7 +2104,7 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
             it.set_option(k, v)
         assert it.get_option("sweep_table_bytes") > 0 and it.get_option("sweep_layout") in (11, 12)
         full = [torch.from_numpy(o).to(dev) for o in case.obs]
-        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (1279, 0), (1280, 0), (1281, 1), (1535, 0), (1537, 0), (100_003, 0),
+        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (895, 0), (896, 1), (897, 0), (1279, 0), (1280, 0), (1281, 1), (1535, 0), (1537, 0), (100_003, 0),
                               (300_007, 1), (300_007, 0), (300_007, 0), (300_007, 700)):
             obs = [t[:count].clone() for t in full]
             it.set_option("sweep", 1)
@@ -2122,7 +2122,7 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
             g = got.cpu().numpy()
             same = (g == w) | (np.isnan(g) & np.isnan(w))
             assert np.all(same), (count, period, int((~same).sum()))
-        assert it.get_option("evals_sweep") == 14
+        assert it.get_option("evals_sweep") == 17
     finally:
         it.close()
 
@@ -2192,7 +2192,7 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
         assert it.get_option("sweep_layout") == 11 and it.table_layout()[1:] == (1, 2)
         gen = torch.Generator(device=dev)
         gen.manual_seed(11)
-        for count, path in ((1_000_000, "in_place"), (15_000_003, "sweep")):
+        for count, path in ((1_000_000, "in_place"), (17_000_003, "sweep")):
             obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
             got = it.eval_tensors(obs)
             assert it.last_path == path, (count, it.last_path, it.last_path_reason)

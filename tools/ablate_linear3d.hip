@@ -115,6 +115,8 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
 // `threads` per workgroup, `wgs` persistent workgroups per CU (0: 1024 / threads).  Returns hipError_t; -1: shape not instantiated.
 static unsigned long long* g_sweep_stamps = nullptr;  // device buffer, 8 words per workgroup (STAMPS build of the kernel)
 void ablate_set_sweep_stamps(unsigned long long* p) { g_sweep_stamps = p; }
+static int g_sweep_parked = 0;  // rows per wave and round parked in LDS beside the K in registers (linear_sweep.h KL): 0 or 2
+void ablate_set_sweep_parked(int kl) { g_sweep_parked = kl; }
 static unsigned g_sweep_clock = 0;  // ticks of 10 ns per sweep of the leading index (0: measured by the previous launch, 1: rows in sorted order)
 void ablate_set_sweep_clock(unsigned ticks) { g_sweep_clock = ticks; }
 
@@ -141,7 +143,7 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   s.key_scale = 1.0 / h->step;
   s.key_shift = 0;
   while (((h->n - 2) >> s.key_shift) >= 64) ++s.key_shift;
-  const size_t chunk = (size_t)64 * K;
+  const size_t chunk = (size_t)64 * (K + g_sweep_parked);
   s.rounds = (unsigned)((npts + chunk - 1) / chunk);
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -152,10 +154,11 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   s.work = h->work;
   s.stamps = g_sweep_stamps;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define SWEEP(SI_, SJ_, K_, TH_)                                                                                          \
-  if (h->si == SI_ && h->sj == SJ_ && K == K_ && threads == TH_) {                                                         \
-    auto kern = g_sweep_stamps ? k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, true> : k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, false>; \
-    const size_t lds = (size_t)SweepLds<double, K_>::kWave * (TH_ / 64) + SweepLds<double, K_>::kWorkgroup;                                                   \
+#define SWEEP(SI_, SJ_, K_, TH_) SWEEP_KL(SI_, SJ_, K_, TH_, 0)
+#define SWEEP_KL(SI_, SJ_, K_, TH_, KL_)                                                                                  \
+  if (h->si == SI_ && h->sj == SJ_ && K == K_ && threads == TH_ && g_sweep_parked == KL_) {                                \
+    auto kern = g_sweep_stamps ? k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, true, 0, KL_> : k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, false, 0, KL_>; \
+    const size_t lds = (size_t)SweepLds<double, K_, KL_>::kWave * (TH_ / 64) + SweepLds<double, K_, KL_>::kWorkgroup;                                                   \
     if (lds > 64 * 1024) {                                                                                                \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                                 \
@@ -167,6 +170,10 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   }
 #define SWEEP_LAYOUTS(K_, TH_) SWEEP(1, 1, K_, TH_) SWEEP(1, 2, K_, TH_)
   SWEEP_LAYOUTS(8, 1024)
+  SWEEP_KL(1, 1, 12, 768, 2)
+  SWEEP_KL(1, 2, 12, 768, 2)
+  SWEEP_KL(1, 1, 8, 1024, 2)
+  SWEEP_KL(1, 1, 10, 768, 4)
   SWEEP_LAYOUTS(8, 768)
   SWEEP_LAYOUTS(12, 768)
   SWEEP_LAYOUTS(14, 768)
@@ -177,6 +184,7 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   SWEEP_LAYOUTS(16, 512)
 #undef SWEEP_LAYOUTS
 #undef SWEEP
+#undef SWEEP_KL
   return -1;
 }
 

@@ -13,6 +13,7 @@ lib.ablate_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctype
 lib.ablate_launch.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
 lib.ablate_launch_sweep.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 lib.ablate_set_sweep_clock.argtypes = [ctypes.c_uint]
+lib.ablate_set_sweep_parked.argtypes = [ctypes.c_int]
 lib.ablate_set_sweep_stamps.argtypes = [ctypes.c_void_p]
 lib.ablate_destroy.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
@@ -65,6 +66,8 @@ for n, si, sj in GRIDS:
     for shape in SHAPES:
         K, th = shape[0], shape[1]
         wgs = shape[2] if len(shape) > 2 else 0
+        kl = shape[3] if len(shape) > 3 else 0  # K x threads x workgroups per CU (0: default) x rows parked in LDS
+        lib.ablate_set_sweep_parked(kl)
         out = torch.full((P,), -7.0, dtype=torch.float64, device=dev)
         sweep = lambda: lib.ablate_launch_sweep(h, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), P, K, th, wgs, stream)
         stamps = torch.zeros(256 * 16 * 4 * 8, dtype=torch.int64, device=dev)
@@ -90,7 +93,7 @@ for n, si, sj in GRIDS:
                 np.save(os.path.join(ROOT, "gpurun_out", "sweep_dump", f"st_{n}_{si}{sj}_{K}x{th}_{ck}.npy"), raw)
             al = timeline(raw, K)
             lib.ablate_set_sweep_stamps(None)
-            print(json.dumps({"grid": n, "layout": [si, sj], "K": K, "threads": th, "wgs_per_cu": wgs, "clock_us": ck / 100.0, "bitwise_equal": same,
+            print(json.dumps({"grid": n, "layout": [si, sj], "K": K, "threads": th, "wgs_per_cu": wgs, "parked_rows": kl, "clock_us": ck / 100.0, "bitwise_equal": same,
                               "brick_ms_per_1e8": round(tb, 4), "sweep_ms_per_1e8": round(ms, 4), **al}), flush=True)
         del out, stamps
     lib.ablate_destroy(h)
