@@ -64,19 +64,22 @@ struct SweepArgs {
 };
 
 // K rows of 64 points per wave and round; THREADS per workgroup.
-// LDS per wave: a row buffer of K * 512 bytes (sort exchange before the rows, result exchange
-// after them) that shares its bytes with the quad-transposition pieces of linear_brick.h (5 KiB,
-// used by the rows in between), + 64 counters x 2 + 1 KiB of piece offsets.
+// LDS per wave: a row buffer of K * 512 bytes (sort exchange of the K rows that go back to registers;
+// the KL parked rows are written by the exchange straight to where they wait) that shares its bytes with
+// the quad-transposition pieces of linear_brick.h (5 KiB, used by the rows in between); behind it the
+// parked rows' coordinates; the result exchange after the rows spans both (every parked row has been
+// evaluated by then); + 1 KiB of piece offsets, whose bytes are the sort's 64 counters x 2 before the rows.
 template <typename T, int K, int KL = 0>
 struct SweepLds {
-  static constexpr unsigned kRowOnly = 64u * (K + KL) * sizeof(T);
+  static constexpr unsigned kRowOnly = 64u * K * sizeof(T);
   static constexpr unsigned kPiece = 64u * kPieceRow * 2u * sizeof(T);
   static constexpr unsigned kRow = kRowOnly > kPiece ? kRowOnly : kPiece;
-  static constexpr unsigned kPark = 64u * KL * 3u * sizeof(T);   // the KL rows whose coordinates wait in LDS instead of registers
-  static constexpr unsigned kCnt = 64u * 4u * 2u;
-  static constexpr unsigned kOff = 64u * 16u;
-  static constexpr unsigned kWave = kRow + kPark + kCnt + kOff;
+  static constexpr unsigned kPark = 64u * KL * 3u * sizeof(T);   // the KL rows whose coordinates wait in LDS instead of registers: [3][KL * 64] by sorted position
+  static constexpr unsigned kOff = 64u * 16u;                    // piece offsets of a row (during the rows) | points per bin, first position per bin (during the sort)
+  static constexpr unsigned kWave = kRow + kPark + kOff;
   static constexpr unsigned kWorkgroup = 16;  // behind the waves' regions: ticks | rounds | waves done | -
+  static_assert(kRow + kPark >= 64u * (K + KL) * sizeof(T), "the result exchange spans the row buffer and the parked rows' bytes");
+  static_assert(64u * 4u * 2u <= kOff, "the sort's counters live in the piece offsets' bytes");
 };
 
 // RECT: rectilinear grids, the cell search exactly as in the brick kernel — axes of at most 64
@@ -92,7 +95,7 @@ template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, i
 __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
   constexpr int PPV = 16 / (int)sizeof(T);  // points per 16-byte stream access: 2 (f64) or 4 (f32)
   constexpr int KT = K + KL;                // rows per wave and round
-  static_assert(KT % PPV == 0 && K >= PPV && KT <= 32 && KL >= 0, "rows per wave and round");
+  static_assert(KT % PPV == 0 && KT % 2 == 0 && K >= PPV && KT <= 32 && KL >= 0, "rows per wave and round");
   static_assert(CELL == 0 || (CELL == 2 && sizeof(T) == 4 && SI == 1 && SJ == 1), "2 x 4 x 4 bricks: f32");
   static_assert(RECT == (AXR != 0), "rectilinear grids: lane-resident axes only");
   typedef typename LeafVec<T, 2>::type P;
@@ -109,9 +112,9 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   typedef unsigned short __attribute__((may_alias)) lds_u16;
   lds_u16* const row16 = reinterpret_cast<lds_u16*>(mine);                   // [64 K] (the row buffer's bytes, between its uses)
   P* const lds_piece = reinterpret_cast<P*>(mine);                           // [16 quads][4][kPieceRow] (the same bytes, during the rows)
-  T* const park = reinterpret_cast<T*>(mine + L::kRow);                      // [KL][3][64] coordinates of the rows beyond the registers
-  lds_u32* const cnt = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark);  // [64] points per bin, then first position per bin at [64..128)
-  lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark + L::kCnt);
+  T* const park = reinterpret_cast<T*>(mine + L::kRow);                      // [3][KL * 64] coordinates of the rows beyond the registers, by sorted position
+  lds_u32* const lds_off = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark);
+  lds_u32* const cnt = lds_off;                                              // [64] points per bin, then first position per bin at [64..128): the same bytes, before the rows
   lds_u32* const wg_words = reinterpret_cast<lds_u32*>(smem_raw + (THREADS / 64) * L::kWave);  // ticks | rounds | waves done
   if (threadIdx.x < 4) wg_words[threadIdx.x] = 0;
   if constexpr (RECT && AXR == 4) {
@@ -179,34 +182,45 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     // -- coordinates: K / PPV 16-byte loads per dimension, lane l holds points kv * 64 PPV + PPV l + {0 .. PPV - 1}
     T x[KT][3];
     const bool full = base + kChunk <= a.npts;
+    if (full) {  // (all but the batch's last round: the loads back to back, nothing between them)
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int kv = 0; kv < KT / PPV; ++kv) {
-        const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
-        TV v;
+        for (int kv = 0; kv < KT / PPV; ++kv) {
+          const TV v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + base) + (kv * 64 + (int)lane));
 #pragma unroll
-        for (int h = 0; h < PPV; ++h) v[h] = a.start[d];
-        if (full || i0 + PPV - 1 < a.npts) {
-          v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + i0));
-        } else {
-#pragma unroll
-          for (int h = 0; h < PPV; ++h)
-            if (i0 + h < a.npts) v[h] = stream_load(a.obs[d] + i0 + h);
+          for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
         }
+    } else {
 #pragma unroll
-        for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
-      }
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int kv = 0; kv < KT / PPV; ++kv) {
+          const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
+          TV v;
+#pragma unroll
+          for (int h = 0; h < PPV; ++h) v[h] = a.start[d];
+          if (i0 + PPV - 1 < a.npts) {
+            v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + i0));
+          } else {
+#pragma unroll
+            for (int h = 0; h < PPV; ++h)
+              if (i0 + h < a.npts) v[h] = stream_load(a.obs[d] + i0 + h);
+          }
+#pragma unroll
+          for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
+        }
+    }
     // -- counting sort of the wave's 64 K points by leading cell index (a hint: NaN -> bin 0)
     cnt[lane] = 0;
     wave_sync();
-    unsigned bin[KT], pos[KT];
+    unsigned pos[KT];  // rank inside (wave, bin) | bin << 16, then the sorted position
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const T u = (x[k][0] - s.key_start) * s.key_scale;
       int c = u >= (T)1 ? (u < (T)(a.n[0] - 2) ? (int)u : a.n[0] - 2) : 0;
-      bin[k] = (unsigned)(c >> s.key_shift);
-      pos[k] = atomicAdd(&cnt[bin[k]], 1u);  // rank inside (wave, bin)
+      const unsigned bin = (unsigned)(c >> s.key_shift);
+      pos[k] = atomicAdd(&cnt[bin], 1u) | (bin << 16);
     }
     wave_sync();
     {
@@ -229,27 +243,32 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      unsigned p = pos[k] + cnt[64 + bin[k]];
+      unsigned p = (pos[k] & 0xFFFFu) + cnt[64 + (pos[k] >> 16)];
       p = p >= rot ? p - rot : p + (unsigned)(64 * KT) - rot;
       pos[k] = p;
     }
+    // (sorted positions K * 64 and up are the parked rows: their coordinates go straight to where they wait,
+    //  park[d][position - K * 64], which lies kParkSkip + d * KL * 64 elements behind the same index of `row`)
+    constexpr unsigned kParkSkip = L::kRow / sizeof(T) - 64u * K;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
 #pragma unroll
-      for (int k = 0; k < KT; ++k) row[pos[k]] = x[k][d];
+      for (int k = 0; k < KT; ++k) {
+        unsigned at = pos[k];
+        if constexpr (KL > 0) at += pos[k] >= 64u * K ? kParkSkip + (unsigned)d * (64u * KL) : 0u;
+        row[at] = x[k][d];
+      }
       wave_sync();
 #pragma unroll
       for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + lane];
-#pragma unroll
-      for (int k = K; k < KT; ++k) park[((k - K) * 3 + d) * 64 + lane] = row[k * 64 + lane];  // (a lane reads back what it parked: no exchange)
       wave_sync();
     }
-    unsigned src[KT];  // where (inside the chunk) the point in my slot k came from
+    unsigned src[KT / 2];  // where (inside the chunk) the points in my slots 2 k2 | 2 k2 + 1 came from (16 bits each)
 #pragma unroll
     for (int k = 0; k < KT; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < KT; ++k) src[k] = row16[k * 64 + lane];
+    for (int k2 = 0; k2 < KT / 2; ++k2) src[k2] = (unsigned)row16[(2 * k2) * 64 + lane] | ((unsigned)row16[(2 * k2 + 1) * 64 + lane] << 16);
     wave_sync();
     // -- K rows in sorted order
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
@@ -260,7 +279,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       __builtin_amdgcn_sched_barrier(0);
       T xr[3];  // this row's point: from the registers, or from where the sort parked it
 #pragma unroll
-      for (int d = 0; d < 3; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[((k - K) * 3 + d) * 64 + lane];
+      for (int d = 0; d < 3; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + lane];
       T t[3];
       int loc[3];
       if constexpr (RECT && AXR == 4) {
@@ -293,7 +312,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
           t[d] = (xr[d] - izl) / a.step[d];                            // regular.rs:339
           loc[d] = l;
         }
-        const size_t gi = base + src[k];
+        const size_t gi = base + ((src[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
         if (!ok && gi < a.npts) atomicMin(a.first_bad, (unsigned long long)gi);
       }
       const unsigned bk = (unsigned)loc[2] / (unsigned)SK;
@@ -320,7 +339,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
     // -- results back into the points' own order through LDS
 #pragma unroll
-    for (int k = 0; k < KT; ++k) row[src[k]] = res[k];
+    for (int k = 0; k < KT; ++k) row[(src[k / 2] >> (16 * (k & 1))) & 0xFFFFu] = res[k];
     wave_sync();
 #pragma unroll
     for (int kv = 0; kv < KT / PPV; ++kv) {

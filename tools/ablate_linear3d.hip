@@ -171,9 +171,10 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
 #define SWEEP_LAYOUTS(K_, TH_) SWEEP(1, 1, K_, TH_) SWEEP(1, 2, K_, TH_)
   SWEEP_LAYOUTS(8, 1024)
   SWEEP_KL(1, 1, 12, 768, 2)
+  SWEEP_KL(1, 1, 12, 768, 4)
+  SWEEP_KL(1, 1, 14, 768, 2)
   SWEEP_KL(1, 2, 12, 768, 2)
   SWEEP_KL(1, 1, 8, 1024, 2)
-  SWEEP_KL(1, 1, 10, 768, 4)
   SWEEP_LAYOUTS(8, 768)
   SWEEP_LAYOUTS(12, 768)
   SWEEP_LAYOUTS(14, 768)

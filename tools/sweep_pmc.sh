@@ -19,7 +19,7 @@ for f in sorted(glob.glob(out + "/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "k_linear" not in n: continue
-        k = ("sweep" if "sweep" in n else "brick") + (" stamps" if "true>" in n.replace(" ", "") and "sweep" in n else "")
+        k = n[n.index("k_linear"):].replace("double, ", "").replace("(interpn::SweepArgs<double>)", "")  # one line per instantiation (rows in registers, threads, ..., stamps, cell, parked rows)
         agg.setdefault(k, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: (round(sum(v[len(v)//2:]) / len(v[len(v)//2:]) / 1e6, 2), len(v)) for c, v in d.items()}, "(1e6 per launch, later half of the launches)")
