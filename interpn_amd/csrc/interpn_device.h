@@ -115,6 +115,73 @@ __device__ __forceinline__ int clamp_loc(T floc_shifted, int dimmax) {
   return li < dimmax ? li : dimmax;
 }
 
+// ---------------------------------------------------------------------------
+// Cell index and normalized coordinate on a regular grid WITHOUT the divide sequences, bit for bit
+// what regular_floc / clamp_loc / `(x - izl) / step` give (f64; round 5).
+//
+// Why: an IEEE f64 division is ~14 issue slots here (2 v_div_scale, v_rcp_f64 at quarter rate, 5 fma,
+// v_mul, v_div_fmas, v_div_fixup) and a 3-D multilinear point makes six of them — half of the vector
+// instructions of a row of the sweep kernel, which holds three waves per SIMD and therefore does not
+// hide them (tools/sweep_clock_probe.py, measurement builds: 1.03 ms per 1e8 points with the
+// divisions, 0.93 with inexact reciprocal multiplications, 0.72 without any table access).  The
+// divisor is the grid's step: the same for every point, so the host supplies rb = RN(1 / b) (one
+// correctly rounded IEEE division), and:
+//
+//  * t = RN(a / b), a = x - izl (multilinear/regular.rs:339): q0 = RN(a rb); r0 = RN(a - b q0);
+//    q1 = RN(q0 + r0 rb); r1 = a - b q1 (exact); t = RN(q1 + r1 rb).  q0 is within 2^-52 |a / b| of the
+//    quotient, so q1 is computed from a value within 2^-104 |a / b| of it and is one of the two
+//    neighbours of a / b (a faithful rounding); the remainder of a faithful quotient is exactly
+//    representable and fma delivers it; and for a faithful q, its exact remainder r and the correctly
+//    rounded reciprocal rb, RN(q + r rb) IS the correctly rounded quotient (Markstein 1990, "Computation
+//    of elementary functions on the IBM RISC System/6000 processor", theorem on the final step of
+//    fma-based division; Muller et al., Handbook of Floating-Point Arithmetic, section on
+//    Newton-Raphson division with an fma: a / b lies at least 2^-p ulp / |b'| (b' = b scaled into
+//    [1, 2)) away from every midpoint of two neighbours, the error of q + r rb against a / b is
+//    |r / b| |b rb - 1| <= (ulp / 2 + gap) b' 2^-p-1, which is below that gap for every b' < 2).
+//    Holds while nothing overflows, underflows or is not finite: the fast form is taken for
+//    2^-128 <= |b| <= 2^128 (host, per handle) and 2^-256 <= |a| < 2^256 (per point: the exponent
+//    field; a = 0 — a point on a grid plane —, infinities and NaN fail it): then 2^-385 < |a / b| <
+//    2^385 and every remainder is a multiple of 2^(-128 - 52 - 385 - 52), far above the subnormals.
+//  * the cell index floor(RN(a0 / b)), a0 = x - start (regular.rs:415-422): qt = RN(a0 rb) lies within
+//    2^-51.6 |a0 / b| of RN(a0 / b); for |qt| < 2^31 that is less than 2^-20, so if qt is further than
+//    2^-20 from every integer the two have the same floor.  Otherwise (2e-6 of random points; every
+//    point on a grid plane) the lane asks for the divisions.  |qt| < 2^31 also makes the reference's
+//    "Unrepresentable coordinate value" check (|floc| >= 2^63, NaN) pass by construction.
+// A lane for which a condition fails reports exact = false and the caller runs the divide sequences
+// for its wave (a wave-uniform branch); results are the reference's either way.
+template <typename T>
+struct StepCell {
+  T t;
+  int loc;
+  bool exact;
+};
+
+__device__ __forceinline__ bool exponent_within_256(double a) {
+  const unsigned e = ((unsigned)__double2hiint(a) >> 20) & 0x7FFu;
+  return e - (1023u - 256u) < 512u;
+}
+
+template <bool FMA>
+__device__ __forceinline__ StepCell<double> step_cell_fast(double x, double start, double step, double rstep, int dimmax) {
+  StepCell<double> r;
+  const double qt = (x - start) * rstep;
+  const double f = __builtin_floor(qt);
+  const double d = qt - f;  // exact for |qt| < 2^31 (or 1.0 for a tiny negative qt: rejected below)
+  r.exact = (__builtin_fabs(d - 0.5) < 0.5 - 0x1p-20) && (__builtin_fabs(qt) < 0x1p31);  // (NaN: false)
+  double lf = f > 0.0 ? f : 0.0;                       // clamp_loc: iloc.max(0).min(dimmax), regular.rs:420-422
+  lf = lf < (double)dimmax ? lf : (double)dimmax;
+  r.loc = (int)lf;
+  const double izl = mul_add<FMA>(step, lf, start);    // regular.rs:334-337 ((T)loc == lf: an integer in [0, dimmax])
+  const double a = x - izl;                            // regular.rs:339, the dividend
+  r.exact = r.exact && exponent_within_256(a);
+  const double q0 = a * rstep;
+  const double r0 = __builtin_fma(-step, q0, a);
+  const double q1 = __builtin_fma(r0, rstep, q0);
+  const double r1 = __builtin_fma(-step, q1, a);
+  r.t = __builtin_fma(r1, rstep, q1);
+  return r;
+}
+
 // core::slice::partition_point(|g| *g < x) restated with Rust std's probe sequence
 // (size-halving binary search); trip count depends only on n, so a wave never diverges.
 template <typename T, typename GridPtr>

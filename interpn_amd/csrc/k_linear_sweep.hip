@@ -145,6 +145,16 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
     s.key_scale = (T)(1.0 / g.step[0]);
   }
   if (!(s.key_scale > 0) || !(s.key_scale < (T)1e30)) { s.key_scale = 0; }  // every point in bin 0: still correct
+  // regular grids: the correctly rounded reciprocals of the steps, and whether every step lies where the
+  // division-free forms of interpn_device.h::step_cell_fast are the reference's values
+  s.fastdiv = g.kind == kRectilinear ? 0u : 1u;
+  for (int d = 0; d < 3; ++d) {
+    const T st = (T)g.step[d];
+    const volatile T one = (T)1;   // (one IEEE division in T, at run time)
+    s.rstep[d] = g.kind == kRectilinear ? (T)0 : one / st;
+    const double mag = st < 0 ? -(double)st : (double)st;
+    if (!(mag >= 0x1p-128 && mag <= 0x1p128)) s.fastdiv = 0;  // (NaN, 0, infinities, far-out steps: the divide sequences)
+  }
   s.key_shift = 0;
   while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;
   const size_t chunk = (size_t)64 * (g.kind == kRectilinear ? sweep_rows<T, true>() + sweep_parked<T, true>() : sweep_rows<T, false>() + sweep_parked<T, false>());

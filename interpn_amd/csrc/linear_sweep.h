@@ -55,6 +55,8 @@ struct SweepArgs {
   BrickArgs<T, 3> b;   // bricks (steps SI, SJ), obs, out, first_bad, npts, start, step, n, nbj, nbk
   T key_start, key_scale;  // the sort key: (x0 - key_start) * key_scale ~ the leading cell index (a locality hint: it need not be the exact cell; rectilinear: the uniform grid over the axis' span)
   int key_shift;       // leading cell index >> key_shift < 64 bins
+  T rstep[3];          // regular grids: RN(1 / step[d]), computed by the host in T (interpn_device.h: step_cell_fast)
+  unsigned fastdiv;    // != 0: every step is in the range where step_cell_fast is the reference's value (2^-128 <= |step| <= 2^128, finite)
   unsigned rounds;     // 64 * K points each
   unsigned per_shard;  // rounds per shard (8 shards)
   unsigned period;     // > 0: ticks per sweep, overriding the measured one; 1: rows in sorted order (no clock)
@@ -91,7 +93,9 @@ struct SweepLds {
 // KL: rows per wave and round BESIDE the K in registers, their coordinates parked in LDS between the sort and their
 //     turn (the kernel leaves 68 KiB of a CU's LDS unused at K = 12; the window is what bounds the table misses:
 //     table lines x 8 / points held chip-wide).
-template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false, int CELL = 0, int KL = 0>
+// ABL: measurement builds (tools/ablate_linear3d.hip only; 0 in the library) — 1: no table access (cell values made up
+//     from the coordinates), 2: no streams (coordinates made up from the point index, nothing stored), 3: the six IEEE divisions per point as multiplications by a reciprocal (timing only).
+template <typename T, bool RECT, bool FMA, int SI, int SJ, int K, int THREADS, int AXR = 0, bool STAMPS = false, int CELL = 0, int KL = 0, int ABL = 0>
 __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) {
   constexpr int PPV = 16 / (int)sizeof(T);  // points per 16-byte stream access: 2 (f64) or 4 (f32)
   constexpr int KT = K + KL;                // rows per wave and round
@@ -187,7 +191,13 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int kv = 0; kv < KT / PPV; ++kv) {
-          const TV v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + base) + (kv * 64 + (int)lane));
+          TV v;
+          if constexpr (ABL == 2) {
+#pragma unroll
+            for (int h = 0; h < PPV; ++h) v[h] = ablate_coord<T>(base + (size_t)(kv * 64 + (int)lane) * PPV + h, d, a.start[d], a.step[d], a.n[d]);
+          } else {
+            v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + base) + (kv * 64 + (int)lane));
+          }
 #pragma unroll
           for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
         }
@@ -303,14 +313,37 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         }
       } else {
         bool ok = true;
+        bool exact = false;
+        if constexpr (sizeof(T) == 8 && ABL != 3) {
+          // cell index and t without the six divide sequences (interpn_device.h::step_cell_fast: the same bits)
+          exact = s.fastdiv != 0;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          T floc;
-          ok &= regular_floc<T>(xr[d], a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
-          const int l = clamp_loc<T>(floc, a.n[d] - 2);                  // regular.rs:420-422
-          const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);       // regular.rs:334-337
-          t[d] = (xr[d] - izl) / a.step[d];                            // regular.rs:339
-          loc[d] = l;
+          for (int d = 0; d < 3; ++d) {
+            const StepCell<T> sc = step_cell_fast<FMA>(xr[d], a.start[d], a.step[d], s.rstep[d], a.n[d] - 2);
+            t[d] = sc.t;
+            loc[d] = sc.loc;
+            exact = exact && sc.exact;
+          }
+        }
+        if (__any(!exact)) {  // a lane on a grid plane, far outside the grid, not finite ...: the reference's operations as they stand, for the wave
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            T floc;
+            if constexpr (ABL == 3) {  // (timing only: reciprocal multiplications, results differ in the last bits)
+              const T rs = (T)1 / a.step[d];
+              floc = dev_floor<T>((xr[d] - a.start[d]) * rs);
+              const int l = clamp_loc<T>(floc, a.n[d] - 2);
+              const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);
+              t[d] = (xr[d] - izl) * rs;
+              loc[d] = l;
+              continue;
+            }
+            ok &= regular_floc<T>(xr[d], a.start[d], a.step[d], &floc);  // multilinear/regular.rs:415-418
+            const int l = clamp_loc<T>(floc, a.n[d] - 2);                  // regular.rs:420-422
+            const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);       // regular.rs:334-337
+            t[d] = (xr[d] - izl) / a.step[d];                            // regular.rs:339
+            loc[d] = l;
+          }
         }
         const size_t gi = base + ((src[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
         if (!ok && gi < a.npts) atomicMin(a.first_bad, (unsigned long long)gi);
@@ -322,7 +355,13 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
       wave_sync();
       const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
-      const Cell<T> c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
+      Cell<T> c;
+      if constexpr (ABL == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c.v[e >> 2][(e >> 1) & 1][e & 1] = t[e % 3] + (T)(toff.x & 7u) + (T)e;
+      } else {
+        c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
+      }
       T rr2[2];
 #pragma unroll
       for (int dk = 0; dk < 2; ++dk) {  // reference order (regular.rs:347-403): i first, k last
@@ -345,7 +384,9 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     for (int kv = 0; kv < KT / PPV; ++kv) {
       const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
       const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * lane]);
-      if (full || i0 + PPV - 1 < a.npts) {
+      if constexpr (ABL == 2) {
+        if (v[0] == (T)123.456) stream_store(reinterpret_cast<TV*>(a.out + i0), v);  // (never)
+      } else if (full || i0 + PPV - 1 < a.npts) {
         stream_store(reinterpret_cast<TV*>(a.out + i0), v);
       } else {
 #pragma unroll

@@ -117,6 +117,10 @@ static unsigned long long* g_sweep_stamps = nullptr;  // device buffer, 8 words 
 void ablate_set_sweep_stamps(unsigned long long* p) { g_sweep_stamps = p; }
 static int g_sweep_parked = 0;  // rows per wave and round parked in LDS beside the K in registers (linear_sweep.h KL): 0 or 2
 void ablate_set_sweep_parked(int kl) { g_sweep_parked = kl; }
+static int g_sweep_abl = 0;  // linear_sweep.h ABL: 1 no table access, 2 no streams (K = 12 x 768 + 2 parked rows only)
+void ablate_set_sweep_abl(int abl) { g_sweep_abl = abl; }
+static unsigned g_sweep_fastdiv = 1;  // 0: the divide sequences for every row (the form before step_cell_fast)
+void ablate_set_sweep_fastdiv(unsigned on) { g_sweep_fastdiv = on; }
 static unsigned g_sweep_clock = 0;  // ticks of 10 ns per sweep of the leading index (0: measured by the previous launch, 1: rows in sorted order)
 void ablate_set_sweep_clock(unsigned ticks) { g_sweep_clock = ticks; }
 
@@ -143,6 +147,8 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   s.key_scale = 1.0 / h->step;
   s.key_shift = 0;
   while (((h->n - 2) >> s.key_shift) >= 64) ++s.key_shift;
+  { const volatile double one = 1.0; for (int d = 0; d < 3; ++d) s.rstep[d] = one / h->step; }
+  s.fastdiv = g_sweep_fastdiv;
   const size_t chunk = (size_t)64 * (K + g_sweep_parked);
   s.rounds = (unsigned)((npts + chunk - 1) / chunk);
   int dev = 0, cus = 256;
@@ -155,9 +161,10 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   s.stamps = g_sweep_stamps;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define SWEEP(SI_, SJ_, K_, TH_) SWEEP_KL(SI_, SJ_, K_, TH_, 0)
-#define SWEEP_KL(SI_, SJ_, K_, TH_, KL_)                                                                                  \
-  if (h->si == SI_ && h->sj == SJ_ && K == K_ && threads == TH_ && g_sweep_parked == KL_) {                                \
-    auto kern = g_sweep_stamps ? k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, true, 0, KL_> : k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, false, 0, KL_>; \
+#define SWEEP_KL(SI_, SJ_, K_, TH_, KL_) SWEEP_ABL(SI_, SJ_, K_, TH_, KL_, 0)
+#define SWEEP_ABL(SI_, SJ_, K_, TH_, KL_, ABL_)                                                                           \
+  if (h->si == SI_ && h->sj == SJ_ && K == K_ && threads == TH_ && g_sweep_parked == KL_ && g_sweep_abl == ABL_) {         \
+    auto kern = g_sweep_stamps ? k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, true, 0, KL_, ABL_> : k_linear_sweep<double, false, true, SI_, SJ_, K_, TH_, 0, false, 0, KL_, ABL_>; \
     const size_t lds = (size_t)SweepLds<double, K_, KL_>::kWave * (TH_ / 64) + SweepLds<double, K_, KL_>::kWorkgroup;                                                   \
     if (lds > 64 * 1024) {                                                                                                \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -172,6 +179,9 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   SWEEP_LAYOUTS(8, 1024)
   SWEEP_KL(1, 1, 12, 768, 2)
   SWEEP_KL(1, 1, 12, 768, 4)
+  SWEEP_ABL(1, 1, 12, 768, 2, 1)
+  SWEEP_ABL(1, 1, 12, 768, 2, 2)
+  SWEEP_ABL(1, 1, 12, 768, 2, 3)
   SWEEP_KL(1, 1, 14, 768, 2)
   SWEEP_KL(1, 2, 12, 768, 2)
   SWEEP_KL(1, 1, 8, 1024, 2)
@@ -186,6 +196,7 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
 #undef SWEEP_LAYOUTS
 #undef SWEEP
 #undef SWEEP_KL
+#undef SWEEP_ABL
   return -1;
 }
 

@@ -14,12 +14,21 @@ lib.ablate_launch.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p]
 lib.ablate_launch_sweep.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 lib.ablate_set_sweep_clock.argtypes = [ctypes.c_uint]
 lib.ablate_set_sweep_parked.argtypes = [ctypes.c_int]
+lib.ablate_set_sweep_abl.argtypes = [ctypes.c_int]
+lib.ablate_set_sweep_fastdiv.argtypes = [ctypes.c_uint]
 lib.ablate_set_sweep_stamps.argtypes = [ctypes.c_void_p]
 lib.ablate_destroy.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 P = 100_000_256 // 512 * 512
 gen = torch.Generator(device=dev); gen.manual_seed(3)
 obs = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3)]
+if os.environ.get("SWEEP_PRESORT"):  # points ordered by x0 inside windows of 2^w points (the table then stays in the L2: what is left is everything but the misses)
+    w = 1 << int(os.environ["SWEEP_PRESORT"])
+    for lo in range(0, P, w):
+        idx = torch.argsort(obs[0][lo:lo + w])
+        for d in range(3):
+            obs[d][lo:lo + w] = obs[d][lo:lo + w][idx]
+    del idx
 stream = torch.cuda.current_stream(dev).cuda_stream
 SHAPES = [(8, 1024), (8, 512), (12, 768), (16, 768), (16, 512)]
 if os.environ.get("SWEEP_SHAPES"):
@@ -66,8 +75,12 @@ for n, si, sj in GRIDS:
     for shape in SHAPES:
         K, th = shape[0], shape[1]
         wgs = shape[2] if len(shape) > 2 else 0
-        kl = shape[3] if len(shape) > 3 else 0  # K x threads x workgroups per CU (0: default) x rows parked in LDS
+        kl = shape[3] if len(shape) > 3 else 0  # K x threads x workgroups per CU (0: default) x rows parked in LDS [x measurement build: 1 no table access, 2 no streams]
+        abl = shape[4] if len(shape) > 4 else 0
+        fastdiv = shape[5] if len(shape) > 5 else 1  # 0: the divide sequences (the kernel before step_cell_fast)
+        lib.ablate_set_sweep_fastdiv(fastdiv)
         lib.ablate_set_sweep_parked(kl)
+        lib.ablate_set_sweep_abl(abl)
         out = torch.full((P,), -7.0, dtype=torch.float64, device=dev)
         sweep = lambda: lib.ablate_launch_sweep(h, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), P, K, th, wgs, stream)
         stamps = torch.zeros(256 * 16 * 4 * 8, dtype=torch.int64, device=dev)
@@ -93,7 +106,7 @@ for n, si, sj in GRIDS:
                 np.save(os.path.join(ROOT, "gpurun_out", "sweep_dump", f"st_{n}_{si}{sj}_{K}x{th}_{ck}.npy"), raw)
             al = timeline(raw, K)
             lib.ablate_set_sweep_stamps(None)
-            print(json.dumps({"grid": n, "layout": [si, sj], "K": K, "threads": th, "wgs_per_cu": wgs, "parked_rows": kl, "clock_us": ck / 100.0, "bitwise_equal": same,
+            print(json.dumps({"grid": n, "layout": [si, sj], "K": K, "threads": th, "wgs_per_cu": wgs, "parked_rows": kl, "ablation": abl, "fastdiv": fastdiv, "clock_us": ck / 100.0, "bitwise_equal": same,
                               "brick_ms_per_1e8": round(tb, 4), "sweep_ms_per_1e8": round(ms, 4), **al}), flush=True)
         del out, stamps
     lib.ablate_destroy(h)
