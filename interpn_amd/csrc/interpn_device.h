@@ -165,12 +165,16 @@ template <bool FMA>
 __device__ __forceinline__ StepCell<double> step_cell_fast(double x, double start, double step, double rstep, int dimmax) {
   StepCell<double> r;
   const double qt = (x - start) * rstep;
-  const double f = __builtin_floor(qt);
-  const double d = qt - f;  // exact for |qt| < 2^31 (or 1.0 for a tiny negative qt: rejected below)
+  const double d = __builtin_amdgcn_fract(qt);  // qt - floor(qt): exact for |qt| < 2^31 (0.999.. for a tiny negative qt: rejected below)
   r.exact = (__builtin_fabs(d - 0.5) < 0.5 - 0x1p-20) && (__builtin_fabs(qt) < 0x1p31);  // (NaN: false)
-  double lf = f > 0.0 ? f : 0.0;                       // clamp_loc: iloc.max(0).min(dimmax), regular.rs:420-422
-  lf = lf < (double)dimmax ? lf : (double)dimmax;
-  r.loc = (int)lf;
+  // clamp_loc: iloc.max(0).min(dimmax), regular.rs:420-422.  Truncation serves as floor here: they differ for
+  // negative qt only, which the clamp takes to 0 either way.  (Where |qt| >= 2^31 or qt is NaN the conversion's
+  // value is not used: `exact` is false and the caller replaces everything derived from it.)
+  int li = (int)qt;
+  li = li > 0 ? li : 0;
+  li = li < dimmax ? li : dimmax;
+  r.loc = li;
+  const double lf = (double)li;
   const double izl = mul_add<FMA>(step, lf, start);    // regular.rs:334-337 ((T)loc == lf: an integer in [0, dimmax])
   const double a = x - izl;                            // regular.rs:339, the dividend
   r.exact = r.exact && exponent_within_256(a);

@@ -9,13 +9,13 @@ namespace interpn {
 namespace {
 
 constexpr int kSweepRows = 12;       // f64: rows of 64 points per wave and round in registers: three waves per SIMD at 168 VGPRs ...
-constexpr int kSweepParked = 2;      // ... + rows parked in LDS between the sort and their turn (linear_sweep.h KL): 1.08 -> 1.055 ms at 64^3
+constexpr int kSweepParked = 4;      // ... + rows parked in LDS between the sort and their turn (linear_sweep.h KL): 156 of a CU's 160 KiB; 64^3: 0.925 (two rows) -> 0.90 ms
+constexpr int kSweepParkedRect = 2;  // rectilinear grids, axes in lanes: the cell search's registers leave room for two (four spill 7)
 constexpr int kSweepRowsF32 = 24;    // f32: half the registers per point
 constexpr int kSweepThreads = 768;   // one workgroup per CU
 constexpr int kSweepRowsF32Rect = 20;  // ... less the registers of the cell search (24 rows spill 6-29 VGPRs there)
 template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? kSweepRows : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
-// (regular f64 grids only: with the registers of a cell search beside them the two rows more spill 7-20 VGPRs)
-template <typename T, bool RECT = false> constexpr int sweep_parked() { return (sizeof(T) == 8 && !RECT) ? kSweepParked : 0; }
+template <typename T, bool RECT = false> constexpr int sweep_parked() { return sizeof(T) == 8 ? (RECT ? kSweepParkedRect : kSweepParked) : 0; }
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
 constexpr size_t kSweepPointsPerCu = (size_t)(kSweepRows + kSweepParked) * kSweepThreads;
 constexpr size_t kSweepPointsPerCuF32 = (size_t)kSweepRowsF32 * kSweepThreads;
@@ -59,18 +59,23 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
 int sweep_applies(const GridDesc& g, size_t npts) {
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
+  if (g.sweep_table_bytes >= (1ull << 32)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
-  const size_t lds = (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup +
-                     (g.kind == kRectilinear ? kSweepAxisLds : 0);  // (the f32 shape needs no more)
+  const size_t lds = g.kind == kRectilinear
+                         ? (size_t)SweepLds<double, kSweepRows, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParkedRect>::kWorkgroup + kSweepAxisLds
+                         : (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup;  // (the f32 shapes need no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
   // must give every wave a few rounds (the period is a round's duration; the launch's start and end
-  // cost ~35 us more than the brick kernel's).  Measured crossover (profiles/r05_sweep_threshold.jsonl):
-  // 64^3 at 1.4e7 points, 80^3 at 6e6, 128^3 at 1e7; six rounds per wave = 1.65e7 points (regular f64) is never slower.
+  // cost ~35 us more than the brick kernel's).  Measured crossover (profiles/r05_sweep_threshold.jsonl, third
+  // session: the division-free kernel): f64 64^3 at 8e6 points, 80^3 at 6e6, 128^3 at 1.3e7; four rounds per
+  // wave = 1.26e7 points (regular f64) is at most 2 % slower there and 6-12 % faster at 64^3 / 80^3.  f32 (its
+  // rows still divide): six rounds.
   if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
-  if (npts < 6 * (g.dtype == kF64 ? kSweepPointsPerCu : kSweepPointsPerCuF32) * cus) return 1;
+  const size_t per_cu = g.dtype == kF64 ? (size_t)(kSweepRows + (g.kind == kRectilinear ? kSweepParkedRect : kSweepParked)) * kSweepThreads : kSweepPointsPerCuF32;
+  if (npts < (g.dtype == kF64 ? 4 : 6) * per_cu * cus) return 1;
   return 2;
 }
 

@@ -349,18 +349,44 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         if (!ok && gi < a.npts) atomicMin(a.first_bad, (unsigned long long)gi);
       }
       const unsigned bk = (unsigned)loc[2] / (unsigned)SK;
-      const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK);
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
-      wave_sync();
-      const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
       Cell<T> c;
-      if constexpr (ABL == 1) {
+      if constexpr (sizeof(T) == 8 && CELL == 0 && SI == 1 && SJ == 1 && ABL != 1) {
+        // One line per cell: the point's four pieces lie 32 bytes apart from `mine_b`, the byte offset of its
+        // brick row.  Lane q of a quad loads piece q of the quad's points 0..3: their offsets come across the
+        // quad by DPP (no LDS round trip in the row's dependent chain), and 32-bit byte offsets beside the
+        // table's base keep the address arithmetic off the vector unit (the host takes this kernel for tables
+        // under 4 GiB only).
+        const unsigned mine_b = ((((unsigned)loc[0] * a.nbj + (unsigned)loc[1]) * a.nbk + bk) * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK)) * (unsigned)sizeof(T);
+        const unsigned char* const tb = reinterpret_cast<const unsigned char*>(a.bricks);
+        const unsigned mypiece = q * (unsigned)(Geom::KW * sizeof(T));
+        P pc[4];
+        pc[0] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x00, 0xF, 0xF, true) + mypiece));
+        pc[1] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x55, 0xF, 0xF, true) + mypiece));
+        pc[2] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xAA, 0xF, 0xF, true) + mypiece));
+        pc[3] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xFF, 0xF, 0xF, true) + mypiece));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) c.v[e >> 2][(e >> 1) & 1][e & 1] = t[e % 3] + (T)(toff.x & 7u) + (T)e;
+        for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pc[r];
+        wave_sync();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const P w = lds_piece[(quad * 4 + q) * kPieceRow + p];
+          c.v[p >> 1][p & 1][0] = w.x;
+          c.v[p >> 1][p & 1][1] = w.y;
+        }
+        wave_sync();
       } else {
-        c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
+        const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          lds_off[(quad * 4 + p) * 4 + q] = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], kpart, p >> 1, p & 1);
+        wave_sync();
+        const uint4 toff = *reinterpret_cast<const uint4*>(&lds_off[(quad * 4 + q) * 4]);
+        if constexpr (ABL == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c.v[e >> 2][(e >> 1) & 1][e & 1] = t[e % 3] + (T)(toff.x & 7u) + (T)e;
+        } else {
+          c = gather_cell<T>(a.bricks, toff, 0u, lds_piece, quad, q);
+        }
       }
       T rr2[2];
 #pragma unroll

@@ -54,12 +54,12 @@ def test_column_kernel_barrier_form_and_sweep_kernel_registers(tmp_path):
     shows the source meets s_barrier's contract, so the cause is not in the source's barrier sequence; the
     s_barrier form stays behind -DINTERPN_COLUMN_SBARRIER until it has been run under a watchdog.)
     (2) The sweep kernel's product shape must not spill: 12 rows of points live in its registers
-    (linear_sweep.h; two more wait in LDS) and three waves per SIMD leave it 168."""
+    (linear_sweep.h; four more wait in LDS) and three waves per SIMD leave it 168."""
     csrc = os.path.join(ROOT, "interpn_amd", "csrc")
     one = tmp_path / "one.hip"
     one.write_text('#include "cubic_column.h"\n#include "linear_sweep.h"\nusing namespace interpn;\n'
                    "template __global__ void interpn::k_cubic_column<double, false, true, 768, 1, false>(const CubicColumnArgs<double>);\n"
-                   "template __global__ void interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false, 0, 2>(const SweepArgs<double>);\n")
+                   "template __global__ void interpn::k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false, 0, 4>(const SweepArgs<double>);\n")
     asm = tmp_path / "one.s"
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "-I", csrc,
                            "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", str(asm), str(one)], cwd=csrc)

@@ -2081,8 +2081,8 @@ def _sweep_case(kind, axis, nobs, seed, extrap=0.1, specials=True, dtype=np.floa
                          ids=["reg", "reg64", "reg130", "rect", "rect64", "rect_probe_sequence", "rect_long", "rect_long_tables",
                               "rect_900", "rect_lds_forced"])
 def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
-    """The sweep evaluation of 3-D multilinear batches (linear_sweep.h: every wave sorts 896 (f64 regular: 12 rows
-    in registers + 2 parked in LDS) / 768 (f64 rectilinear) / 1536 (f32; 1280 on rectilinear grids) points by leading cell index on chip and walks its rows in
+    """The sweep evaluation of 3-D multilinear batches (linear_sweep.h: every wave sorts 1024 (f64 regular: 12 rows
+    in registers + 4 parked in LDS) / 896 (f64 rectilinear: 12 + 2) / 1536 (f32; 1280 on rectilinear grids) points by leading cell index on chip and walks its rows in
     step with a clock; f32 on its 2 x 4 x 4 bricks) against the oracle
     and, bit for bit, against the brick kernel: batches of one point, of one round less / plus one
     point, of many ragged rounds; extrapolated and special points; with the clock (measured period,
@@ -2104,7 +2104,7 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
             it.set_option(k, v)
         assert it.get_option("sweep_table_bytes") > 0 and it.get_option("sweep_layout") in (11, 12)
         full = [torch.from_numpy(o).to(dev) for o in case.obs]
-        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (895, 0), (896, 1), (897, 0), (1279, 0), (1280, 0), (1281, 1), (1535, 0), (1537, 0), (100_003, 0),
+        for count, period in ((1, 0), (767, 0), (768, 1), (769, 1500), (895, 0), (896, 1), (897, 0), (1023, 0), (1024, 1), (1025, 0), (1279, 0), (1280, 0), (1281, 1), (1535, 0), (1537, 0), (100_003, 0),
                               (300_007, 1), (300_007, 0), (300_007, 0), (300_007, 700)):
             obs = [t[:count].clone() for t in full]
             it.set_option("sweep", 1)
@@ -2122,7 +2122,89 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
             g = got.cpu().numpy()
             same = (g == w) | (np.isnan(g) & np.isnan(w))
             assert np.all(same), (count, period, int((~same).sum()))
-        assert it.get_option("evals_sweep") == 17
+        assert it.get_option("evals_sweep") == 20
+    finally:
+        it.close()
+
+
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("steps,starts", [((2.0 / 19, 2.0 / 16, 2.0 / 32), (-1.0, -1.0, -1.0)),
+                                          ((0.1, 0.3, 1.0 / 3.0), (-0.0, 0.7, -5.0)),          # steps whose quotients round up to integers; a negative-zero start
+                                          ((1e-30, 3e30, 7.0), (1e-25, -4e31, 2.0)),           # inside [2^-128, 2^128]: the short forms
+                                          ((2.0 ** -128, 2.0 ** 128, 1.0), (0.0, 0.0, 0.0)),    # the ends of that range
+                                          ((1e-40, 1.0, 1.0), (0.0, -3.0, 4.0)),                # one step outside it: the divide sequences for every row
+                                          ((1.0, 1e60, 5e-324 * 2 ** 60), (0.0, 0.0, 0.0))],
+                         ids=["linspace", "thirds", "wide", "range_ends", "tiny_step", "huge_and_subnormalish"])
+def test_sweep_cell_index_and_t_without_divisions(oracle, steps, starts, fma):
+    """interpn_device.h::step_cell_fast (the sweep kernel's cell index and normalized coordinate on regular f64
+    grids from the step's reciprocal and fma remainders, no divide sequence) against the oracle's divisions,
+    bit for bit, on the points that sit on or next to every condition of the short forms: grid planes and
+    their floating-point neighbours (quotients that are integers or within a few ulp of one), points 2^-21 ..
+    2^-19 of a cell away from a plane (either side of the near-integer threshold), x - izl of 0, of subnormal
+    size and beyond 2^256, +-0, infinities, NaN, far extrapolation up to where the reference reports an
+    unrepresentable coordinate; steps at and beyond the ends of the range the host admits
+    (multilinear/regular.rs:334-339, :415-422)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    dims = [20, 17, 33]
+    nobs = 40_000
+    obs = []
+    for d in range(3):
+        st, s0, n = steps[d], starts[d], dims[d]
+        k = rng.integers(-2, n + 2, nobs).astype(np.float64)
+        frac = rng.random(nobs)
+        x = s0 + st * (k + frac)
+        sel = rng.integers(0, 12, nobs)
+        plane = s0 + st * k
+        x = np.where(sel == 0, plane, x)
+        x = np.where(sel == 1, np.nextafter(plane, np.inf), x)
+        x = np.where(sel == 2, np.nextafter(plane, -np.inf), x)
+        for e, code in ((-21, 3), (-20, 4), (-19, 5)):
+            x = np.where(sel == code, s0 + st * (k + rng.choice([-1.0, 1.0], nobs) * 2.0 ** e * (1 + 0.5 * frac)), x)
+        x = np.where(sel == 6, plane + st * 2.0 ** -300 * frac, x)       # x - izl far below 2^-256 steps (or absorbed: = the plane)
+        x = np.where(sel == 7, s0 + st * (k + frac) * 2.0 ** rng.integers(20, 70, nobs), x)  # far outside, up to |floc| ~ 2^75: unrepresentable beyond 2^63
+        specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e300, -1e300, 2.0 ** 31 * st + s0, -(2.0 ** 31) * st + s0,
+                             2.0 ** 63 * st + s0, 2.0 ** 62 * st + s0, -(2.0 ** 63) * st + s0, np.nextafter(-(2.0 ** 63) * st + s0, -np.inf)])
+        x = np.where(sel == 8, specials[rng.integers(0, specials.size, nobs)], x)
+        obs.append(np.ascontiguousarray(x))
+    # (an unrepresentable coordinate aborts the reference at its first such point: check the prefix the reference
+    #  writes AND, by cutting the batch there, that every later stretch evaluates bit for bit as well)
+    vals = rng.uniform(-1.0, 1.0, int(np.prod(dims)))
+    it = interpn_amd.Interpolator.regular("linear", dims, np.array(starts), np.array(steps), vals, fma=fma)
+    try:
+        it.set_option("sweep", 1)
+        lo = 0
+        stretches = 0
+        while lo < nobs and stretches < 400:
+            o = [a[lo:] for a in obs]
+            want, status = np.full(o[0].size, -7.0), None
+            try:
+                oracle.linear_regular(dims, np.array(starts), np.array(steps), vals, o, want, fma=fma)
+            except AssertionError as e:  # pyoracle.OracleError: "Unrepresentable coordinate value" at e.first_bad
+                status = e.first_bad
+                assert status is not None
+            got = it.eval_tensors([torch.from_numpy(a).to(dev) for a in o])
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            bad = None
+            try:
+                it.finish()
+            except AssertionError as e:
+                bad = getattr(e, "first_bad_index", None)
+                assert bad is not None
+            g = got.cpu().numpy()
+            upto = o[0].size if status is None else status
+            assert (bad is None) == (status is None) and (bad is None or bad == status), (lo, bad, status)
+            same = (g[:upto] == want[:upto]) | (np.isnan(g[:upto]) & np.isnan(want[:upto]))
+            assert np.all(same), (lo, int((~same).sum()), np.flatnonzero(~same)[:5], [a[np.flatnonzero(~same)[:3]] for a in o])
+            stretches += 1
+            if status is None:
+                break
+            lo += status + 1
+        assert stretches >= 1
     finally:
         it.close()
 
@@ -2192,7 +2274,7 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
         assert it.get_option("sweep_layout") == 11 and it.table_layout()[1:] == (1, 2)
         gen = torch.Generator(device=dev)
         gen.manual_seed(11)
-        for count, path in ((1_000_000, "in_place"), (17_000_003, "sweep")):
+        for count, path in ((1_000_000, "in_place"), (13_000_003, "sweep")):
             obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
             got = it.eval_tensors(obs)
             assert it.last_path == path, (count, it.last_path, it.last_path_reason)

@@ -1,0 +1,107 @@
+"""The arithmetic behind interpn_device.h::step_cell_fast, checked on the CPU with exact rationals.
+
+The sweep kernel computes t = RN(a / b) for a divisor b that is the same for every point (a regular grid's
+step) as   q0 = RN(a rb); r0 = RN(a - b q0); q1 = RN(q0 + r0 rb); r1 = a - b q1; t = RN(q1 + r1 rb)   with
+rb = RN(1 / b) from the host, instead of the hardware's divide sequence, and claims the same bits
+(Markstein's theorem on the final step of fma-based division).  Here every fma is evaluated exactly with
+fractions.Fraction and rounded once (float(Fraction) is correctly rounded), and the result is compared with
+Python's IEEE division on
+  * random operands over the exponent range the kernel admits for the short form,
+  * the hardest operands there are for a division's rounding: quotients that miss the midpoint of two
+    neighbouring doubles by the smallest possible amount (a = (b M -+ 1) / 2^54 for the odd 54-bit M with
+    b M = +-1 mod 2^54: a / b lies 2^-54 ulp from the midpoint M),
+  * quotients next to powers of two, exact quotients, and the steps of the benchmark's grids.
+No GPU, no oracle: this pins the algorithm, the GPU tests pin its implementation
+(tests/test_gpu_parity.py::test_sweep_cell_index_and_t_without_divisions)."""
+import math
+import random
+from fractions import Fraction
+
+import numpy as np
+
+
+def fma(a, b, c):
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def div_short(a, b):
+    rb = 1.0 / b
+    q0 = a * rb
+    r0 = fma(-b, q0, a)
+    q1 = fma(r0, rb, q0)
+    r1 = fma(-b, q1, a)
+    assert Fraction(r1) == Fraction(a) - Fraction(b) * Fraction(q1), "the remainder of a faithful quotient is exact"
+    return fma(r1, rb, q1)
+
+
+def same(x, y):
+    return x == y and math.copysign(1.0, x) == math.copysign(1.0, y)
+
+
+def test_random_operands():
+    rnd = random.Random(5)
+    for _ in range(60_000):
+        b = math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-128, 127)) * rnd.choice((-1.0, 1.0))
+        a = math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-256, 255)) * rnd.choice((-1.0, 1.0))
+        assert same(div_short(a, b), a / b), (a.hex(), b.hex())
+
+
+def test_quotients_next_to_midpoints():
+    """b M = +-1 (mod 2^54) for an odd 54-bit M: a = (b M -+ 1) / 2^54 is an integer and a / b misses the
+    midpoint M (in units of half an ulp of the quotient) by 1 / b — nothing is closer."""
+    rnd = random.Random(11)
+    done = 0
+    while done < 6000:
+        B = rnd.getrandbits(53) | (1 << 52) | 1
+        for sign in (1, -1):
+            M = (sign * pow(B, -1, 1 << 54)) % (1 << 54)
+            if M < (1 << 53):
+                continue
+            A = (B * M - sign) >> 54
+            assert (A << 54) + sign == B * M
+            if A >= (1 << 53) or A == 0:
+                continue
+            e = rnd.randint(-100, 100)
+            a, b = math.ldexp(float(A), e), math.ldexp(float(B), -52)
+            assert float(A) == A
+            assert same(div_short(a, b), a / b), (a.hex(), b.hex())
+            assert same(div_short(-a, b), -a / b)
+            done += 1
+
+
+def test_special_quotients_and_benchmark_steps():
+    rnd = random.Random(3)
+    steps = [2.0 / 63, 2.0 / 127, 2.0 / 31, 0.1, 1.0 / 3.0, 1.0, 0.5, 3.0, 1e-30, 3e30, math.ldexp(1.0, -128), math.ldexp(1.0, 128),
+             float(np.nextafter(2.0, 1.0)), float(np.nextafter(1.0, 2.0))]  # (the last two: significands all ones / 1 + ulp)
+    for b in steps:
+        for k in range(0, 70):
+            for a in (b * k, float(np.nextafter(b * k, np.inf)), float(np.nextafter(b * k, -np.inf)), b * (k + 0.5), b * (k + rnd.random())):
+                if a == 0.0 or not (2.0 ** -256 <= abs(a) < 2.0 ** 256):
+                    continue
+                assert same(div_short(a, b), a / b), (a.hex(), b.hex())
+        for _ in range(3000):
+            a = math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-60, 60))
+            assert same(div_short(a, b), a / b), (a.hex(), b.hex())
+            q = math.ldexp(1.0, rnd.randint(-40, 40))  # quotients at and next to powers of two
+            for qq in (q, float(np.nextafter(q, 0.0)), float(np.nextafter(q, np.inf))):
+                a2 = qq * b
+                if 2.0 ** -256 <= abs(a2) < 2.0 ** 256:
+                    assert same(div_short(a2, b), a2 / b), (a2.hex(), b.hex())
+
+
+def test_cell_index_from_the_reciprocal():
+    """floor(RN(a0 / b)) = floor(RN(a0 rb)) whenever RN(a0 rb) is further than 2^-20 from every integer and below
+    2^31 in magnitude (the condition under which the kernel keeps the short form)."""
+    rnd = random.Random(8)
+    checked = 0
+    for _ in range(200_000):
+        b = rnd.choice((2.0 / 63, 0.1, 1.0 / 3.0, 7.0, 1e-30, 3e30))
+        k = rnd.randint(-5, 2 ** rnd.randint(1, 30))
+        near = rnd.random() < 0.5
+        a0 = b * (k + (rnd.choice((-1, 1)) * 2.0 ** rnd.uniform(-24, -16) if near else rnd.random()))
+        qt = a0 * (1.0 / b)
+        d = qt - math.floor(qt)
+        if abs(d - 0.5) < 0.5 - 2.0 ** -20 and abs(qt) < 2.0 ** 31:
+            assert math.floor(qt) == math.floor(a0 / b), (a0.hex(), b.hex())
+            checked += 1
+    assert checked > 100_000
