@@ -186,6 +186,43 @@ __device__ __forceinline__ StepCell<double> step_cell_fast(double x, double star
   return r;
 }
 
+// f32: the same forms with p = 24.  Admitted: 2^-16 <= |step| <= 2^16 (host) and 2^-24 <= |x - izl| < 2^24 (per
+// point): quotients in (2^-41, 2^41), remainders multiples of 2^(-16 - 23 - 41 - 23) — normal numbers.  The
+// cell index: RN(a0 rb) lies within 2^-22.4 |a0 / b| of RN(a0 / b); the short form is kept while qt is further
+// than 2^-21 (|qt| + 1) from every integer, which also bounds |qt| below 2^20 (and rejects NaN and infinities).
+__device__ __forceinline__ bool exponent_within_24(float a) {
+  const unsigned e = (__float_as_uint(a) >> 23) & 0xFFu;
+  return e - (127u - 24u) < 48u;
+}
+
+template <bool FMA>
+__device__ __forceinline__ StepCell<float> step_cell_fast(float x, float start, float step, float rstep, int dimmax) {
+  StepCell<float> r;
+  const float qt = (x - start) * rstep;
+  const float d = __builtin_amdgcn_fractf(qt);
+  const float margin = __builtin_fmaf(__builtin_fabsf(qt), 0x1p-21f, 0x1p-21f);
+  r.exact = __builtin_fabsf(d - 0.5f) + margin < 0.5f;  // (NaN, infinities, |qt| >= 2^20: false)
+  int li = (int)qt;  // see the f64 form
+  li = li > 0 ? li : 0;
+  li = li < dimmax ? li : dimmax;
+  r.loc = li;
+  const float lf = (float)li;
+  const float izl = mul_add<FMA>(step, lf, start);
+  const float a = x - izl;
+  r.exact = r.exact && exponent_within_24(a);
+  const float q0 = a * rstep;
+  const float r0 = __builtin_fmaf(-step, q0, a);
+  const float q1 = __builtin_fmaf(r0, rstep, q0);
+  const float r1 = __builtin_fmaf(-step, q1, a);
+  r.t = __builtin_fmaf(r1, rstep, q1);
+  return r;
+}
+
+// the steps the host may hand to step_cell_fast (per element type)
+template <typename T> struct StepCellRange;
+template <> struct StepCellRange<double> { static constexpr double lo = 0x1p-128, hi = 0x1p128; };
+template <> struct StepCellRange<float> { static constexpr double lo = 0x1p-16, hi = 0x1p16; };
+
 // core::slice::partition_point(|g| *g < x) restated with Rust std's probe sequence
 // (size-halving binary search); trip count depends only on n, so a wave never diverges.
 template <typename T, typename GridPtr>

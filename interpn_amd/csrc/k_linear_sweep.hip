@@ -66,16 +66,20 @@ int sweep_applies(const GridDesc& g, size_t npts) {
                          : (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup;  // (the f32 shapes need no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
-  // automatic: a table the L2 holds anyway gains nothing (48^3: 1.04 against 1.05 ms), and a batch
-  // must give every wave a few rounds (the period is a round's duration; the launch's start and end
+  // automatic: a batch must give every wave a few rounds (the period is a round's duration; the launch's start and end
   // cost ~35 us more than the brick kernel's).  Measured crossover (profiles/r05_sweep_threshold.jsonl, third
   // session: the division-free kernel): f64 64^3 at 8e6 points, 80^3 at 6e6, 128^3 at 1.3e7; four rounds per
-  // wave = 1.26e7 points (regular f64) is at most 2 % slower there and 6-12 % faster at 64^3 / 80^3.  f32 (its
-  // rows still divide): six rounds.
-  if (g.sweep_table_bytes <= thresholds(g.cfg).table_l2_sized) return 0;
+  // wave = 1.26e7 points (regular f64) is at most 2 % slower there and 6-12 % faster at 64^3 / 80^3.  f32: six rounds.
+  // Tables the L2 holds (third session): on regular grids the division-free rows make the sweep kernel the
+  // faster one there too for large batches (1e8 points: f64 24^3 .. 48^3 0.77-0.83 against 0.91-0.96 ms, f32 64^3
+  // 0.59 against 0.68; 3.2e7 points: 7-10 % ahead; 12^3: equal) — from eight rounds per wave; rectilinear grids
+  // keep the brick kernel there (48^3: 1.04 against 1.05 ms).
+  const bool beyond_l2 = g.sweep_table_bytes > thresholds(g.cfg).table_l2_sized;
+  if (!beyond_l2 && g.kind == kRectilinear) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   const size_t per_cu = g.dtype == kF64 ? (size_t)(kSweepRows + (g.kind == kRectilinear ? kSweepParkedRect : kSweepParked)) * kSweepThreads : kSweepPointsPerCuF32;
-  if (npts < (g.dtype == kF64 ? 4 : 6) * per_cu * cus) return 1;
+  const size_t rounds = g.dtype == kF64 ? (beyond_l2 ? 4 : 8) : 6;
+  if (npts < rounds * per_cu * cus) return 1;
   return 2;
 }
 
@@ -158,7 +162,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
     const volatile T one = (T)1;   // (one IEEE division in T, at run time)
     s.rstep[d] = g.kind == kRectilinear ? (T)0 : one / st;
     const double mag = st < 0 ? -(double)st : (double)st;
-    if (!(mag >= 0x1p-128 && mag <= 0x1p128)) s.fastdiv = 0;  // (NaN, 0, infinities, far-out steps: the divide sequences)
+    if (!(mag >= StepCellRange<T>::lo && mag <= StepCellRange<T>::hi)) s.fastdiv = 0;  // (NaN, 0, infinities, far-out steps: the divide sequences)
   }
   s.key_shift = 0;
   while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       } else {
         bool ok = true;
         bool exact = false;
-        if constexpr (sizeof(T) == 8 && ABL != 3) {
+        if constexpr (ABL != 3) {
           // cell index and t without the six divide sequences (interpn_device.h::step_cell_fast: the same bits)
           exact = s.fastdiv != 0;
 #pragma unroll
@@ -350,15 +350,15 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       }
       const unsigned bk = (unsigned)loc[2] / (unsigned)SK;
       Cell<T> c;
-      if constexpr (sizeof(T) == 8 && CELL == 0 && SI == 1 && SJ == 1 && ABL != 1) {
-        // One line per cell: the point's four pieces lie 32 bytes apart from `mine_b`, the byte offset of its
-        // brick row.  Lane q of a quad loads piece q of the quad's points 0..3: their offsets come across the
-        // quad by DPP (no LDS round trip in the row's dependent chain), and 32-bit byte offsets beside the
-        // table's base keep the address arithmetic off the vector unit (the host takes this kernel for tables
-        // under 4 GiB only).
-        const unsigned mine_b = ((((unsigned)loc[0] * a.nbj + (unsigned)loc[1]) * a.nbk + bk) * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK)) * (unsigned)sizeof(T);
+      if constexpr (SI == 1 && SJ == 1 && ABL != 1) {
+        // One line per cell: the point's four pieces lie at fixed distances from `mine_b`, the byte offset of
+        // its first one (2 x 2 x KW bricks: KW elements apart; the f32 2 x 4 x 4 bricks: rows (di, oj + dj) of four).
+        // Lane q of a quad loads piece q of the quad's points 0..3: their offsets come across the quad by DPP
+        // (no LDS round trip in the row's dependent chain), and 32-bit byte offsets beside the table's base
+        // keep the address arithmetic off the vector unit (the host takes this kernel for tables under 4 GiB only).
+        const unsigned mine_b = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK), 0, 0) * (unsigned)sizeof(T);
         const unsigned char* const tb = reinterpret_cast<const unsigned char*>(a.bricks);
-        const unsigned mypiece = q * (unsigned)(Geom::KW * sizeof(T));
+        const unsigned mypiece = (CELL == 2 ? ((q >> 1) * 4u + (q & 1u)) * 4u : q * (unsigned)Geom::KW) * (unsigned)sizeof(T);
         P pc[4];
         pc[0] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x00, 0xF, 0xF, true) + mypiece));
         pc[1] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x55, 0xF, 0xF, true) + mypiece));

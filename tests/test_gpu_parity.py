@@ -1838,14 +1838,25 @@ def test_eval_device_reports_its_path_and_reserve_stops_allocation(oracle, monke
     assert np.array_equal(res.cpu().numpy(), want)
     it.finish()
     it.close()
-    # a handle that never sorts: nothing to reserve, path always in place, no reason
-    lin = synthetic_case("linear", "regular", 3, [9, 8, 7], 1000, 1, np.float64)
+    # a handle that never sorts and never sweeps (2-D): nothing to reserve, path always in place, no reason
+    lin = synthetic_case("linear", "regular", 2, [9, 8], 1000, 1, np.float64)
     it = _make_interp(interpn_amd, lin)
     it.reserve(10**8, 4)
     assert it.get_option("scratch_bytes") == 0
     it.eval_tensors([torch.from_numpy(o).to(dev) for o in lin.obs])
     it.finish()
     assert it.last_path == "in_place" and it.last_path_reason == ""
+    it.close()
+    # a 3-D multilinear handle: the sweep kernel's work words for batches that size (1.25 KiB per stream), nothing for small ones
+    lin = synthetic_case("linear", "regular", 3, [9, 8, 7], 1000, 1, np.float64)
+    it = _make_interp(interpn_amd, lin)
+    it.reserve(10**6, 4)
+    assert it.get_option("scratch_bytes") == 0
+    it.reserve(10**8, 4)
+    assert it.get_option("scratch_bytes") == 4 * 1280
+    it.eval_tensors([torch.from_numpy(o).to(dev) for o in lin.obs])
+    it.finish()
+    assert it.last_path == "in_place"
     it.close()
 
 
@@ -2136,6 +2147,20 @@ def test_sweep_evaluation(oracle, kind, axis, env, fma, dtype):
                                           ((1.0, 1e60, 5e-324 * 2 ** 60), (0.0, 0.0, 0.0))],
                          ids=["linspace", "thirds", "wide", "range_ends", "tiny_step", "huge_and_subnormalish"])
 def test_sweep_cell_index_and_t_without_divisions(oracle, steps, starts, fma):
+    _step_cell_case(oracle, steps, starts, fma, np.float64)
+
+
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("steps,starts", [((2.0 / 19, 2.0 / 16, 2.0 / 32), (-1.0, -1.0, -1.0)),
+                                          ((0.1, 0.3, 1.0 / 3.0), (-0.0, 0.7, -5.0)),
+                                          ((2.0 ** -16, 2.0 ** 16, 7.0), (0.0, 0.0, 2.0)),       # the ends of the f32 range of steps
+                                          ((1e-6, 1.0, 1e6), (0.0, -3.0, 4.0))],               # outside it: the divide sequences for every row
+                         ids=["linspace", "thirds", "range_ends", "outside"])
+def test_sweep_cell_index_and_t_without_divisions_f32(oracle, steps, starts, fma):
+    _step_cell_case(oracle, steps, starts, fma, np.float32)
+
+
+def _step_cell_case(oracle, steps, starts, fma, dtype):
     """interpn_device.h::step_cell_fast (the sweep kernel's cell index and normalized coordinate on regular f64
     grids from the step's reciprocal and fma remainders, no divide sequence) against the oracle's divisions,
     bit for bit, on the points that sit on or next to every condition of the short forms: grid planes and
@@ -2143,7 +2168,7 @@ def test_sweep_cell_index_and_t_without_divisions(oracle, steps, starts, fma):
     2^-19 of a cell away from a plane (either side of the near-integer threshold), x - izl of 0, of subnormal
     size and beyond 2^256, +-0, infinities, NaN, far extrapolation up to where the reference reports an
     unrepresentable coordinate; steps at and beyond the ends of the range the host admits
-    (multilinear/regular.rs:334-339, :415-422)."""
+    (multilinear/regular.rs:334-339, :415-422).  f32: the same with its own ranges."""
     import torch
 
     import interpn_amd
@@ -2153,37 +2178,41 @@ def test_sweep_cell_index_and_t_without_divisions(oracle, steps, starts, fma):
     dims = [20, 17, 33]
     nobs = 40_000
     obs = []
+    f32 = dtype == np.float32
+    steps = tuple(float(dtype(v)) for v in steps)
+    starts = tuple(float(dtype(v)) for v in starts)
     for d in range(3):
         st, s0, n = steps[d], starts[d], dims[d]
         k = rng.integers(-2, n + 2, nobs).astype(np.float64)
         frac = rng.random(nobs)
         x = s0 + st * (k + frac)
         sel = rng.integers(0, 12, nobs)
-        plane = s0 + st * k
+        plane = (s0 + st * k).astype(dtype).astype(np.float64)
         x = np.where(sel == 0, plane, x)
-        x = np.where(sel == 1, np.nextafter(plane, np.inf), x)
-        x = np.where(sel == 2, np.nextafter(plane, -np.inf), x)
-        for e, code in ((-21, 3), (-20, 4), (-19, 5)):
+        x = np.where(sel == 1, np.nextafter(plane.astype(dtype), dtype(np.inf)).astype(np.float64), x)
+        x = np.where(sel == 2, np.nextafter(plane.astype(dtype), dtype(-np.inf)).astype(np.float64), x)
+        for e, code in (((-13, 3), (-11, 4), (-9, 5)) if f32 else ((-21, 3), (-20, 4), (-19, 5))):
             x = np.where(sel == code, s0 + st * (k + rng.choice([-1.0, 1.0], nobs) * 2.0 ** e * (1 + 0.5 * frac)), x)
         x = np.where(sel == 6, plane + st * 2.0 ** -300 * frac, x)       # x - izl far below 2^-256 steps (or absorbed: = the plane)
         x = np.where(sel == 7, s0 + st * (k + frac) * 2.0 ** rng.integers(20, 70, nobs), x)  # far outside, up to |floc| ~ 2^75: unrepresentable beyond 2^63
         specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e300, -1e300, 2.0 ** 31 * st + s0, -(2.0 ** 31) * st + s0,
                              2.0 ** 63 * st + s0, 2.0 ** 62 * st + s0, -(2.0 ** 63) * st + s0, np.nextafter(-(2.0 ** 63) * st + s0, -np.inf)])
         x = np.where(sel == 8, specials[rng.integers(0, specials.size, nobs)], x)
-        obs.append(np.ascontiguousarray(x))
+        with np.errstate(over="ignore", invalid="ignore"):
+            obs.append(np.ascontiguousarray(x.astype(dtype)))
     # (an unrepresentable coordinate aborts the reference at its first such point: check the prefix the reference
     #  writes AND, by cutting the batch there, that every later stretch evaluates bit for bit as well)
-    vals = rng.uniform(-1.0, 1.0, int(np.prod(dims)))
-    it = interpn_amd.Interpolator.regular("linear", dims, np.array(starts), np.array(steps), vals, fma=fma)
+    vals = rng.uniform(-1.0, 1.0, int(np.prod(dims))).astype(dtype)
+    it = interpn_amd.Interpolator.regular("linear", dims, np.array(starts, dtype), np.array(steps, dtype), vals, fma=fma)
     try:
         it.set_option("sweep", 1)
         lo = 0
         stretches = 0
         while lo < nobs and stretches < 400:
             o = [a[lo:] for a in obs]
-            want, status = np.full(o[0].size, -7.0), None
+            want, status = np.full(o[0].size, -7.0, dtype), None
             try:
-                oracle.linear_regular(dims, np.array(starts), np.array(steps), vals, o, want, fma=fma)
+                oracle.linear_regular(dims, np.array(starts, dtype), np.array(steps, dtype), vals, o, want, fma=fma)
             except AssertionError as e:  # pyoracle.OracleError: "Unrepresentable coordinate value" at e.first_bad
                 status = e.first_bad
                 assert status is not None
@@ -2261,7 +2290,7 @@ def test_sweep_first_bad_index_alignment_and_streams(oracle):
         assert it.last_path == "sweep" and it.get_option("scratch_allocs") == allocs
         it.finish()
         assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
-        # automatic mode: this grid's table is L2-sized -> never; a 64^3 grid: only for batches that give every wave a few rounds
+        # automatic mode: only for batches that give every wave a few rounds (eight where the L2 holds the table, four beyond)
         it.set_option("sweep", -1)
         it.eval_tensors(obs)
         assert it.last_path == "in_place"

@@ -105,3 +105,79 @@ def test_cell_index_from_the_reciprocal():
             assert math.floor(qt) == math.floor(a0 / b), (a0.hex(), b.hex())
             checked += 1
     assert checked > 100_000
+
+
+# ---- f32: the same forms with p = 24 (rounding to f32 done exactly: float(Fraction) would round twice) ----
+def rn32(fr):
+    """Fraction -> nearest float32 (ties to even), exact; normal range only."""
+    if fr == 0:
+        return np.float32(0.0)
+    sign = -1 if fr < 0 else 1
+    fr = abs(fr)
+    e = fr.numerator.bit_length() - fr.denominator.bit_length()
+    if Fraction(2) ** e > fr:
+        e -= 1
+    assert -126 <= e <= 127
+    scaled = fr / Fraction(2) ** (e - 23)  # in [2^23, 2^24)
+    n = scaled.numerator // scaled.denominator
+    rem = scaled - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (n & 1)):
+        n += 1
+    return np.float32(sign * math.ldexp(float(n), e - 23))
+
+
+def fma32(a, b, c):
+    return rn32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def div_short32(a, b):
+    a, b = np.float32(a), np.float32(b)
+    rb = np.float32(1.0) / b
+    q0 = a * rb
+    r0 = fma32(-b, q0, a)
+    q1 = fma32(r0, rb, q0)
+    r1 = fma32(-b, q1, a)
+    assert Fraction(float(r1)) == Fraction(float(a)) - Fraction(float(b)) * Fraction(float(q1))
+    return fma32(r1, rb, q1)
+
+
+def test_f32_random_and_midpoint_operands():
+    rnd = random.Random(21)
+    for _ in range(20_000):
+        b = np.float32(math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-16, 15)) * rnd.choice((-1.0, 1.0)))
+        a = np.float32(math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-24, 23)) * rnd.choice((-1.0, 1.0)))
+        got, want = div_short32(a, b), a / b
+        assert got == want and type(want) is np.float32, (float(a).hex(), float(b).hex())
+    done = 0
+    while done < 4000:  # quotients 2^-25 ulp from a midpoint: b M = +-1 (mod 2^25), M odd with 25 bits
+        B = rnd.getrandbits(24) | (1 << 23) | 1
+        for sign in (1, -1):
+            M = (sign * pow(B, -1, 1 << 25)) % (1 << 25)
+            if M < (1 << 24):
+                continue
+            A = (B * M - sign) >> 25
+            if A >= (1 << 24) or A == 0:
+                continue
+            e = rnd.randint(-12, 12)
+            a, b = np.float32(math.ldexp(float(A), e - 23)), np.float32(math.ldexp(float(B), -23))
+            if not (2.0 ** -24 <= abs(float(a)) < 2.0 ** 24):
+                continue
+            assert div_short32(a, b) == a / b, (float(a).hex(), float(b).hex())
+            done += 1
+
+
+def test_f32_cell_index_from_the_reciprocal():
+    rnd = random.Random(9)
+    checked = 0
+    for _ in range(100_000):
+        b = np.float32(rnd.choice((2.0 / 63, 0.1, 1.0 / 3.0, 7.0, 2.0 / 159)))
+        k = rnd.randint(-5, 2 ** rnd.randint(1, 19))
+        near = rnd.random() < 0.5
+        a0 = np.float32(float(b) * (k + (rnd.choice((-1, 1)) * 2.0 ** rnd.uniform(-22, -8) if near else rnd.random())))
+        qt = a0 * (np.float32(1.0) / b)
+        d = qt - np.floor(qt)
+        margin = fma32(abs(qt), np.float32(2.0 ** -21), np.float32(2.0 ** -21))
+        if np.float32(abs(np.float32(d - np.float32(0.5))) + margin) < np.float32(0.5):
+            assert np.floor(qt) == np.floor(a0 / b), (float(a0).hex(), float(b).hex())
+            checked += 1
+    assert checked > 50_000
