@@ -585,6 +585,78 @@ def run_ablation(torch, spec, obs, out, it, seconds):
     return res
 
 
+def run_sweep_ablation(torch, spec, obs, out, kernel_name, seconds):
+    """Measurement builds of the SWEEP kernel's own source (interpn_amd/csrc/linear_sweep.h, template flag ABL;
+    tools/ablate_linear3d.hip) in the product's shape — full / no table access / no streams — and the cost of
+    the line visits alone: as many visits of random 128-byte lines as the batch has points, made the way the
+    kernel makes them (quad-cooperative, 16 lines per wave instruction), from an L2-resident table and from one of
+    this run's table size.  The last two are the floor under any kernel that reads one line per point
+    (DESIGN.md section 4.1).  Outputs of the measurement builds are meaningless by construction."""
+    import ctypes
+
+    path = os.path.join(ROOT, "tools", "libinterpn_ablate.so")
+    if not os.path.exists(path):
+        return {"error": "tools/libinterpn_ablate.so not built"}
+    if "k_linear_sweep<double, false, true, 1, 1, 12, 768, 0, false, 0, 4" not in kernel_name:
+        return {"error": f"the product kernel of this run is {kernel_name!r}: no measurement build of that shape"}
+    lib = ctypes.CDLL(path)
+    lib.ablate_create.restype = ctypes.c_void_p
+    lib.ablate_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    lib.ablate_launch_sweep.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.ablate_set_sweep_parked.argtypes = [ctypes.c_int]
+    lib.ablate_set_sweep_abl.argtypes = [ctypes.c_int]
+    lib.ablate_set_sweep_clock.argtypes = [ctypes.c_uint]
+    lib.ablate_line_visits.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ablate_destroy.argtypes = [ctypes.c_void_p]
+    dev = obs[0].device
+    vals_dev = torch.from_numpy(spec["vals"]).to(dev)
+    h = lib.ablate_create(ctypes.c_void_p(vals_dev.data_ptr()), spec["n"], 1, 1, float(spec["steps"][0]))
+    if not h:
+        return {"error": "ablate_create failed"}
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    P = obs[0].numel()
+    P16 = P // 16 * 16  # (the harness takes 16-byte aligned streams; the last few points do not matter here)
+    res = {}
+
+    def timed(fn):
+        ms, k = [], 0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end or k < 8:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn()
+            b.record()
+            if rc != 0:
+                raise RuntimeError(f"HIP error {rc}")
+            torch.cuda.synchronize()
+            if k >= 3:  # (the sweep kernel measures its period on its first launches)
+                ms.append(a.elapsed_time(b))
+            k += 1
+        return round(float(np.mean(ms)), 4)
+
+    try:
+        lib.ablate_set_sweep_parked(4)
+        lib.ablate_set_sweep_clock(0)
+        for abl, key in ((0, "full_ms"), (1, "no_table_access_ms"), (2, "no_streams_ms")):
+            lib.ablate_set_sweep_abl(abl)
+            res[key] = timed(lambda: lib.ablate_launch_sweep(h, obs[0].data_ptr(), obs[1].data_ptr(), obs[2].data_ptr(), out.data_ptr(), P16, 12, 768, 0,
+                                                             ctypes.c_void_p(stream)))
+        lib.ablate_set_sweep_abl(0)
+        table = torch.rand(16 * 2**20 // 8, dtype=torch.float64, device=dev)
+        sink = torch.zeros(8, dtype=torch.float64, device=dev)
+        for nbytes, key in ((2 * 2**20, "line_visits_L2_resident_table_ms"), (10 * 2**20, "line_visits_10MiB_table_ms")):
+            res[key] = timed(lambda: lib.ablate_line_visits(ctypes.c_void_p(table.data_ptr()), nbytes, P16, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(stream)))
+    except RuntimeError as e:
+        return {"error": str(e)}
+    finally:
+        lib.ablate_destroy(h)
+    res["note"] = ("measurement builds of the product kernel's source in its shape (12 rows in registers + 4 parked, 768 threads): no_table_access = "
+                   "streams, sort and arithmetic on made-up cell values; no_streams = sort, gathers and arithmetic on made-up coordinates, nothing stored; "
+                   "line_visits = as many quad-cooperative reads of random 128-byte lines as the batch has points and nothing else (tools/tune_sector.hip) — "
+                   "the floor of one line per point; the sweep keeps its 10 MiB table L2-resident in time")
+    return res
+
+
 def sharding_text(world, bcast):
     """The record's description of the multi-GPU data path, generated from what this run did."""
     head = ("obs sharded contiguously, one shard per rank" if world > 1 else
@@ -884,6 +956,7 @@ def worker(args):
             if not args.no_ablate:
                 try:
                     rec["roofline"]["ablation"] = run_ablation(torch, spec, obs, out, it, 0.25)
+                    rec["roofline"]["sweep_ablation"] = run_sweep_ablation(torch, spec, obs, out, rec["roofline"].get("kernel", ""), 0.2)
                     so = rec["roofline"]["ablation"].get("stream_only_ms")
                     if so:
                         # the part's achievable rate for this 3-read / 1-write stream pattern (no table access)

@@ -179,6 +179,8 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
   SWEEP_LAYOUTS(8, 1024)
   SWEEP_KL(1, 1, 12, 768, 2)
   SWEEP_KL(1, 1, 12, 768, 4)
+  SWEEP_ABL(1, 1, 12, 768, 4, 1)
+  SWEEP_ABL(1, 1, 12, 768, 4, 2)
   SWEEP_ABL(1, 1, 12, 768, 2, 1)
   SWEEP_ABL(1, 1, 12, 768, 2, 2)
   SWEEP_ABL(1, 1, 12, 768, 2, 3)
@@ -198,6 +200,35 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
 #undef SWEEP_KL
 #undef SWEEP_ABL
   return -1;
+}
+
+// Nothing but visits of random 128-byte lines, the way the product kernels make them (the four lanes of a quad read
+// 4 x 16 bytes spread over one line, 16 lines per wave instruction; tools/tune_sector.hip, mode B): what `visits` of them
+// cost from a table of `table_bytes` — the floor under any kernel that reads one line per point.  `table` >= table_bytes.
+namespace {
+__device__ __forceinline__ unsigned long long visit_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_line_visits(const double2* __restrict__ tab, size_t nlines, double* sink, size_t nquads, int reps) {
+  const size_t nthreads = (size_t)gridDim.x * 256;
+  double acc = 0;
+  for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < nquads * 4; s += nthreads) {
+    const size_t quad = s >> 2;
+    const unsigned q = (unsigned)(s & 3);
+    for (int r = 0; r < reps; ++r) {
+      const size_t line = visit_mix(quad * 16 + (unsigned)r) % nlines;
+      const double2 v = tab[line * 8 + 2 * q];
+      acc += v.x + v.y;
+    }
+  }
+  if (acc == 1.2345) sink[0] = acc;  // (never: the table holds finite table values)
+}
+}  // namespace
+int ablate_line_visits(const void* table, size_t table_bytes, size_t visits, double* sink, void* stream) {
+  if (!table || !sink || table_bytes < 128 || visits < 4) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_line_visits, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const double2*>(table), table_bytes / 128,
+                     sink, visits / 4, 4);
+  return (int)hipGetLastError();
 }
 
 void ablate_destroy(void* handle) {
