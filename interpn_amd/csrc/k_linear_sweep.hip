@@ -98,7 +98,7 @@ static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, 
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);
   }
-  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0, CELL, KL}, 0b0010000011u);
+  g.tag.set("k_linear_sweep", {RECT, FMA, SI, SJ, K, TH, AXR, 0, CELL, KL, 0}, 0b00010000011u);  // (the last: ABL, measurement builds only)
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH), lds, stream, s);
   return hipGetLastError();
 }
