@@ -88,7 +88,9 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   // 3-D grids whose dims 0, 1 give at most 4096 class pairs keep it as well when the sorted evaluation is asked for at
   // creation (INTERPN_HIP_BINNED=1; cubic3_column.h: not taken by itself, profiles/REJECTED.md round 5; 64^3 f64: 33.5 MiB)
   const bool column3 = g.ndims == 3 && (long long)(g.n[0] - 1) * (g.n[1] - 1) <= kMaxBins && g.cfg.column != 0 && g.cfg.binned == 1;
-  if (!forced && (g.ndims == 4 || column3) && best != 4 && fits11) {
+  // 3-D grids keep it for the sweep evaluation of large batches too (cubic_sweep.h; option sweep = 0 at creation: not built)
+  const bool sweep3 = g.ndims == 3 && g.cfg.sweep != 0;
+  if (!forced && (g.ndims == 4 || column3 || sweep3) && best != 4 && fits11) {
     if (pool_alloc(h->device, &h->bricks11_owned, bytes11) == hipSuccess) {
       GridDesc t = g;
       t.brick_step[0] = t.brick_step[1] = 1;

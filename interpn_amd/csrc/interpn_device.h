@@ -218,6 +218,38 @@ __device__ __forceinline__ StepCell<float> step_cell_fast(float x, float start, 
   return r;
 }
 
+// The two short forms on their own (cubic_sweep.h: the saturation class of a point needs floor(RN(a0 / b)) itself,
+// not only the clamped cell index).  Same conditions, same proofs as in step_cell_fast; the return value says
+// whether the result is the reference's (false: the caller must use the divide sequence).
+__device__ __forceinline__ bool floor_quotient_fast(double a0, double rb, double* floc) {
+  const double qt = a0 * rb;
+  const double d = __builtin_amdgcn_fract(qt);
+  *floc = __builtin_floor(qt);
+  return (__builtin_fabs(d - 0.5) < 0.5 - 0x1p-20) && (__builtin_fabs(qt) < 0x1p31);
+}
+__device__ __forceinline__ bool floor_quotient_fast(float a0, float rb, float* floc) {
+  const float qt = a0 * rb;
+  const float d = __builtin_amdgcn_fractf(qt);
+  *floc = __builtin_floorf(qt);
+  return __builtin_fabsf(d - 0.5f) + __builtin_fmaf(__builtin_fabsf(qt), 0x1p-21f, 0x1p-21f) < 0.5f;
+}
+__device__ __forceinline__ bool divide_fast(double a, double b, double rb, double* q) {
+  const double q0 = a * rb;
+  const double r0 = __builtin_fma(-b, q0, a);
+  const double q1 = __builtin_fma(r0, rb, q0);
+  const double r1 = __builtin_fma(-b, q1, a);
+  *q = __builtin_fma(r1, rb, q1);
+  return exponent_within_256(a);
+}
+__device__ __forceinline__ bool divide_fast(float a, float b, float rb, float* q) {
+  const float q0 = a * rb;
+  const float r0 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(r0, rb, q0);
+  const float r1 = __builtin_fmaf(-b, q1, a);
+  *q = __builtin_fmaf(r1, rb, q1);
+  return exponent_within_24(a);
+}
+
 // the steps the host may hand to step_cell_fast (per element type)
 template <typename T> struct StepCellRange;
 template <> struct StepCellRange<double> { static constexpr double lo = 0x1p-128, hi = 0x1p128; };

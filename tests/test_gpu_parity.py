@@ -2238,6 +2238,73 @@ def _step_cell_case(oracle, steps, starts, fma, dtype):
         it.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["cubic_extrap", "linearized"])
+@pytest.mark.parametrize("kind,axis", [("regular", [20, 17, 33]), ("regular", [9, 8, 150]),  # dim-2 cell index >> 2 for the 64 bins
+                                       ("regular", [64, 9, 12]), ("rectilinear", [24, 11, 40]), ("rectilinear", [8, 70, 90])],
+                         ids=["reg", "reg_long_dim2", "reg_flat", "rect", "rect_long"])
+def test_cubic_sweep_evaluation(oracle, kind, axis, linearize, fma, dtype):
+    """The sweep evaluation of 3-D multicubic batches (cubic_sweep.h: every wave sorts 640 (f64; 512 on rectilinear grids) /
+    1280 (f32) points by their dim-2 cell on chip and walks its rows in step with a clock, rows = cubic_brick.h's on the fully
+    overlapped tile table, regular grids without divide sequences) against the oracle and, bit for bit, against the tiled
+    kernel in place: batches of one point, of a round less / plus one point, of many ragged rounds; extrapolated (both
+    `linearize_extrapolation` values) and special points; with the clock and without; both cargo flavours
+    (multicubic/regular.rs:297-623, rectilinear.rs:237-545)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = synthetic_case("cubic", kind, 3, axis, 200_003, 1200 + sum(axis), dtype, linearize=linearize, extrap=0.25, specials=True)
+    want = run_oracle(oracle, case, fma)
+    tname = "double" if dtype == np.float64 else "float"
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular("cubic", case.dims, case.starts, case.steps, case.vals, linearize_extrapolation=linearize, fma=fma)
+    else:
+        it = interpn_amd.Interpolator.rectilinear("cubic", case.grids, case.vals, linearize_extrapolation=linearize, fma=fma)
+    try:
+        full = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for count, period in ((1, 0), (511, 0), (512, 1), (513, 0), (639, 0), (640, 1), (641, 1500), (1279, 0), (1280, 0), (1281, 1), (100_003, 0),
+                              (200_003, 1), (200_003, 0), (200_003, 0), (200_003, 2500)):
+            obs = [t[:count].clone() for t in full]
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert it.kernel_name().startswith(f"interpn::k_cubic_sweep<{tname}, " + ("true" if kind == "rectilinear" else "false")), it.kernel_name()
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place" and it.kernel_name().startswith("interpn::k_cubic_"), it.kernel_name()
+            it.finish()
+            g, r = got.cpu().numpy(), ref.cpu().numpy()
+            assert np.all((g == r) | (np.isnan(g) & np.isnan(r))), (count, period)
+            w = want[:count]
+            same = (g == w) | (np.isnan(g) & np.isnan(w))
+            assert np.all(same), (count, period, int((~same).sum()))
+        # an unrepresentable coordinate: the first failing index, the prefix in front of it (regular grids; rectilinear ones never fail)
+        if kind == "regular":
+            bad = [t.clone() for t in full]
+            bad[2][150_000] = float("nan")
+            bad[0][60_001] = float("inf")
+            bad[1][60_002] = float("nan")
+            it.set_option("sweep", 1)
+            out = it.eval_tensors(bad)
+            assert it.last_path == "sweep"
+            with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                it.finish()
+            assert ei.value.first_bad_index == 60_001
+            assert np.array_equal(out.cpu().numpy()[:60_001], want[:60_001])
+        # automatic mode: small batches stay in place
+        it.set_option("sweep", -1)
+        it.eval_tensors(full)
+        assert it.last_path == "in_place"
+        it.finish()
+    finally:
+        it.close()
+
+
 def test_sweep_first_bad_index_alignment_and_streams(oracle):
     """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
     multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and
@@ -2403,8 +2470,8 @@ def test_column_evaluation_of_sorted_3d_multicubic(oracle, monkeypatch, dtype, a
 
 def test_column_evaluation_3d_only_on_request(oracle, monkeypatch):
     """The 3-D column path is never taken by itself (64^3 f64 at 1e7 points: sort 0.35 ms + kernel 0.55 against
-    0.65 in place, profiles/REJECTED.md round 5); a handle created with INTERPN_HIP_BINNED=1 keeps the fully
-    overlapped tile table beside its in-place layout and takes it: the oracle's bits either way."""
+    0.65 in place, profiles/REJECTED.md round 5; what large batches take by themselves is the sweep kernel,
+    cubic_sweep.h: 0.46 ms); a handle created with INTERPN_HIP_BINNED=1 takes it: the oracle's bits either way."""
     import torch
 
     import interpn_amd
@@ -2422,7 +2489,7 @@ def test_column_evaluation_3d_only_on_request(oracle, monkeypatch):
     sub = [o[idx].cpu().numpy() for o in obs]
     w = np.zeros(idx.numel())
     oracle.cubic_regular(dims, starts, steps, vals, True, sub, w)
-    for env, path in ((None, "in_place"), ("1", "binned")):
+    for env, path in ((None, "sweep"), ("1", "binned")):
         if env:
             monkeypatch.setenv("INTERPN_HIP_BINNED", env)
         it = interpn_amd.Interpolator.regular("cubic", dims, starts, steps, vals, linearize_extrapolation=True)
