@@ -89,7 +89,11 @@ int maybe_build_cubic_tiles(interpn_hip_interp* h) {
   // creation (INTERPN_HIP_BINNED=1; cubic3_column.h: not taken by itself, profiles/REJECTED.md round 5; 64^3 f64: 33.5 MiB)
   const bool column3 = g.ndims == 3 && (long long)(g.n[0] - 1) * (g.n[1] - 1) <= kMaxBins && g.cfg.column != 0 && g.cfg.binned == 1;
   // 3-D grids keep it for the sweep evaluation of large batches too (cubic_sweep.h; option sweep = 0 at creation: not built)
-  const bool sweep3 = g.ndims == 3 && g.cfg.sweep != 0;
+  // — where the automatic rule can take it (k_cubic_sweep.hip::cubic_sweep_applies: regular grids, the table between the L2's size
+  // and 128 MiB, f32 32 MiB), or anywhere when the sweep is forced at creation (INTERPN_HIP_SWEEP=1)
+  const bool sweep3 = g.ndims == 3 && (g.cfg.sweep > 0 ||
+                                       (g.cfg.sweep < 0 && g.kind == kRegular && bytes11 > thresholds(g.cfg).table_l2_sized &&
+                                        bytes11 <= (g.dtype == kF64 ? (size_t)128 << 20 : (size_t)32 << 20)));
   if (!forced && (g.ndims == 4 || column3 || sweep3) && best != 4 && fits11) {
     if (pool_alloc(h->device, &h->bricks11_owned, bytes11) == hipSuccess) {
       GridDesc t = g;
