@@ -489,8 +489,8 @@ def committed_config_traffic(row, spec):
                     main = {c: d[c] for c in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum",
                                               "TCC_EA0_WRREQ_64B_sum") if c in d}
             # fabric REQUESTS (128-byte reads, 64-/32-byte writes) of all the evaluation's kernels, and the rate this run's time
-            # makes of them: every BASELINE configuration sits at 5.2-5.8e10 requests/s, the part's random-line rate
-            # (cfg4, whose writes are partial lines: 4e10)
+            # makes of them (the one-pass brick kernels on unordered points sit at 5.2-5.8e10 requests/s, the fabric's
+            # random-line rate; the sweep kernel makes fewer requests — DESIGN.md section 4; cfg4, whose writes are partial lines: 4e10)
             reqs = sum(d.get("TCC_EA0_RDREQ_sum", 0.0) + d.get("TCC_EA0_WRREQ_sum", 0.0) for d in e.get("kernels", {}).values())
             return {"fabric_requests_per_evaluation": round(reqs) if reqs else None,
                     "fabric_requests_per_point": round(reqs / row["points"], 3) if reqs else None,
