@@ -70,7 +70,7 @@
  *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
  *                                       with a clock; linear_sweep.h; multicubic: 640 / 1280 points by their cell along dim 2,
  *                                       rows on the fully overlapped tile table, cubic_sweep.h): auto (multilinear: batches of >= 4
- *                                       rounds per wave ~ 1.26e7 points in f64, 8 where the L2 holds the table, f32 6; multicubic:
+ *                                       rounds per wave ~ 1.26e7 points in f64, 8 where the L2 holds the table, f32 3 / 6; multicubic:
  *                                       regular grids with that table beyond the L2, from 2 rounds per wave ~ 4e6 points), never,
  *                                       or whenever the handle has the table (creation: 0 also skips building it);
  *                                       INTERPN_HIP_SWEEP_PERIOD=n ticks of 10 ns per sweep (0 = what the previous launch

@@ -79,7 +79,7 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if (!beyond_l2 && g.kind == kRectilinear) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   const size_t per_cu = g.dtype == kF64 ? (size_t)(kSweepRows + (g.kind == kRectilinear ? kSweepParkedRect : kSweepParked)) * kSweepThreads : kSweepPointsPerCuF32;
-  const size_t rounds = g.dtype == kF64 ? (beyond_l2 ? 4 : 8) : 6;
+  const size_t rounds = g.dtype == kF64 ? (beyond_l2 ? 4 : 8) : (beyond_l2 ? 3 : 6);  // (f32, third session: 80^3 from 9e6 points, 128^3 from 6e6; 64^3 — L2-resident — from 2.4e7)
   if (npts < rounds * per_cu * cus) return 1;
   return 2;
 }
