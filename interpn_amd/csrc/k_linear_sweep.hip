@@ -173,7 +173,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
   s.rounds = (unsigned)rounds;
   s.per_shard = (s.rounds + 7u) / 8u;
   s.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
-  s.period_default = 2200;  // 22 us: a round on a 64^3 f64 grid (the first launch through a scratch block; the kernel measures from then on)
+  s.period_default = 2600;  // 26 us: 0.9 x a round of 16 rows on a 64^3 f64 grid (the first launch through a scratch block; the kernel measures from then on)
   s.work = static_cast<SweepWork*>(work);
   s.stamps = nullptr;
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
