@@ -2305,6 +2305,27 @@ def test_cubic_sweep_evaluation(oracle, kind, axis, linearize, fma, dtype):
         it.close()
 
 
+def test_division_free_forms_against_the_divide_sequences():
+    """interpn_device.h::divide_fast / floor_quotient_fast on the GPU against the hardware's own IEEE divide sequences
+    (tools/ablate_linear3d.hip::ablate_division_selftest): 2^30 (a, b) pairs per type over the admitted exponent ranges,
+    a quarter of them with quotients next to integers — every quotient bit for bit, every floor that the short form
+    reports as exact (~8e7 of the f64 pairs, more in f32).  (The arithmetic itself is pinned on the CPU with exact rationals: tests/test_step_cell_cpu.py.)"""
+    import ctypes
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libinterpn_ablate.so")
+    if not os.path.exists(path):
+        pytest.skip("tools/libinterpn_ablate.so not built")
+    lib = ctypes.CDLL(path)
+    lib.ablate_division_selftest.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_uint, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+    for f32 in (0, 1):
+        bad, floors = ctypes.c_ulonglong(1), ctypes.c_ulonglong(0)
+        rc = lib.ablate_division_selftest(f32, 0x5EED0000 + f32, 1024, ctypes.byref(bad), ctypes.byref(floors))
+        assert rc == 0, rc
+        assert bad.value == 0, (f32, bad.value)
+        assert floors.value > 2**25, (f32, floors.value)  # the pairs whose quotient lies below 2^31 (f32: 2^20) and away from the integers
+
+
 def test_sweep_first_bad_index_alignment_and_streams(oracle):
     """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
     multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and

@@ -231,6 +231,79 @@ int ablate_line_visits(const void* table, size_t table_bytes, size_t visits, dou
   return (int)hipGetLastError();
 }
 
+// The division-free forms of interpn_device.h against the hardware's IEEE divide sequences, on the GPU itself: every
+// thread draws (a, b) pairs over the admitted exponent ranges (random significands, both signs; every fourth pair with a
+// quotient next to an integer or a power of two) and compares divide_fast(a, b, RN(1 / b)) with a / b bit for bit, and
+// floor_quotient_fast's floor with floor(a / b) wherever it reports its result as exact.  Returns the number of
+// differing pairs in `*mismatches` (tests/test_gpu_parity.py::test_division_free_forms_against_the_divide_sequences).
+extern "C++" {
+namespace {
+template <typename T> struct SelfTestBits;
+template <> struct SelfTestBits<double> {
+  static __device__ double make(unsigned long long r, int elo, int ehi) {
+    const int e = elo + (int)((r >> 53) % (unsigned)(ehi - elo));
+    const double m = 1.0 + (double)(r & ((1ull << 52) - 1)) * 0x1p-52;
+    return ldexp((r >> 63) ? -m : m, e);
+  }
+  static __device__ bool same(double x, double y) { return __double_as_longlong(x) == __double_as_longlong(y); }
+  static constexpr int alo = -256, ahi = 256, blo = -128, bhi = 128;
+};
+template <> struct SelfTestBits<float> {
+  static __device__ float make(unsigned long long r, int elo, int ehi) {
+    const int e = elo + (int)((r >> 40) % (unsigned)(ehi - elo));
+    const float m = 1.0f + (float)(r & ((1u << 23) - 1)) * 0x1p-23f;
+    return ldexpf((r >> 63) ? -m : m, e);
+  }
+  static __device__ bool same(float x, float y) { return __float_as_uint(x) == __float_as_uint(y); }
+  static constexpr int alo = -24, ahi = 24, blo = -16, bhi = 16;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_division_selftest(unsigned long long seed, unsigned per_thread, unsigned long long* mismatches, unsigned long long* checked_floor) {
+  typedef SelfTestBits<T> B;
+  unsigned long long z = seed + ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+  unsigned long long bad = 0, fl = 0;
+  for (unsigned i = 0; i < per_thread; ++i) {
+    const unsigned long long r1 = visit_mix(z), r2 = visit_mix(z + 1), r3 = visit_mix(z + 2);
+    z += 3;
+    const T b = B::make(r1, B::blo, B::bhi);
+    T a = B::make(r2, B::alo, B::ahi);
+    if ((i & 3u) == 3u) {  // quotients next to integers / powers of two: a = b * (k + tiny) in working precision
+      const T k = (T)(long long)((r3 >> 8) % 4096ull) + (T)1;
+      const T eps = (T)((r3 & 255ull)) * (sizeof(T) == 8 ? (T)0x1p-50 : (T)0x1p-21);
+      a = b * (k + ((r3 >> 62) & 1 ? eps : -eps));
+    }
+    const volatile T one = (T)1;
+    const T rb = one / b;
+    T q;
+    const bool in_range = divide_fast(a, b, rb, &q);
+    if (in_range && !B::same(q, a / b)) ++bad;
+    T floc;
+    if (floor_quotient_fast(a, rb, &floc)) {
+      ++fl;
+      const T ref = sizeof(T) == 8 ? (T)floor((double)(a / b)) : (T)floorf((float)(a / b));
+      if (!B::same(floc, ref) && !(floc == ref)) ++bad;  // (floors of +0 / -0 compare equal)
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+  atomicAdd(checked_floor, fl);
+}
+}  // namespace
+}  // extern "C++"
+int ablate_division_selftest(int f32, unsigned long long seed, unsigned per_thread, unsigned long long* mismatches, unsigned long long* floors_checked) {
+  unsigned long long* d = nullptr;
+  if (hipMalloc(&d, 16) != hipSuccess) return (int)hipGetLastError();
+  (void)hipMemset(d, 0, 16);
+  if (f32) hipLaunchKernelGGL(k_division_selftest<float>, dim3(4096), dim3(256), 0, 0, seed, per_thread, d, d + 1);
+  else hipLaunchKernelGGL(k_division_selftest<double>, dim3(4096), dim3(256), 0, 0, seed, per_thread, d, d + 1);
+  hipError_t e = hipDeviceSynchronize();
+  unsigned long long h[2] = {~0ull, 0};
+  if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (mismatches) *mismatches = h[0];
+  if (floors_checked) *floors_checked = h[1];
+  return (int)e;
+}
+
 void ablate_destroy(void* handle) {
   Ablate* h = static_cast<Ablate*>(handle);
   if (!h) return;
