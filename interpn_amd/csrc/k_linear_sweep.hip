@@ -59,6 +59,7 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
 int sweep_applies(const GridDesc& g, size_t npts) {
   if (g.method == kCubic) return cubic_sweep_applies(g, npts);  // 3-D multicubic: cubic_sweep.h
+  if (g.method == kLinear && g.ndims == 2) return linear2_sweep_applies(g, npts);  // 2-D multilinear: k_linear2_brick.hip
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
   if (g.sweep_table_bytes >= (1ull << 32)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
@@ -195,6 +196,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
                                void* work, hipStream_t stream) {
   if (g.method == kCubic) return launch_cubic_sweep(g, obs, out, npts, first_bad, work, stream);
+  if (g.method == kLinear && g.ndims == 2) return launch_linear2_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.ndims != 3 || !g.sweep_bricks || !work || npts == 0) return hipErrorInvalidValue;
   for (int d = 0; d < 3; ++d)
     if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)

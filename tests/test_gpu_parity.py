@@ -2326,6 +2326,64 @@ def test_division_free_forms_against_the_divide_sequences():
         assert floors.value > 2**25, (f32, floors.value)  # the pairs whose quotient lies below 2^31 (f32: 2^20) and away from the integers
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("axis", [[70, 90], [200, 40], [40, 300]], ids=["70x90", "long_dim0", "long_dim1"])  # leading cell index >> 2 for the 64 bins; many bricks per row
+def test_linear2_sweep_evaluation(oracle, axis, fma, dtype):
+    """The sweep evaluation of 2-D multilinear batches on regular grids (k_linear2_brick.hip::k_linear2_sweep: every wave sorts
+    1280 (f64: 16 rows in registers + 4 parked in LDS) / 2048 (f32) points by leading cell index on chip and walks its rows in
+    step with a clock; rows = the 2-D brick kernel's lane-pair gather, cell index and t without divide sequences) against the
+    oracle and, bit for bit, against the brick kernel: batches of one point, of a round less / plus one point, of many ragged
+    rounds; extrapolated and special points (grid lines, +-0, infinities, NaN: the first-failing-index contract); with the
+    clock and without; both cargo flavours (multilinear/regular.rs:296-404)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = synthetic_case("linear", "regular", 2, axis, 250_007, 1500 + sum(axis), dtype, extrap=0.2, specials=True)
+    want = run_oracle(oracle, case, fma)
+    tname = "double" if dtype == np.float64 else "float"
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals, fma=fma)
+    try:
+        full = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for count, period in ((1, 0), (1279, 0), (1280, 1), (1281, 0), (2047, 0), (2048, 1), (2049, 1500), (100_003, 0), (250_007, 1), (250_007, 0),
+                              (250_007, 0), (250_007, 900)):
+            obs = [t[:count].clone() for t in full]
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert it.kernel_name().startswith(f"interpn::k_linear2_sweep<{tname}, "), it.kernel_name()
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place" and it.kernel_name().startswith("interpn::k_linear2_brick"), it.kernel_name()
+            it.finish()
+            g, r = got.cpu().numpy(), ref.cpu().numpy()
+            assert np.all((g == r) | (np.isnan(g) & np.isnan(r))), (count, period)
+            w = want[:count]
+            same = (g == w) | (np.isnan(g) & np.isnan(w))
+            assert np.all(same), (count, period, int((~same).sum()))
+        bad = [t.clone() for t in full]
+        bad[1][200_000] = float("nan")
+        bad[0][70_001] = float("inf")
+        bad[1][70_002] = float("nan")
+        it.set_option("sweep", 1)
+        out = it.eval_tensors(bad)
+        assert it.last_path == "sweep"
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            it.finish()
+        assert ei.value.first_bad_index == 70_001
+        assert np.array_equal(out.cpu().numpy()[:70_001], want[:70_001])
+        it.set_option("sweep", -1)
+        it.eval_tensors(full)
+        assert it.last_path == "in_place"  # (a small batch)
+        it.finish()
+    finally:
+        it.close()
+
+
 def test_sweep_first_bad_index_alignment_and_streams(oracle):
     """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
     multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and
