@@ -66,7 +66,7 @@
  *                                       from the records instead of from the upper eight bits of the index words, where the sort
  *                                       leaves them by default — slices are then 2^24 points at most),
  *                                       INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
- *       INTERPN_HIP_SWEEP=-1|0|1        2-D / 3-D multilinear and 3-D multicubic (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 1024 / 1536
+ *       INTERPN_HIP_SWEEP=-1|0|1        2-D / 3-D multilinear and nearest-neighbour, 3-D multicubic (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 1024 / 1536
  *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
  *                                       with a clock; linear_sweep.h; multicubic: 640 / 1280 points by their cell along dim 2,
  *                                       rows on the fully overlapped tile table, cubic_sweep.h): auto (multilinear: batches of >= 4

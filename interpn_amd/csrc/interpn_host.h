@@ -206,6 +206,9 @@ inline Thresholds thresholds(const LaunchConfig& c) {
 bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell);
 int sweep_applies(const GridDesc& g, size_t npts);
 size_t sweep_work_bytes();
+int nearest_sweep_applies(const GridDesc& g, size_t npts);  // k_nearest.hip (2-D / 3-D nearest neighbour, regular grids)
+hipError_t launch_nearest_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
+                                void* work, hipStream_t stream);
 int linear2_sweep_applies(const GridDesc& g, size_t npts);  // k_linear2_brick.hip (2-D multilinear, regular grids)
 hipError_t launch_linear2_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
                                 void* work, hipStream_t stream);

@@ -58,6 +58,7 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
 
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
 int sweep_applies(const GridDesc& g, size_t npts) {
+  if (g.method == kNearest) return nearest_sweep_applies(g, npts);  // 2-D / 3-D nearest neighbour: k_nearest.hip
   if (g.method == kCubic) return cubic_sweep_applies(g, npts);  // 3-D multicubic: cubic_sweep.h
   if (g.method == kLinear && g.ndims == 2) return linear2_sweep_applies(g, npts);  // 2-D multilinear: k_linear2_brick.hip
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
@@ -195,6 +196,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
 
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
                                void* work, hipStream_t stream) {
+  if (g.method == kNearest) return launch_nearest_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kCubic) return launch_cubic_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kLinear && g.ndims == 2) return launch_linear2_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.ndims != 3 || !g.sweep_bricks || !work || npts == 0) return hipErrorInvalidValue;

@@ -2384,6 +2384,67 @@ def test_linear2_sweep_evaluation(oracle, axis, fma, dtype):
         it.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("axis", [[20, 17, 33], [150, 6, 7], [70, 90], [300, 9]], ids=["3d", "3d_long_dim0", "2d", "2d_long_dim0"])
+def test_nearest_sweep_evaluation(oracle, axis, fma, dtype):
+    """The sweep evaluation of 2-D / 3-D nearest-neighbour batches on regular grids (k_nearest.hip::k_nearest_sweep: the
+    multilinear sweep kernel's scaffold and division-free index stage, one gather per point) against the oracle and, bit for
+    bit, against the one-pass kernel: ragged rounds, extrapolated and special points (dt exactly 0.5, grid planes, +-0,
+    infinities, NaN: the first-failing-index contract), with the clock and without; both cargo flavours
+    (nearest/regular.rs:234-317)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = len(axis)
+    case = synthetic_case("nearest", "regular", n, axis, 250_007, 1700 + sum(axis), dtype, extrap=0.2, specials=True)
+    # points exactly half way between two nodes (dt == 0.5 where the arithmetic is exact) and their neighbours
+    for d in range(n):
+        mid = (case.starts[d] + case.steps[d] * (np.arange(40) % (axis[d] - 1) + 0.5)).astype(dtype)
+        case.obs[d][1000:1040] = mid
+        case.obs[d][1040:1080] = np.nextafter(mid, dtype(np.inf))
+        case.obs[d][1080:1120] = np.nextafter(mid, dtype(-np.inf))
+    want = run_oracle(oracle, case, fma)
+    tname = "double" if dtype == np.float64 else "float"
+    it = interpn_amd.Interpolator.regular("nearest", case.dims, case.starts, case.steps, case.vals, fma=fma)
+    try:
+        full = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for count, period in ((1, 0), (1023, 0), (1024, 1), (1025, 0), (1279, 0), (1281, 1), (1535, 0), (1537, 0), (2049, 1500), (100_003, 0),
+                              (250_007, 1), (250_007, 0), (250_007, 0), (250_007, 900)):
+            obs = [t[:count].clone() for t in full]
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert it.kernel_name().startswith(f"interpn::k_nearest_sweep<{tname}, {n}, "), it.kernel_name()
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place" and it.kernel_name().startswith("interpn::k_nearest<"), it.kernel_name()
+            it.finish()
+            g, r = got.cpu().numpy(), ref.cpu().numpy()
+            assert np.array_equal(g, r), (count, period)
+            assert np.array_equal(g, want[:count]), (count, period)
+        bad = [t.clone() for t in full]
+        bad[-1][200_000] = float("nan")
+        bad[0][70_001] = float("inf")
+        it.set_option("sweep", 1)
+        out = it.eval_tensors(bad)
+        assert it.last_path == "sweep"
+        with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+            it.finish()
+        assert ei.value.first_bad_index == 70_001
+        assert np.array_equal(out.cpu().numpy()[:70_001], want[:70_001])
+        it.set_option("sweep", -1)
+        it.eval_tensors(full)
+        assert it.last_path == "in_place"  # (a small batch)
+        it.finish()
+    finally:
+        it.close()
+
+
 def test_sweep_first_bad_index_alignment_and_streams(oracle):
     """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
     multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and
