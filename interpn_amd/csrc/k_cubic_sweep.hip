@@ -54,14 +54,14 @@ template <typename T, bool RECT, bool FMA, int K = cubic_sweep_rows<T, RECT>(), 
 static hipError_t go(const GridDesc& g, CubicSweepArgs<T> s, unsigned cus, hipStream_t stream) {
   {
     const size_t chunk = (size_t)64 * (K + KL);
-    const size_t rounds = (s.c.npts + chunk - 1) / chunk;
+    const size_t rounds = (s.r.npts + chunk - 1) / chunk;
     if (rounds > 0xFFFFFFF0ull) return hipErrorInvalidValue;
-    s.rounds = (unsigned)rounds;
-    s.per_shard = (s.rounds + 7u) / 8u;
+    s.r.rounds = (unsigned)rounds;
+    s.r.per_shard = (s.r.rounds + 7u) / 8u;
   }
   unsigned blocks = cus;
   {
-    const unsigned need = (s.rounds + (TH / 64) - 1) / (TH / 64);
+    const unsigned need = (s.r.rounds + (TH / 64) - 1) / (TH / 64);
     if (blocks > need) blocks = need;
   }
   auto kern = k_cubic_sweep<T, RECT, FMA, K, KL, TH>;
@@ -95,15 +95,20 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
     if (bytes >= 0xFFFFF000ull) return hipErrorInvalidValue;
     a.table_bytes = (unsigned)bytes;
   }
+  SweepRounds<T, 3>& r = s.r;
   a.out = static_cast<T*>(out);
   a.first_bad = first_bad;
   a.npts = npts;
+  r.out = a.out;
+  r.npts = npts;
   a.scatter = nullptr;
   a.index_base = 0;
   a.eighth = 0;
   a.linearize = g.linearize;
   for (int d = 0; d < 3; ++d) {
     a.obs[d] = static_cast<const T*>(obs[d]);
+    r.obs[d] = a.obs[d];
+    r.absent[d] = g.kind == kRectilinear ? (T)0 : (T)g.start[d];
     a.start[d] = (T)g.start[d];
     a.step[d] = (T)g.step[d];
     a.n[d] = g.n[d];
@@ -125,18 +130,19 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
     (void)fill_axis_args<T, 3>(g, a.ax);
     if (a.ax.use_lds && a.ax.image_bytes > kCubicSweepAxisLds) a.ax.use_lds = 0;
     const double span = g.bound_hi[2] - g.bound_lo[2];
-    s.key_start = (T)g.bound_lo[2];
-    s.key_scale = span > 0 ? (T)((double)(g.n[2] - 1) / span) : (T)0;
+    r.key_start = (T)g.bound_lo[2];
+    r.key_scale = span > 0 ? (T)((double)(g.n[2] - 1) / span) : (T)0;
   } else {
-    s.key_start = (T)g.start[2];
-    s.key_scale = (T)(1.0 / g.step[2]);
+    r.key_start = (T)g.start[2];
+    r.key_scale = (T)(1.0 / g.step[2]);
   }
-  if (!(s.key_scale > 0) || !(s.key_scale < (T)1e30)) s.key_scale = 0;  // every point in bin 0: still correct
-  s.key_shift = 0;
-  while (((g.n[2] - 2) >> s.key_shift) >= 64) ++s.key_shift;
-  s.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
-  s.period_default = 4000;  // 40 us: a round of ten cubic rows (the kernel measures from its first launch on)
-  s.work = static_cast<SweepWork*>(work);
+  if (!(r.key_scale > 0) || !(r.key_scale < (T)1e30)) r.key_scale = 0;  // every point in bin 0: still correct
+  r.key_cells = g.n[2] - 2;
+  r.key_shift = 0;
+  while (((g.n[2] - 2) >> r.key_shift) >= 64) ++r.key_shift;
+  r.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
+  r.period_default = 4000;  // 40 us: a round of ten cubic rows (the kernel measures from its first launch on)
+  r.work = static_cast<SweepWork*>(work);
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   if (g.kind == kRegular) return g.fma ? go<T, false, true>(g, s, cus, stream) : go<T, false, false>(g, s, cus, stream);
   return g.fma ? go<T, true, true>(g, s, cus, stream) : go<T, true, false>(g, s, cus, stream);

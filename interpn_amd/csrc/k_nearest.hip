@@ -6,7 +6,7 @@
 #include <type_traits>
 
 #include "lane_axes.h"
-#include "linear_sweep.h"  // SweepWork
+#include "sweep_rounds.h"
 #include "rect_args.h"
 
 namespace interpn {
@@ -134,261 +134,50 @@ __global__ void __launch_bounds__(kBlock) k_nearest(const NearestArgs<T, N> a) {
 // index stage is the multilinear one; on regular grids it runs without divide sequences (interpn_device.h::step_cell_fast).
 template <typename T, int N>
 struct NearestSweepArgs {
-  NearestArgs<T, N> b;
-  T key_start, key_scale;
-  int key_shift;
-  unsigned rounds, per_shard, period, period_default;
-  T rstep[N];
-  unsigned fastdiv;
-  SweepWork* work;
+  SweepRounds<T, N> r;   // sweep_rounds.h: the streams, the sort key, the rounds
+  const T* vals;
+  unsigned long long* first_bad;
+  T start[N], step[N], rstep[N];  // rstep: RN(1 / step), a division in T on the host (interpn_device.h::step_cell_fast)
+  int n[N];
+  unsigned long long stride[N];
+  unsigned fastdiv;      // != 0: every step lies where step_cell_fast is the reference's value
 };
-
-template <typename T, int N, int K, int KL>
-struct NearestSweepLds {
-  static constexpr unsigned kRow = 64u * K * sizeof(T);
-  static constexpr unsigned kPark = 64u * KL * (unsigned)N * sizeof(T);
-  static constexpr unsigned kCnt = 64u * 4u * 2u;
-  static constexpr unsigned kWave = kRow + kPark + kCnt;
-  static constexpr unsigned kWorkgroup = 16;
-  static_assert(kRow + kPark >= 64u * (K + KL) * sizeof(T), "the result exchange spans the row buffer and the parked rows' bytes");
-};
-
-template <int FROM, int TO, typename F>
-__device__ __forceinline__ void nearest_static_for(F&& f) {
-  if constexpr (FROM < TO) {
-    f(std::integral_constant<int, FROM>{});
-    nearest_static_for<FROM + 1, TO>(f);
-  }
-}
 
 template <typename T, int N, bool FMA, int K, int KL, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_nearest_sweep(const NearestSweepArgs<T, N> s) {
-  constexpr int PPV = 16 / (int)sizeof(T);
-  constexpr int KT = K + KL;
-  static_assert(KT % PPV == 0 && KT % 2 == 0 && K >= PPV && KT <= 32, "rows per wave and round");
-  typedef T TV __attribute__((ext_vector_type(PPV)));
-  typedef NearestSweepLds<T, N, K, KL> L;
-  const NearestArgs<T, N>& a = s.b;
+  typedef SweepRoundsLds<T, N, K, KL> L;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned wave = threadIdx.x >> 6;
-  unsigned char* const mine = smem_raw + wave * L::kWave;
-  T* const row = reinterpret_cast<T*>(mine);
-  typedef unsigned short __attribute__((may_alias)) lds_u16;
-  lds_u16* const row16 = reinterpret_cast<lds_u16*>(mine);
-  T* const park = reinterpret_cast<T*>(mine + L::kRow);
-  lds_u32* const cnt = reinterpret_cast<lds_u32*>(mine + L::kRow + L::kPark);
-  lds_u32* const wg_words = reinterpret_cast<lds_u32*>(smem_raw + (THREADS / 64) * L::kWave);
-  if (threadIdx.x < 4) wg_words[threadIdx.x] = 0;
-  __syncthreads();
-  constexpr size_t kChunk = (size_t)64 * KT;
-  const unsigned nwaves = gridDim.x * (THREADS / 64);
-  SweepWork* const work = s.work;
-  unsigned period = s.period;
-  if (period == 0) {
-    period = __hip_atomic_load(&work->period, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (period == 0) period = s.period_default;
-  }
-  period = __builtin_amdgcn_readfirstlane(period);
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  unsigned shard = xcc & 7u;
-  auto take = [&](unsigned sh) -> unsigned {
-    unsigned v = 0;
-    if (lane == 0) v = atomicAdd(&work->head[sh][0], 1u);
-    return v;
-  };
-  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-  unsigned my_rounds = 0;
-  unsigned ticket = take(shard);
-  while (true) {
-    unsigned rr = __builtin_amdgcn_readfirstlane(ticket);
-    if (rr >= s.per_shard || shard * s.per_shard + rr >= s.rounds) {
-      bool found = false;
-      for (unsigned c = 1; c < 8 && !found; ++c) {
-        const unsigned sh = (shard + c) & 7u;
-        const unsigned seen = __hip_atomic_load(&work->head[sh][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen < s.per_shard && sh * s.per_shard + seen < s.rounds) { found = true; shard = sh; }
-      }
-      if (!found) break;
-      ticket = take(shard);
-      continue;
-    }
-    const unsigned r = shard * s.per_shard + rr;
-    ticket = take(shard);
-    ++my_rounds;
-    const size_t base = (size_t)r * kChunk;
-    T x[KT][N];
-    const bool full = base + kChunk <= a.npts;
-    if (full) {
-#pragma unroll
-      for (int d = 0; d < N; ++d)
-#pragma unroll
-        for (int kv = 0; kv < KT / PPV; ++kv) {
-          const TV v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + base) + (kv * 64 + (int)lane));
-#pragma unroll
-          for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
-        }
-    } else {
-#pragma unroll
-      for (int d = 0; d < N; ++d)
-#pragma unroll
-        for (int kv = 0; kv < KT / PPV; ++kv) {
-          const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
-          TV v;
-#pragma unroll
-          for (int h = 0; h < PPV; ++h) v[h] = a.start[d];
-          if (i0 + PPV - 1 < a.npts) {
-            v = stream_load(reinterpret_cast<const TV*>(a.obs[d] + i0));
-          } else {
-#pragma unroll
-            for (int h = 0; h < PPV; ++h)
-              if (i0 + h < a.npts) v[h] = stream_load(a.obs[d] + i0 + h);
-          }
-#pragma unroll
-          for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
-        }
-    }
-    cnt[lane] = 0;
-    wave_sync();
-    unsigned pos[KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const T u = (x[k][0] - s.key_start) * s.key_scale;
-      int c = u >= (T)1 ? (u < (T)(a.n[0] - 2) ? (int)u : a.n[0] - 2) : 0;
-      const unsigned bin = (unsigned)(c >> s.key_shift);
-      pos[k] = atomicAdd(&cnt[bin], 1u) | (bin << 16);
-    }
-    wave_sync();
-    {
-      const unsigned mine_cnt = cnt[lane];
-      unsigned incl = mine_cnt;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned up = (unsigned)__shfl_up((int)incl, off);
-        if (lane >= (unsigned)off) incl += up;
-      }
-      cnt[64 + lane] = incl - mine_cnt;
-    }
-    wave_sync();
-    unsigned rot = 0;
-    if (period > 1) {
-      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
-      const unsigned ph = now % period;
-      rot = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)ph * KT) / period) * 64u);
-    }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      unsigned p = (pos[k] & 0xFFFFu) + cnt[64 + (pos[k] >> 16)];
-      p = p >= rot ? p - rot : p + (unsigned)(64 * KT) - rot;
-      pos[k] = p;
-    }
+  sweep_rounds<T, N, K, KL, THREADS, 0, L>(s.r, smem_raw, [&](auto, const T (&xr)[N], size_t gi) -> T {
+    T t[N];
+    int loc[N];
+    bool ok = true;
+    bool exact = s.fastdiv != 0;
 #pragma unroll
     for (int d = 0; d < N; ++d) {
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        unsigned at = pos[k];
-        if constexpr (KL > 0) at += pos[k] >= 64u * K ? (unsigned)d * (64u * KL) : 0u;  // (the parked rows' bytes follow the row buffer directly)
-        row[at] = x[k][d];
-      }
-      wave_sync();
-#pragma unroll
-      for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + lane];
-      wave_sync();
+      const StepCell<T> sc = step_cell_fast<FMA>(xr[d], s.start[d], s.step[d], s.rstep[d], s.n[d] - 2);
+      t[d] = sc.t;
+      loc[d] = sc.loc;
+      exact = exact && sc.exact;
     }
-    unsigned src[KT / 2];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
-    wave_sync();
-#pragma unroll
-    for (int k2 = 0; k2 < KT / 2; ++k2) src[k2] = (unsigned)row16[(2 * k2) * 64 + lane] | ((unsigned)row16[(2 * k2 + 1) * 64 + lane] << 16);
-    wave_sync();
-    T res[KT];
-    nearest_static_for<0, KT>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      T xr[N];
-#pragma unroll
-      for (int d = 0; d < N; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + lane];
-      T t[N];
-      int loc[N];
-      bool ok = true;
-      bool exact = s.fastdiv != 0;
+    if (__any(!exact)) {  // a lane on a grid plane, far outside, not finite ...: the reference's operations as they stand, for the wave
 #pragma unroll
       for (int d = 0; d < N; ++d) {
-        const StepCell<T> sc = step_cell_fast<FMA>(xr[d], a.start[d], a.step[d], s.rstep[d], a.n[d] - 2);
-        t[d] = sc.t;
-        loc[d] = sc.loc;
-        exact = exact && sc.exact;
-      }
-      if (__any(!exact)) {  // a lane on a grid plane, far outside, not finite ...: the reference's operations as they stand, for the wave
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-          T floc;
-          ok &= regular_floc<T>(xr[d], a.start[d], a.step[d], &floc);  // nearest/regular.rs:306-309
-          const int l = clamp_loc<T>(floc, a.n[d] - 2);
-          const T izl = mul_add<FMA>(a.step[d], (T)l, a.start[d]);
-          t[d] = (xr[d] - izl) / a.step[d];
-          loc[d] = l;
-        }
-      }
-      const size_t gi = base + ((src[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
-      if (!ok && gi < a.npts) atomicMin(a.first_bad, (unsigned long long)gi);
-      // nearest/regular.rs:283-287: the node at origin + (dt <= 0.5 ? 0 : 1) per dimension (NaN compares false => 1); one gather
-      const T half = (T)1 / ((T)1 + (T)1);
-      unsigned long long idx = 0;
-#pragma unroll
-      for (int d = 0; d < N; ++d) idx += (unsigned long long)(loc[d] + ((t[d] <= half) ? 0 : 1)) * a.stride[d];
-      res[k] = a.vals[idx];
-      asm volatile("" : "+v"(res[k]));
-    });
-#pragma unroll
-    for (int k = 0; k < KT; ++k) row[(src[k / 2] >> (16 * (k & 1))) & 0xFFFFu] = res[k];
-    wave_sync();
-#pragma unroll
-    for (int kv = 0; kv < KT / PPV; ++kv) {
-      const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
-      const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * lane]);
-      if (full || i0 + PPV - 1 < a.npts) {
-        stream_store(reinterpret_cast<TV*>(a.out + i0), v);
-      } else {
-#pragma unroll
-        for (int h = 0; h < PPV; ++h)
-          if (i0 + h < a.npts) stream_store(a.out + i0 + h, v[h]);
+        T floc;
+        ok &= regular_floc<T>(xr[d], s.start[d], s.step[d], &floc);  // nearest/regular.rs:306-309
+        const int l = clamp_loc<T>(floc, s.n[d] - 2);
+        const T izl = mul_add<FMA>(s.step[d], (T)l, s.start[d]);     // regular.rs:272-275
+        t[d] = (xr[d] - izl) / s.step[d];
+        loc[d] = l;
       }
     }
-    wave_sync();
-  }
-  const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-  if (lane == 0) {  // the period measurement, exactly as in linear_sweep.h
-    const unsigned my_ticks = (unsigned)(t_end - t_begin);
-    atomicAdd(&wg_words[0], my_ticks);
-    atomicAdd(&wg_words[1], my_rounds);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (atomicAdd(&wg_words[2], 1u) == THREADS / 64 - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const unsigned wg_ticks = wg_words[0], wg_rounds = wg_words[1];
-      if (wg_rounds) {
-        const unsigned long long r1 = atomicAdd(&work->ticks, (unsigned long long)wg_ticks);
-        const unsigned r2 = atomicAdd(&work->rounds, wg_rounds);
-        asm volatile("" ::"v"(r1), "v"(r2));
-      }
-      const unsigned d = atomicAdd(&work->done[0], 1u);
-      if (d == gridDim.x - 1) {
-        const unsigned long long ticks = atomicAdd(&work->ticks, 0ull);
-        const unsigned rounds = atomicAdd(&work->rounds, 0u);
-        if (rounds >= 4 * nwaves) {
-          unsigned long long p = ticks * 9 / ((unsigned long long)rounds * 10);
-          p = p < 200 ? 200 : (p > 20000 ? 20000 : p);
-          atomicExch(&work->period, (unsigned)p);
-        }
-        for (int xx = 0; xx < 8; ++xx) atomicExch(&work->head[xx][0], 0u);
-        atomicExch(&work->ticks, 0ull);
-        atomicExch(&work->rounds, 0u);
-        atomicExch(&work->done[0], 0u);
-      }
-    }
-  }
+    if (!ok && gi < s.r.npts) atomicMin(s.first_bad, (unsigned long long)gi);
+    // nearest/regular.rs:283-287: the node at origin + (dt <= 0.5 ? 0 : 1) per dimension (NaN compares false => 1); one gather
+    const T half = (T)1 / ((T)1 + (T)1);
+    unsigned long long idx = 0;
+#pragma unroll
+    for (int d = 0; d < N; ++d) idx += (unsigned long long)(loc[d] + ((t[d] <= half) ? 0 : 1)) * s.stride[d];
+    return s.vals[idx];
+  });
 }
 
 template <typename T, int N>
@@ -462,7 +251,7 @@ template <typename T, int N> constexpr int nearest_sweep_parked() { return sizeo
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
 int nearest_sweep_applies(const GridDesc& g, size_t npts) {
   if (g.method != kNearest || (g.ndims != 2 && g.ndims != 3) || g.kind != kRegular || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
-  const size_t lds = (size_t)NearestSweepLds<double, 3, 12, 4>::kWave * (kNearestSweepThreads / 64) + NearestSweepLds<double, 3, 12, 4>::kWorkgroup;
+  const size_t lds = (size_t)SweepRoundsLds<double, 3, 12, 4>::kWave * (kNearestSweepThreads / 64) + SweepRoundsLds<double, 3, 12, 4>::kWorkgroup;
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
@@ -479,46 +268,45 @@ template <typename T, int N>
 static hipError_t launch_sweep_n(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad, void* work, hipStream_t stream) {
   constexpr int K = nearest_sweep_rows<T, N>(), KL = nearest_sweep_parked<T, N>(), TH = kNearestSweepThreads;
   NearestSweepArgs<T, N> s;
-  NearestArgs<T, N>& a = s.b;
-  a.vals = static_cast<const T*>(g.vals);
-  a.out = static_cast<T*>(out);
-  a.first_bad = first_bad;
-  a.npts = npts;
+  SweepRounds<T, N>& r = s.r;
+  s.vals = static_cast<const T*>(g.vals);
+  r.out = static_cast<T*>(out);
+  s.first_bad = first_bad;
+  r.npts = npts;
   s.fastdiv = 1;
   unsigned long long acc = 1;
   for (int d = N - 1; d >= 0; --d) {
-    a.obs[d] = static_cast<const T*>(obs[d]);
-    a.start[d] = (T)g.start[d];
-    a.step[d] = (T)g.step[d];
-    a.n[d] = g.n[d];
-    a.stride[d] = acc;
+    r.obs[d] = static_cast<const T*>(obs[d]);
+    s.start[d] = (T)g.start[d];
+    r.absent[d] = s.start[d];
+    s.step[d] = (T)g.step[d];
+    s.n[d] = g.n[d];
+    s.stride[d] = acc;
     acc *= (unsigned long long)g.n[d];
     const volatile T one = (T)1;
     s.rstep[d] = one / (T)g.step[d];
     const double mag = g.step[d] < 0 ? -g.step[d] : g.step[d];
     if (!(mag >= StepCellRange<T>::lo && mag <= StepCellRange<T>::hi)) s.fastdiv = 0;
   }
-  a.ax.use_lds = 0;
-  a.ax.image = nullptr;
-  a.ax.image_bytes = 0;
-  s.key_start = (T)g.start[0];
-  s.key_scale = (T)(1.0 / g.step[0]);
-  if (!(s.key_scale > 0) || !(s.key_scale < (T)1e30)) s.key_scale = 0;
-  s.key_shift = 0;
-  while (((g.n[0] - 2) >> s.key_shift) >= 64) ++s.key_shift;
+  r.key_start = (T)g.start[0];
+  r.key_scale = (T)(1.0 / g.step[0]);
+  if (!(r.key_scale > 0) || !(r.key_scale < (T)1e30)) r.key_scale = 0;
+  r.key_cells = g.n[0] - 2;
+  r.key_shift = 0;
+  while (((g.n[0] - 2) >> r.key_shift) >= 64) ++r.key_shift;
   const size_t chunk = (size_t)64 * (K + KL);
   const size_t rounds = (npts + chunk - 1) / chunk;
   if (rounds > 0xFFFFFFF0ull) return hipErrorInvalidValue;
-  s.rounds = (unsigned)rounds;
-  s.per_shard = (s.rounds + 7u) / 8u;
-  s.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
-  s.period_default = 2000;
-  s.work = static_cast<SweepWork*>(work);
+  r.rounds = (unsigned)rounds;
+  r.per_shard = (r.rounds + 7u) / 8u;
+  r.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
+  r.period_default = 2000;
+  r.work = static_cast<SweepWork*>(work);
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   unsigned blocks = cus;
-  const unsigned need = (s.rounds + (TH / 64) - 1) / (TH / 64);
+  const unsigned need = (r.rounds + (TH / 64) - 1) / (TH / 64);
   if (blocks > need) blocks = need;
-  const size_t lds = (size_t)NearestSweepLds<T, N, K, KL>::kWave * (TH / 64) + NearestSweepLds<T, N, K, KL>::kWorkgroup;
+  const size_t lds = (size_t)SweepRoundsLds<T, N, K, KL>::kWave * (TH / 64) + SweepRoundsLds<T, N, K, KL>::kWorkgroup;
   auto launch = [&](auto kern, bool fma) -> hipError_t {
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
