@@ -318,8 +318,8 @@ template hipError_t launch_linear2_brick<float>(const GridDesc&, const float* co
 // ---- host side of the 2-D sweep evaluation ------------------------------------------------------------------------
 namespace {
 constexpr int kSweep2Threads = 768;
-template <typename T> constexpr int sweep2_rows() { return sizeof(T) == 8 ? 16 : 32; }
-template <typename T> constexpr int sweep2_parked() { return sizeof(T) == 8 ? 4 : 0; }
+template <typename T> constexpr int sweep2_rows() { return sizeof(T) == 8 ? 16 : 28; }  // (f32: 32 rows in registers spill 21 in the fma flavour)
+template <typename T> constexpr int sweep2_parked() { return 4; }
 }  // namespace
 
 // 0 = never for this handle, 1 = not for this batch, 2 = yes.
@@ -333,11 +333,10 @@ int linear2_sweep_applies(const GridDesc& g, size_t npts) {
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
   // automatic (profiles/r05_linear2_sweep.jsonl, 1e8 points): f64 1000^2 1.52 -> 0.87 ms, 2000^2 1.93 -> 1.52, and on tables the
-  // L2 holds 512^2 0.80 -> 0.68, 64^2 0.73 -> 0.56 (3e7 points: 0.22 -> 0.21); f32 1000^2 0.97 -> 0.68, 2000^2 1.59 -> 1.21, but
-  // 512^2 0.58 against 0.60: f32 only beyond the L2.  Crossover: 1000^2 below 1e7 points (0.131 against 0.161 ms there), L2-resident
+  // L2 holds 512^2 0.80 -> 0.68, 64^2 0.73 -> 0.56 (3e7 points: 0.22 -> 0.21); f32 (28 rows in registers + 4 parked: 32 in registers
+  // spilled and gained nothing) 512^2 0.58 -> 0.48, 1000^2 0.96 -> 0.57, 2000^2 1.59 -> 0.80.  Crossover: 1000^2 below 1e7 points (0.131 against 0.161 ms there), L2-resident
   // tables at 2e7 (64^2 .. 512^2: 0.96-0.99 there, 0.84-0.90 at 4e7): from 2.5 rounds per wave, six where the L2 holds the table.
   const bool beyond_l2 = bytes > thresholds(g.cfg).table_l2_sized;
-  if (!beyond_l2 && g.dtype != kF64) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   const size_t per_round = (size_t)(g.dtype == kF64 ? 20 : 32) * kSweep2Threads * cus;
   if (npts < (beyond_l2 ? per_round * 5 / 2 : per_round * 6)) return 1;
