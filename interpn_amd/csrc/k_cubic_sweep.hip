@@ -9,7 +9,7 @@ namespace {
 
 constexpr int kCubicSweepThreads = 768;  // one workgroup per CU, three waves per SIMD
 // rows of 64 points per wave and round: in registers + parked in LDS (cubic_sweep.h K, KL)
-template <typename T, bool RECT> constexpr int cubic_sweep_rows() { return sizeof(T) == 8 ? (RECT ? 6 : 8) : 16; }
+template <typename T, bool RECT> constexpr int cubic_sweep_rows() { return sizeof(T) == 8 ? 6 : 16; }
 template <typename T, bool RECT> constexpr int cubic_sweep_parked() { return sizeof(T) == 8 ? 2 : 4; }
 // LDS the axis image of a rectilinear grid may take beside the waves' regions
 constexpr size_t kCubicSweepAxisLds = 16 * 1024;
@@ -28,7 +28,7 @@ int cubic_sweep_applies(const GridDesc& g, size_t npts) {
   if (g.method != kCubic || g.ndims != 3 || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
   unsigned nb[2];
   if (!tiles11(g, nb)) return 0;
-  const size_t lds = (size_t)CubicSweepLds<double, 8, 2>::kWave * (kCubicSweepThreads / 64) + CubicSweepLds<double, 8, 2>::kWorkgroup +
+  const size_t lds = (size_t)CubicSweepLds<double, 6, 2>::kWave * (kCubicSweepThreads / 64) + CubicSweepLds<double, 6, 2>::kWorkgroup +
                      (g.kind == kRectilinear ? kCubicSweepAxisLds : 0);
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
@@ -45,7 +45,7 @@ int cubic_sweep_applies(const GridDesc& g, size_t npts) {
   if (bytes <= thresholds(g.cfg).table_l2_sized) return 0;
   if (bytes > (g.dtype == kF64 ? (size_t)128 << 20 : (size_t)32 << 20)) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
-  const size_t per_round = (size_t)(g.dtype == kF64 ? 10 : 20) * kCubicSweepThreads * cus;
+  const size_t per_round = (size_t)(g.dtype == kF64 ? 8 : 20) * kCubicSweepThreads * cus;
   if (npts < (g.dtype == kF64 ? 2 * per_round : per_round + per_round / 2)) return 1;
   return 2;
 }

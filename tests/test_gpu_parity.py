@@ -2245,7 +2245,7 @@ def _step_cell_case(oracle, steps, starts, fma, dtype):
                                        ("regular", [64, 9, 12]), ("rectilinear", [24, 11, 40]), ("rectilinear", [8, 70, 90])],
                          ids=["reg", "reg_long_dim2", "reg_flat", "rect", "rect_long"])
 def test_cubic_sweep_evaluation(oracle, kind, axis, linearize, fma, dtype):
-    """The sweep evaluation of 3-D multicubic batches (cubic_sweep.h: every wave sorts 640 (f64; 512 on rectilinear grids) /
+    """The sweep evaluation of 3-D multicubic batches (cubic_sweep.h: every wave sorts 512 (f64) /
     1280 (f32) points by their dim-2 cell on chip and walks its rows in step with a clock, rows = cubic_brick.h's on the fully
     overlapped tile table, regular grids without divide sequences) against the oracle and, bit for bit, against the tiled
     kernel in place: batches of one point, of a round less / plus one point, of many ragged rounds; extrapolated (both
