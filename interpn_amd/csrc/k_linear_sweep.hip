@@ -75,10 +75,9 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   // wave = 1.26e7 points (regular f64) is at most 2 % slower there and 6-12 % faster at 64^3 / 80^3.  f32: six rounds.
   // Tables the L2 holds (third session): on regular grids the division-free rows make the sweep kernel the
   // faster one there too for large batches (1e8 points: f64 24^3 .. 48^3 0.77-0.83 against 0.91-0.96 ms, f32 64^3
-  // 0.59 against 0.68; 3.2e7 points: 7-10 % ahead; 12^3: equal) — from eight rounds per wave; rectilinear grids
-  // keep the brick kernel there (48^3: 1.04 against 1.05 ms).
+  // 0.59 against 0.68; 3.2e7 points: 7-10 % ahead; 12^3: equal) — from eight rounds per wave; rectilinear grids too
+  // (f64 32^3 / 48^3: 0.92-0.95 against 0.99-1.01 ms per 1e8 points, f32 48^3 / 64^3: 0.65-0.66 against 0.78-0.79).
   const bool beyond_l2 = g.sweep_table_bytes > thresholds(g.cfg).table_l2_sized;
-  if (!beyond_l2 && g.kind == kRectilinear) return 0;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   const size_t per_cu = g.dtype == kF64 ? (size_t)(kSweepRows + (g.kind == kRectilinear ? kSweepParkedRect : kSweepParked)) * kSweepThreads : kSweepPointsPerCuF32;
   const size_t rounds = g.dtype == kF64 ? (beyond_l2 ? 4 : 8) : (beyond_l2 ? 3 : 6);  // (f32, third session: 80^3 from 9e6 points, 128^3 from 6e6; 64^3 — L2-resident — from 2.4e7)
