@@ -384,11 +384,8 @@ static hipError_t launch2_t(const GridDesc& g, const void* const* obs, void* out
   const unsigned need = (r.rounds + (TH / 64) - 1) / (TH / 64);
   if (blocks > need) blocks = need;
   const size_t lds = (size_t)SweepRoundsLds<T, 2, K, KL>::kWave * (TH / 64) + SweepRoundsLds<T, 2, K, KL>::kWorkgroup;
-  static std::atomic<unsigned long long> opted{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   auto launch = [&](auto kern, bool fma) -> hipError_t {
-    if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !((opted.load() >> dev) & 1ull))) {
+    if (lds > 64 * 1024) {  // (per launch: the two flavours are two kernels, and the call is cheap beside a batch of this size)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
@@ -396,9 +393,7 @@ static hipError_t launch2_t(const GridDesc& g, const void* const* obs, void* out
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(TH), lds, stream, s);
     return hipGetLastError();
   };
-  hipError_t e = g.fma ? launch(k_linear2_sweep<T, true, K, KL, TH>, true) : launch(k_linear2_sweep<T, false, K, KL, TH>, false);
-  if (e == hipSuccess && dev >= 0 && dev < 64) opted.fetch_or(1ull << dev);  // (both flavours opted in by their own first launch: the bit only skips the call once BOTH ran; harmless to repeat)
-  return e;
+  return g.fma ? launch(k_linear2_sweep<T, true, K, KL, TH>, true) : launch(k_linear2_sweep<T, false, K, KL, TH>, false);
 }
 
 hipError_t launch_linear2_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad, void* work, hipStream_t stream) {
