@@ -2445,6 +2445,50 @@ def test_nearest_sweep_evaluation(oracle, axis, fma, dtype):
         it.close()
 
 
+@pytest.mark.parametrize("method,dims,count", [("cubic", [64, 64, 64], 10_000_000), ("linear", [1000, 1000], 12_000_000), ("nearest", [128, 128, 128], 20_000_000),
+                                               ("nearest", [1200, 1000], 16_000_000)], ids=["cubic3", "linear2", "nearest3", "nearest2"])
+def test_sweep_family_automatic_paths_full_size(oracle, method, dims, count):
+    """The sweep kernels of 3-D multicubic, 2-D multilinear and nearest-neighbour at sizes the automatic rules take them by
+    themselves: the path is reported as the sweep, the whole batch equals the one-pass kernel's bit for bit, 1e5 sampled points
+    equal the oracle."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = len(dims)
+    rng = np.random.default_rng(91)
+    starts = np.full(n, -1.0)
+    steps = np.array([2.0 / (d - 1) for d in dims])
+    vals = rng.uniform(-1, 1, int(np.prod(dims)))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(92)
+    obs = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(n)]
+    it = interpn_amd.Interpolator.regular(method, dims, starts, steps, vals)
+    try:
+        got = it.eval_tensors(obs)
+        assert it.last_path == "sweep", (it.last_path, it.last_path_reason, it.kernel_name())
+        name = it.kernel_name()
+        it.finish()
+        it.set_option("sweep", 0)
+        ref = it.eval_tensors(obs)
+        assert it.last_path == "in_place"
+        it.finish()
+        assert torch.equal(got, ref), name
+        idx = torch.randint(0, count, (100_000,), device=dev, generator=gen)
+        sub = [o[idx].cpu().numpy() for o in obs]
+        w = np.zeros(idx.numel())
+        if method == "cubic":
+            oracle.cubic_regular(dims, starts, steps, vals, False, sub, w)
+        elif method == "linear":
+            oracle.linear_regular(dims, starts, steps, vals, sub, w)
+        else:
+            oracle.nearest_regular(dims, starts, steps, vals, sub, w)
+        assert np.array_equal(got[idx].cpu().numpy(), w)
+    finally:
+        it.close()
+
+
 def test_sweep_first_bad_index_alignment_and_streams(oracle):
     """The sweep path keeps the reference's abort contract (the smallest failing index of the batch,
     multilinear/regular.rs:277-280, 418), leaves batches whose streams are not 16-byte aligned and
