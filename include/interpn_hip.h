@@ -66,12 +66,13 @@
  *                                       from the records instead of from the upper eight bits of the index words, where the sort
  *                                       leaves them by default — slices are then 2^24 points at most),
  *                                       INTERPN_HIP_SCATTER_STAGED=0 (the sort stores records directly)
- *       INTERPN_HIP_SWEEP=-1|0|1        2-D / 3-D multilinear and nearest-neighbour, 3-D multicubic (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 1024 / 1536
+ *       INTERPN_HIP_SWEEP=-1|0|1        2-D / 3-D multilinear, nearest-neighbour and multicubic (f64, f32), device-pointer evaluation: the sweep kernel (every wave orders 1024 / 1536
  *                                       points by leading cell index on chip, all waves walk the one-line brick table in step
  *                                       with a clock; linear_sweep.h; multicubic: 512 / 1280 points by their cell along dim 2,
  *                                       rows on the fully overlapped tile table, cubic_sweep.h): auto (multilinear: batches of >= 4
  *                                       rounds per wave ~ 1.26e7 points in f64, 8 where the L2 holds the table, f32 3 / 6; multicubic:
- *                                       regular grids with that table beyond the L2, from 2 rounds per wave ~ 4e6 points), never,
+ *                                       regular grids with that table beyond the L2, from 2 rounds per wave ~ 4e6 points; 2-D
+ *                                       multicubic: f64 regular grids from 8 rounds per wave ~ 2.2e7 points), never,
  *                                       or whenever the handle has the table (creation: 0 also skips building it);
  *                                       INTERPN_HIP_SWEEP_PERIOD=n ticks of 10 ns per sweep (0 = what the previous launch
  *                                       measured, 1 = no clock)

@@ -1,4 +1,4 @@
-// 3-D multicubic on the fully overlapped tile table with the points of every wave ordered on chip by
+// 3-D (and, with N = 2, 2-D) multicubic on the fully overlapped tile table with the points of every wave ordered on chip by
 // their cell index along the table's slowest dimension, and all waves of the chip walking that index in
 // step with a clock: the sweep evaluation of linear_sweep.h (read its head first: the window argument,
 // the per-wave sort, the clock, the rounds dealt on demand are the same) with cubic_brick.h's rows.
@@ -22,23 +22,26 @@
 
 namespace interpn {
 
-template <typename T>
+// N = 3: the points are ordered by their dim-2 cell (the tile table is stored plane by plane); N = 2: one plane, its tiles stored
+// row of tiles by row of tiles: ordered by their dim-0 cell.
+template <typename T, int N = 3>
 struct CubicSweepArgs {
-  SweepRounds<T, 3> r;     // sweep_rounds.h: the streams, the sort key (dim 2: the tile table's slowest index), the rounds
-  CubicBrickArgs<T, 3> c;  // bricks (steps 1,1), table_bytes, first_bad, start, step, n, ax, plane_stride, nbj, linearize (obs / out / npts: in `r`)
-  T rstep[3];              // regular grids: RN(1 / step[d]), a division in T on the host (interpn_device.h: floor_quotient_fast / divide_fast)
+  SweepRounds<T, N> r;     // sweep_rounds.h: the streams, the sort key, the rounds
+  CubicBrickArgs<T, N> c;  // bricks (steps 1,1), table_bytes, first_bad, start, step, n, ax, plane_stride, nbj, linearize (obs / out / npts: in `r`)
+  T rstep[N];              // regular grids: RN(1 / step[d]), a division in T on the host (interpn_device.h: floor_quotient_fast / divide_fast)
   unsigned fastdiv;        // != 0: every step lies where those forms are the reference's values (StepCellRange<T>)
 };
 
 // LDS per wave: the scaffold's row buffer is also the tile image of cubic_brick.h's LDS-DMA gather (64 tiles: 8 KiB f64, 4 KiB f32).
-template <typename T, int K, int KL>
-using CubicSweepLds = SweepRoundsLds<T, 3, K, KL, 64u * (unsigned)sizeof(T) * 16u>;
+template <typename T, int K, int KL, int N = 3>
+using CubicSweepLds = SweepRoundsLds<T, N, K, KL, 64u * (unsigned)sizeof(T) * 16u>;
 
-template <typename T, bool RECT, bool FMA, int K, int KL, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T> s) {
+template <typename T, bool RECT, bool FMA, int K, int KL, int THREADS, int N = 3>
+__global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T, N> s) {
+  static_assert(N == 2 || N == 3, "tiled multicubic sweep: N = 2, 3");
   typedef typename CubicDimSel<T, RECT>::type DimT;
-  typedef CubicSweepLds<T, K, KL> L;
-  const CubicBrickArgs<T, 3>& a = s.c;
+  typedef CubicSweepLds<T, K, KL, N> L;
+  const CubicBrickArgs<T, N>& a = s.c;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = threadIdx.x >> 6;
@@ -56,14 +59,14 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T>
   // LDS byte address of this wave's tile image (= its row buffer), in a scalar register
   const unsigned lds_wave = (unsigned)__builtin_amdgcn_readfirstlane(
       (int)((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + wave * L::kWave));
-  sweep_rounds<T, 3, K, KL, THREADS, 2, L>(s.r, smem_raw, [&](auto, const T (&xr)[3], size_t gi) -> T {
-    DimT dim[3];
-    int loc[3];
+  sweep_rounds<T, N, K, KL, THREADS, (N == 3 ? 2 : 0), L>(s.r, smem_raw, [&](auto, const T (&xr)[N], size_t gi) -> T {
+    DimT dim[N];
+    int loc[N];
     bool ok = true;
     if constexpr (RECT) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const Axis<T> ax = make_axis<T, 3>(a.ax, axis_base, d);
+      for (int d = 0; d < N; ++d) {
+        const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
         loc[d] = cubic_rect_locate<T>(ax, xr[d], a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
       }
     } else {
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T>
         bool exact = true;
         ok = true;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < N; ++d) {
           const T xx = xr[d];
           T floc;
           if constexpr (FAST) {
@@ -112,7 +115,9 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T>
     // my point's tile (steps 1,1: tile index = cell) as a byte offset; instruction q of a plane's DMA has me
     // fetch piece c of point p (cubic_brick.h::dma_issue_plane)
     constexpr unsigned PP = (unsigned)sizeof(T);
-    const unsigned tb = ((unsigned)loc[2] * a.plane_stride[2] + (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u) * (unsigned)sizeof(T);
+    unsigned tb = (unsigned)(loc[0] * (int)a.nbj + loc[1]) * 16u;
+    if constexpr (N == 3) tb += (unsigned)loc[2] * a.plane_stride[2];
+    tb *= (unsigned)sizeof(T);
     unsigned toff[PP];
 #pragma unroll
     for (int q = 0; q < (int)PP; ++q) {
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T>
       for (int d = 0; d < 2; ++d)
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
-    return reduce_planes_dma<T, 3, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior);
+    return reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior);
   });
 }
 

@@ -2241,6 +2241,68 @@ def _step_cell_case(oracle, steps, starts, fma, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
 @pytest.mark.parametrize("linearize", [False, True], ids=["cubic_extrap", "linearized"])
+@pytest.mark.parametrize("kind,axis", [("regular", [150, 140]), ("regular", [300, 90]), ("rectilinear", [130, 160])], ids=["reg", "reg_long_dim0", "rect"])
+def test_cubic2_sweep_evaluation(oracle, kind, axis, linearize, fma, dtype):
+    """The same for 2-D multicubic batches (cubic_sweep.h with N = 2: one plane of tiles, the points of a wave ordered by their
+    dim-0 cell, the slowest dimension of the tile table): against the oracle and, bit for bit, against the tiled kernel in
+    place, ragged rounds, special and extrapolated points, the first failing index
+    (multicubic/regular.rs:297-623, rectilinear.rs:237-545)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    case = synthetic_case("cubic", kind, 2, axis, 200_003, 1300 + sum(axis), dtype, linearize=linearize, extrap=0.25, specials=True)
+    want = run_oracle(oracle, case, fma)
+    tname = "double" if dtype == np.float64 else "float"
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular("cubic", case.dims, case.starts, case.steps, case.vals, linearize_extrapolation=linearize, fma=fma)
+    else:
+        it = interpn_amd.Interpolator.rectilinear("cubic", case.grids, case.vals, linearize_extrapolation=linearize, fma=fma)
+    try:
+        full = [torch.from_numpy(o).to(dev) for o in case.obs]
+        rows = 14 if dtype == np.float64 else 28
+        for count, period in ((1, 0), (rows * 64 - 1, 0), (rows * 64, 1), (rows * 64 + 1, 1500), (100_003, 0), (200_003, 1), (200_003, 0), (200_003, 2500)):
+            obs = [t[:count].clone() for t in full]
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert it.kernel_name().startswith(f"interpn::k_cubic_sweep<{tname}, " + ("true" if kind == "rectilinear" else "false")), it.kernel_name()
+            assert it.kernel_name().endswith(", 2>"), it.kernel_name()
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place" and it.kernel_name().startswith("interpn::k_cubic_"), it.kernel_name()
+            it.finish()
+            g, r = got.cpu().numpy(), ref.cpu().numpy()
+            assert np.all((g == r) | (np.isnan(g) & np.isnan(r))), (count, period)
+            w = want[:count]
+            same = (g == w) | (np.isnan(g) & np.isnan(w))
+            assert np.all(same), (count, period, int((~same).sum()))
+        if kind == "regular":
+            bad = [t.clone() for t in full]
+            bad[1][150_000] = float("nan")
+            bad[0][60_001] = float("inf")
+            bad[1][60_002] = float("nan")
+            it.set_option("sweep", 1)
+            out = it.eval_tensors(bad)
+            assert it.last_path == "sweep"
+            with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                it.finish()
+            assert ei.value.first_bad_index == 60_001
+            assert np.array_equal(out.cpu().numpy()[:60_001], want[:60_001])
+        it.set_option("sweep", -1)
+        it.eval_tensors(full)
+        assert it.last_path == "in_place"
+        it.finish()
+    finally:
+        it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("linearize", [False, True], ids=["cubic_extrap", "linearized"])
 @pytest.mark.parametrize("kind,axis", [("regular", [20, 17, 33]), ("regular", [9, 8, 150]),  # dim-2 cell index >> 2 for the 64 bins
                                        ("regular", [64, 9, 12]), ("rectilinear", [24, 11, 40]), ("rectilinear", [8, 70, 90])],
                          ids=["reg", "reg_long_dim2", "reg_flat", "rect", "rect_long"])
@@ -2446,7 +2508,8 @@ def test_nearest_sweep_evaluation(oracle, axis, fma, dtype):
 
 
 @pytest.mark.parametrize("method,dims,count", [("cubic", [64, 64, 64], 10_000_000), ("linear", [1000, 1000], 12_000_000), ("nearest", [128, 128, 128], 20_000_000),
-                                               ("nearest", [1200, 1000], 16_000_000)], ids=["cubic3", "linear2", "nearest3", "nearest2"])
+                                               ("nearest", [1200, 1000], 16_000_000), ("cubic", [512, 512], 30_000_000)],
+                         ids=["cubic3", "linear2", "nearest3", "nearest2", "cubic2"])
 def test_sweep_family_automatic_paths_full_size(oracle, method, dims, count):
     """The sweep kernels of 3-D multicubic, 2-D multilinear and nearest-neighbour at sizes the automatic rules take them by
     themselves: the path is reported as the sweep, the whole batch equals the one-pass kernel's bit for bit, 1e5 sampled points

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""3-D multicubic: the sweep kernel (cubic_sweep.h, option sweep = 1) against the tiled kernel in place (sweep = 0) on the same
-handle — bitwise comparison and HIP-event medians.   python tools/cubic_sweep_probe.py [f32] [rect] n... [points=1e7,...]"""
+"""3-D (2-D with "2d") multicubic: the sweep kernel (cubic_sweep.h, option sweep = 1) against the tiled kernel in place (sweep = 0) on the same
+handle — bitwise comparison and HIP-event medians.   python tools/cubic_sweep_probe.py [f32] [rect] [2d] n... [points=1e7,...]"""
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,21 +12,22 @@ gen = torch.Generator(device=dev); gen.manual_seed(5)
 dtype = np.float32 if "f32" in sys.argv else np.float64
 tdt = torch.float32 if dtype == np.float32 else torch.float64
 rect = "rect" in sys.argv
+ND = 2 if "2d" in sys.argv else 3
 sizes = [int(float(v.split("=")[1])) for v in sys.argv[1:] if v.startswith("points=")] or [10_000_000, 30_000_000]
 for n in [int(v) for v in sys.argv[1:] if v.isdigit()] or [64]:
     g = np.linspace(-1.0, 1.0, n)
     rng = np.random.default_rng(n)
-    vals = rng.uniform(-1, 1, n ** 3).astype(dtype)
+    vals = rng.uniform(-1, 1, n ** ND).astype(dtype)
     if rect:
         grids = []
-        for _ in range(3):
+        for _ in range(ND):
             j = (rng.random(n) - 0.5) * 0.5 * (g[1] - g[0]); j[0] = j[-1] = 0.0
             grids.append((g + j).astype(dtype))
         it = interpn_amd.Interpolator.rectilinear("cubic", grids, vals)
     else:
-        it = interpn_amd.Interpolator.regular("cubic", [n] * 3, np.full(3, -1.0, dtype), np.full(3, g[1] - g[0], dtype), vals)
+        it = interpn_amd.Interpolator.regular("cubic", [n] * ND, np.full(ND, -1.0, dtype), np.full(ND, g[1] - g[0], dtype), vals)
     for P in sizes:
-        obs = [(torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05).to(tdt) for _ in range(3)]
+        obs = [(torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.1 - 1.05).to(tdt) for _ in range(ND)]
         outs, res, names = {}, {}, {}
         for mode in (0, 1, 0, 1):
             it.set_option("sweep", mode)
