@@ -1,6 +1,7 @@
 // Handle creation in the reference's validation order, replication onto another device,
 // destruction, status strings.  (C ABI internals, see abi_internal.h.)
 #include "abi_internal.h"
+#include "cubic_cell_record.h"
 
 using namespace interpn;
 using namespace interpn_abi;
@@ -242,6 +243,26 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       for (auto& r : recs) r.clear();
     }
   }
+  // Per-cell records of a multicubic handle (interpn_host.h: axis_crec_*; INTERPN_HIP_CUBIC_RECORDS=0: none)
+  std::vector<std::vector<CubicCellRecord<T>>> crecs(ngrids);
+  g.axis_crec_bytes = 0;
+  {
+    const char* env = getenv("INTERPN_HIP_CUBIC_RECORDS");
+    bool build = method == kCubic && !(env && atoi(env) == 0);
+    size_t total_bytes = 0;
+    for (size_t i = 0; i < ngrids && build; ++i) {
+      if (grid_lens[i] < 4) build = false;
+      total_bytes += (grid_lens[i] - 1) * sizeof(CubicCellRecord<T>);
+    }
+    if (build && bytes + total_bytes < 0xFFFFFF00ull) {
+      for (size_t i = 0; i < ngrids; ++i) {
+        build_cubic_cell_records<T>(grids[i], (int)grid_lens[i], crecs[i]);
+        g.axis_crec_off[i] = (unsigned)bytes;
+        bytes += crecs[i].size() * sizeof(CubicCellRecord<T>);
+      }
+      g.axis_crec_bytes = (unsigned)total_bytes;
+    }
+  }
   g.axis_alloc_bytes = (unsigned)bytes;
   hipError_t e = pool_alloc(h->device, &h->grids_owned, bytes);
   if (e == hipSuccess) e = hipMemsetAsync(h->grids_owned, 0, bytes, nullptr);
@@ -263,6 +284,8 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
     if (e == hipSuccess && g.axis_rec_bytes)
       e = hipMemcpy((char*)h->grids_owned + (g.axis_rec_compact ? g.axis_recg_off[i] : g.axis_rec_off[i]), recs[i].data(), recs[i].size(),
                     hipMemcpyHostToDevice);
+    if (e == hipSuccess && g.axis_crec_bytes)
+      e = hipMemcpy((char*)h->grids_owned + g.axis_crec_off[i], crecs[i].data(), crecs[i].size() * sizeof(CubicCellRecord<T>), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       interpn_hip_destroy(h);
       return hip_fail(e);

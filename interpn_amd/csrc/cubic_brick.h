@@ -37,6 +37,7 @@ struct CubicBrickArgs {
   T step[N];
   int n[N];
   AxisArgs<T, N> ax;
+  const CubicCellRecord<T>* crec[N];  // rectilinear, LDS-DMA form: the axes' per-cell records (nullptr: none; cubic_rect_locate_rec)
   unsigned plane_stride[N];  // d >= 2: table elements per unit index of dim d
   unsigned nbj;
   int linearize;
@@ -122,6 +123,12 @@ __device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typena
   if constexpr (RECT) return cubic_rect_node<FMA, T>(v0, v1, v2, v3, d);
   else return cubic_regular_node<FMA, T>(v0, v1, v2, v3, d);
 }
+// FAST (rectilinear grids): the node's divisions without divide sequences while `ok` holds (cubic_rect_node_fast)
+template <bool RECT, bool FMA, bool FAST, typename T>
+__device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typename CubicDimSel<T, RECT>::type& d, bool& ok) {
+  if constexpr (RECT && FAST) return cubic_rect_node_fast<FMA, T>(v0, v1, v2, v3, d, ok);
+  else return cubic_node_sel<RECT, FMA, T>(v0, v1, v2, v3, d);
+}
 
 // Gather one (i, j) footprint plane at table offset `delta` for all lanes, reduce dims 0 and 1.
 template <typename T, bool RECT, bool FMA>
@@ -203,8 +210,8 @@ __device__ __forceinline__ void dma_take_tile(unsigned lds_wave, unsigned wl, T 
 }
 
 // dims 0 and 1 of one tile
-template <typename T, bool RECT, bool FMA>
-__device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+template <typename T, bool RECT, bool FMA, bool FAST = false>
+__device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicDimSel<T, RECT>::type* dim, unsigned interior, bool& ok) {
   T w4[4];
   if constexpr (!RECT) {
     if (interior & 1u) {
@@ -217,9 +224,15 @@ __device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicD
     return cubic_regular_node<FMA, T>(w4[0], w4[1], w4[2], w4[3], dim[1]);
   } else {
 #pragma unroll
-    for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
-    return cubic_node_sel<RECT, FMA, T>(w4[0], w4[1], w4[2], w4[3], dim[1]);
+    for (int ej = 0; ej < 4; ++ej) w4[ej] = cubic_node_sel<RECT, FMA, FAST, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0], ok);
+    return cubic_node_sel<RECT, FMA, FAST, T>(w4[0], w4[1], w4[2], w4[3], dim[1], ok);
   }
+}
+
+template <typename T, bool RECT, bool FMA>
+__device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+  bool unused = true;
+  return reduce_tile<T, RECT, FMA, false>(v, dim, interior, unused);
 }
 
 // All 4^(N-2) planes of a point, software-pipelined: the DMA of plane k+1 is issued as soon as
@@ -228,10 +241,12 @@ __device__ __forceinline__ T reduce_tile(const T (&v)[16], const typename CubicD
 // with one tile image per wave and no extra registers (the tile is in registers anyway).
 // Plane order and reduction tree are the reference's (dim 2 inside dim 3;
 // src/multicubic/regular.rs:368-421).
-template <typename T, int N, bool RECT, bool FMA>
+// FAST: see cubic_node_sel; `*ok` (in: the dimensions' `fast`; out: every division of the point was the short form's to take).
+template <typename T, int N, bool RECT, bool FMA, bool FAST = false>
 __device__ __forceinline__ T reduce_planes_dma(__amdgpu_buffer_rsrc_t bricks, const unsigned* dma_off, const unsigned* plane_stride,
                                                unsigned lds_wave, unsigned wl,
-                                               const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+                                               const typename CubicDimSel<T, RECT>::type* dim, unsigned interior, bool* okp = nullptr) {
+  bool ok = FAST ? *okp : true;
   static_assert(N >= 2 && N <= 4, "tiled multicubic: N = 2..4");
   constexpr int NP = N == 2 ? 1 : (N == 3 ? 4 : 16);
   auto delta_of = [&](int k) -> unsigned {  // byte offset of plane k: dim 2 index = k & 3, dim 3 index = k >> 2
@@ -248,22 +263,23 @@ __device__ __forceinline__ T reduce_planes_dma(__amdgpu_buffer_rsrc_t bricks, co
     T v[16];
     dma_take_tile<T>(lds_wave, wl, v);
     if (k + 1 < NP) dma_issue_plane<T>(bricks, dma_off, delta_of(k + 1), lds_wave);
-    const T r01 = reduce_tile<T, RECT, FMA>(v, dim, interior);
+    const T r01 = reduce_tile<T, RECT, FMA, FAST>(v, dim, interior, ok);
     if constexpr (N == 2) {
       res = r01;
     } else {
       s2[k & 3] = r01;
       if ((k & 3) == 3) {
-        const T r2 = cubic_node_sel<RECT, FMA, T>(s2[0], s2[1], s2[2], s2[3], dim[2]);
+        const T r2 = cubic_node_sel<RECT, FMA, FAST, T>(s2[0], s2[1], s2[2], s2[3], dim[2], ok);
         if constexpr (N == 3) {
           res = r2;
         } else {
           s3[k >> 2] = r2;
-          if (k == NP - 1) res = cubic_node_sel<RECT, FMA, T>(s3[0], s3[1], s3[2], s3[3], dim[3]);
+          if (k == NP - 1) res = cubic_node_sel<RECT, FMA, FAST, T>(s3[0], s3[1], s3[2], s3[3], dim[3], ok);
         }
       }
     }
   }
+  if constexpr (FAST) *okp = ok;
   return res;
 }
 
@@ -329,12 +345,19 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
     DimT dim[N];
     int loc[N];
     bool ok = true;
+    [[maybe_unused]] T xs[N];
 #pragma unroll
     for (int d = 0; d < N; ++d) {
       if constexpr (RECT) {
         const T x = live ? stream_load(a.obs[d] + i0) : (T)0;
         const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-        loc[d] = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
+        if constexpr (DMA) {
+          xs[d] = x;
+          if (a.crec[0]) loc[d] = cubic_rect_locate_rec<T>(ax, a.crec[d], x, a.linearize, dim[d]);  // (wave-uniform)
+          else loc[d] = cubic_rect_locate<T, true>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);
+        } else {
+          loc[d] = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
+        }
       } else {
         const T x = live ? stream_load(a.obs[d] + i0) : a.start[d];
         T floc;
@@ -396,7 +419,22 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
     T res;
-    if constexpr (DMA)
+    if constexpr (DMA && RECT) {
+      // the nodes' spacing-ratio divisions first without divide sequences; a wave with a lane whose operands that form
+      // does not take (a ratio or a numerator outside its exponent window, a -0) evaluates once more as the reference writes it
+      bool fast = true;
+#pragma unroll
+      for (int d = 0; d < N; ++d) fast = fast && dim[d].fast;
+      res = reduce_planes_dma<T, N, RECT, FMA, true>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior, &fast);
+      if (__any(!fast)) {
+        if (a.crec[0]) {  // (the records' t and coefficients were the short forms': this wave's again, by division)
+#pragma unroll
+          for (int d = 0; d < N; ++d)
+            (void)cubic_rect_locate<T>(make_axis<T, N>(a.ax, axis_base, d), xs[d], a.linearize, /*fma_linear=*/false, dim[d]);
+        }
+        res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);
+      }
+    } else if constexpr (DMA)
       res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);
     else
       res = PlaneReduce<T, N - 1, RECT, FMA, false>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T,
 #pragma unroll
       for (int d = 0; d < N; ++d) {
         const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-        loc[d] = cubic_rect_locate<T>(ax, xr[d], a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
+        if (a.crec[0]) loc[d] = cubic_rect_locate_rec<T>(ax, a.crec[d], xr[d], a.linearize, dim[d]);  // (wave-uniform)
+        else loc[d] = cubic_rect_locate<T, true>(ax, xr[d], a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
       }
     } else {
       // cell, saturation class and t of the three dimensions: first without the six divide sequences
@@ -131,7 +132,23 @@ __global__ void __launch_bounds__(THREADS) k_cubic_sweep(const CubicSweepArgs<T,
       for (int d = 0; d < 2; ++d)
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
-    return reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior);
+    if constexpr (RECT) {  // (cubic_brick.h: the nodes' divisions in their short form first)
+      bool fast = true;
+#pragma unroll
+      for (int d = 0; d < N; ++d) fast = fast && dim[d].fast;
+      T res = reduce_planes_dma<T, N, RECT, FMA, true>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior, &fast);
+      if (__any(!fast)) {
+        if (a.crec[0]) {
+#pragma unroll
+          for (int d = 0; d < N; ++d)
+            (void)cubic_rect_locate<T>(make_axis<T, N>(a.ax, axis_base, d), xr[d], a.linearize, /*fma_linear=*/false, dim[d]);
+        }
+        res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior);
+      }
+      return res;
+    } else {
+      return reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane, dim, interior);
+    }
   });
 }
 

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cubic_cell_record.h"
+
 namespace interpn {
 
 constexpr int kMaxDims = 8;  // src/python.rs:10
@@ -254,6 +256,32 @@ __device__ __forceinline__ bool divide_fast(float a, float b, float rb, float* q
 template <typename T> struct StepCellRange;
 template <> struct StepCellRange<double> { static constexpr double lo = 0x1p-128, hi = 0x1p128; };
 template <> struct StepCellRange<float> { static constexpr double lo = 0x1p-16, hi = 0x1p16; };
+
+// The quotient sequence of divide_fast alone, and the two tests that admit its operands where the divisor is not a
+// host constant (the spacing ratios of a rectilinear multicubic cell, cubic_rect_node_fast below):
+//   divisor b: positive, 2^-128 <= b < 2^128 (f32: 2^-16 <= b < 2^16), rb = RN(1 / b) by a division in T;
+//   numerator a: 2^-256 <= |a| < 2^256 (f32: 2^-24 .. 2^24) or +0.  (+0 with b > 0: q0 = +0, both remainders
+//   +0 - 0 = +0, both corrections +0 + +0 = +0 = +0 / b.  -0 is not admitted: the corrections would add +0 to -0.)
+__device__ __forceinline__ double quotient_fast(double a, double b, double rb) {
+  const double q0 = a * rb;
+  const double r0 = __builtin_fma(-b, q0, a);
+  const double q1 = __builtin_fma(r0, rb, q0);
+  const double r1 = __builtin_fma(-b, q1, a);
+  return __builtin_fma(r1, rb, q1);
+}
+__device__ __forceinline__ float quotient_fast(float a, float b, float rb) {
+  const float q0 = a * rb;
+  const float r0 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(r0, rb, q0);
+  const float r1 = __builtin_fmaf(-b, q1, a);
+  return __builtin_fmaf(r1, rb, q1);
+}
+__device__ __forceinline__ bool fast_numerator(double a) { return exponent_within_256(a) || __builtin_amdgcn_class(a, 0x40); }
+__device__ __forceinline__ bool fast_numerator(float a) { return exponent_within_24(a) || __builtin_amdgcn_classf(a, 0x40); }
+__device__ __forceinline__ bool fast_divisor(double b) {  // sign bit in the field: negative divisors fail
+  return (((unsigned)__double2hiint(b) >> 20) - (1023u - 128u)) < 256u;
+}
+__device__ __forceinline__ bool fast_divisor(float b) { return ((__float_as_uint(b) >> 23) - (127u - 16u)) < 32u; }
 
 // core::slice::partition_point(|g| *g < x) restated with Rust std's probe sequence
 // (size-halving binary search); trip count depends only on n, so a wave never diverges.
@@ -564,13 +592,17 @@ struct CubicDimRect {
   // carries a single real division; r is the other (non-unit) spacing ratio.
   T r0, a0, c0;  // k0's difference: hB == 1 for None/High, hA == 1 for Low
   T r1, a1, c1;  // k1's difference (None only): hA == 1
+  // cubic_rect_node_fast only (RECIP setup): RN(1 / r0), RN(1 / r1); fast: both ratios pass fast_divisor
+  T rr0, rr1;
+  bool fast;
 };
 
-template <typename T, typename GridPtr>
+template <typename T, bool RECIP = false, typename GridPtr>
 __device__ __forceinline__ void cubic_rect_dim_setup(GridPtr g, int loc, T x, CubicDimRect<T>& d) {
   const T one = (T)1;
   T g0 = g[loc], g1 = g[loc + 1], g2 = g[loc + 2], g3 = g[loc + 3];
   d.r1 = one; d.a1 = one; d.c1 = one;
+  d.rr0 = one; d.rr1 = one; d.fast = false;
   if (d.sat == kSatNone) {
     T h01 = g1 - g0, h12 = g2 - g1, h23 = g3 - g2;
     d.r0 = h01 / h12;  // (hA, hB) = (r0, 1)
@@ -592,6 +624,11 @@ __device__ __forceinline__ void cubic_rect_dim_setup(GridPtr g, int loc, T x, Cu
     d.a0 = d.r0 / (d.r0 + one);
     d.c0 = one / (one + d.r0);
     d.t = (x - g2) / h23;
+  }
+  if constexpr (RECIP) {
+    d.rr0 = one / d.r0;
+    if (d.sat == kSatNone) d.rr1 = one / d.r1;
+    d.fast = fast_divisor(d.r0) && fast_divisor(d.r1);
   }
 }
 
@@ -645,6 +682,47 @@ __device__ __forceinline__ T cubic_rect_node(T v0, T v1, T v2, T v3, const Cubic
     if (FMA && d.fma_linear) return dev_fma<T>(k1, d.t - one, y1);
     T p = k1 * (d.t - one);
     return y1 + p;  // rectilinear.rs:500,:539 — never fused in the flattened arm
+  }
+  return hermite<FMA>(d.t, y0, dy, k0, k1);
+}
+
+// The same node for a wave whose lanes differ in class, without a branch per class and with the two spacing-ratio
+// divisions as quotient_fast: every operation a lane's result depends on is the operation cubic_rect_node does for that
+// lane's class, on the same operands, in the same order (the operands are chosen by selects; what a lane computes for the
+// other classes is discarded) — the reference's bits where `ok` stays true (d.fast and every numerator in use admitted);
+// where it does not the caller evaluates the point again with cubic_rect_node.
+//   first difference  None: cd_unit_b(v0, v1, v2), Low: -cd_unit_a(v0, v1, v2), High: cd_unit_b(v1, v2, v3)   (r0, a0, c0)
+//   second difference None: cd_unit_a(v1, v2, v3) (r1, a1, c1); Low / High: 2 dy - k0
+template <bool FMA, typename T>
+__device__ __forceinline__ T cubic_rect_node_fast(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d, bool& ok) {
+  const T two = (T)2, one = (T)1;
+  const bool low = d.sat == kSatLow, high = d.sat == kSatHigh;
+  const bool none = !(low || high);
+  const T f01 = v1 - v0, f12 = v2 - v1, f23 = v3 - v2;
+  const T e01 = high ? f12 : f01;  // y1 - y0 and y2 - y1 of the first difference's three values
+  const T e12 = high ? f23 : f12;
+  const T num0 = low ? e12 : e01;  // the side that is divided by the ratio: unit_a (Low) b = e12 / r, unit_b dd = e01 / r
+  ok = ok && fast_numerator(num0);
+  const T q0 = quotient_fast(num0, d.r0, d.rr0);
+  const T b0 = low ? q0 : e12;
+  const T d0 = low ? e01 : q0;
+  T k0;
+  if constexpr (FMA) k0 = dev_fma<T>(d.a0, b0, d.c0 * d0);
+  else { const T ab = d.a0 * b0; const T cdd = d.c0 * d0; k0 = ab + cdd; }
+  k0 = low ? -k0 : k0;
+  ok = ok && (!none || fast_numerator(f23));
+  const T q1 = quotient_fast(f23, d.r1, d.rr1);  // (r1 = rr1 = 1 on lanes that are not None: finite work, discarded)
+  T k1n;
+  if constexpr (FMA) k1n = dev_fma<T>(d.a1, q1, d.c1 * f12);
+  else { const T ab = d.a1 * q1; const T cdd = d.c1 * f12; k1n = ab + cdd; }
+  const T y0 = high ? v2 : v1;
+  const T dy = low ? v0 - v1 : e12;
+  const T k1 = none ? k1n : two * dy - k0;
+  if (d.linear) {  // (outside the grid with linearize_extrapolation: Low or High)
+    const T y1 = low ? v0 : v3;
+    if (FMA && d.fma_linear) return dev_fma<T>(k1, d.t - one, y1);
+    T p = k1 * (d.t - one);
+    return y1 + p;
   }
   return hermite<FMA>(d.t, y0, dy, k0, k1);
 }

@@ -118,6 +118,11 @@ struct GridDesc {
   // (axis_recg_off) followed by the records (axis_rec_off).
   int axis_rec_compact = 0;
   unsigned axis_recg_off[8] = {0};
+  // Per-cell records of a rectilinear multicubic handle (interpn_device.h::CubicCellRecord): what a point's cell fixes of
+  // cubic_rect_dim_setup — spacing ratios, central-difference weights, their reciprocals — computed once at creation with the
+  // divisions the kernels would do per point.  n - 1 records per axis behind the image; 0 bytes = none.
+  unsigned axis_crec_off[8] = {0};
+  unsigned axis_crec_bytes = 0;
   // Optional bricked copy of `vals` (multilinear, 3 <= N <= 6; see k_linear_brick.hip): the last
   // three dims in 2 x 2 x KW bricks of one 128-B line, steps (brick_step[0], brick_step[1], KW-1).
   // brick_cell = 1 (N >= 4): 2 x 2 x 2 x KW bricks over the last FOUR dims instead (a whole 4-D cell

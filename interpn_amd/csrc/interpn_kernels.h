@@ -255,7 +255,7 @@ struct CubicRectNode {
   }
 };
 
-template <typename T>
+template <typename T, bool RECIP = false>
 __device__ __forceinline__ int cubic_rect_locate(const Axis<T>& ax, T x, int linearize, bool fma_linear, CubicDimRect<T>& d) {
   const T* g = ax.g;
   const int n = ax.n;
@@ -270,7 +270,40 @@ __device__ __forceinline__ int cubic_rect_locate(const Axis<T>& ax, T x, int lin
   else { d.sat = kSatNone; }
   d.linear = (outside && linearize) ? 1 : 0;
   d.fma_linear = fma_linear ? 1 : 0;
-  cubic_rect_dim_setup<T>(g, loc, x, d);
+  cubic_rect_dim_setup<T, RECIP>(g, loc, x, d);
+  return loc;
+}
+
+// The same from the axis' per-cell records: no division.  d.fast = false: the caller must locate again with
+// cubic_rect_locate (a record whose divisors the short form does not take, or x - gref outside its window / not finite).
+template <typename T>
+__device__ __forceinline__ int cubic_rect_locate_rec(const Axis<T>& ax, const CubicCellRecord<T>* rec, T x, int linearize, CubicDimRect<T>& d) {
+  const int n = ax.n;
+  const int iloc = axis_partition_point<T>(ax, x) - 2;  // rectilinear.rs:377
+  int loc = iloc > 0 ? iloc : 0;
+  loc = loc < n - 4 ? loc : n - 4;  // rectilinear.rs:379-381
+  int k = iloc > -1 ? iloc : -1;
+  k = (k < n - 3 ? k : n - 3) + 1;  // cell: 0 .. n - 2
+  const bool low = k == 0, high = k == n - 2;
+  d.sat = low ? kSatLow : (high ? kSatHigh : kSatNone);  // rectilinear.rs:384-405
+  d.linear = ((iloc == -2 || iloc == n - 2) && linearize) ? 1 : 0;
+  d.fma_linear = 0;
+  constexpr int PV = 16 / (int)sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(PV)));
+  const TV* rv = reinterpret_cast<const TV*>(rec + k);
+  T f[12];
+#pragma unroll
+  for (int q = 0; q < 12 / PV; ++q) {
+    const TV v = rv[q];
+#pragma unroll
+    for (int e = 0; e < PV; ++e) f[q * PV + e] = v[e];
+  }
+  d.r0 = f[3]; d.a0 = f[4]; d.c0 = f[5]; d.rr0 = f[6];
+  d.r1 = f[7]; d.a1 = f[8]; d.c1 = f[9]; d.rr1 = f[10];
+  const T num = x - f[0];
+  const T q = quotient_fast(num, f[1], f[2]);
+  d.t = low ? -q : q;  // Low: -(x - g1) / h01 = -((x - g1) / h01), zeros included
+  d.fast = f[11] != (T)0 && fast_numerator(num);
   return loc;
 }
 

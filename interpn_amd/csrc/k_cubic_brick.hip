@@ -79,6 +79,9 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
   if (g.kind == kRectilinear) lds += fill_axis_args<T, N>(g, a.ax);
+  for (int d = 0; d < N; ++d)
+    a.crec[d] = (g.kind == kRectilinear && g.axis_crec_bytes)
+                    ? reinterpret_cast<const CubicCellRecord<T>*>(static_cast<const unsigned char*>(g.axis_image) + g.axis_crec_off[d]) : nullptr;
   unsigned blocks = grid_blocks(npts, 1, g.cfg);
   a.eighth = 0;
   if (scatter && g.cfg.deal && blocks >= 64) {

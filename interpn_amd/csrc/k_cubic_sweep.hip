@@ -11,6 +11,9 @@ constexpr int kCubicSweepThreads = 768;  // one workgroup per CU, three waves pe
 // rows of 64 points per wave and round: in registers + parked in LDS (cubic_sweep.h K, KL)
 template <typename T, bool RECT, int N = 3> constexpr int cubic_sweep_rows() { return N == 2 ? (sizeof(T) == 8 ? 10 : 24) : (sizeof(T) == 8 ? 6 : 16); }
 template <typename T, bool RECT, int N = 3> constexpr int cubic_sweep_parked() { return N == 2 ? 4 : (sizeof(T) == 8 ? 2 : 4); }
+// threads per workgroup: rectilinear f64 rows (three CubicDimRect + the tile: ~130 registers beside the rows' coordinates) get
+// the 256 registers of two waves per SIMD
+template <typename T, bool RECT, int N = 3> constexpr int cubic_sweep_threads() { return RECT && sizeof(T) == 8 ? 512 : kCubicSweepThreads; }
 // LDS the axis image of a rectilinear grid may take beside the waves' regions
 constexpr size_t kCubicSweepAxisLds = 16 * 1024;
 
@@ -63,7 +66,7 @@ int cubic_sweep_applies(const GridDesc& g, size_t npts) {
   return 2;
 }
 
-template <typename T, int N, bool RECT, bool FMA, int K = cubic_sweep_rows<T, RECT, N>(), int KL = cubic_sweep_parked<T, RECT, N>(), int TH = kCubicSweepThreads>
+template <typename T, int N, bool RECT, bool FMA, int K = cubic_sweep_rows<T, RECT, N>(), int KL = cubic_sweep_parked<T, RECT, N>(), int TH = cubic_sweep_threads<T, RECT, N>()>
 static hipError_t go(const GridDesc& g, CubicSweepArgs<T, N> s, unsigned cus, hipStream_t stream) {
   {
     const size_t chunk = (size_t)64 * (K + KL);
@@ -142,6 +145,9 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
   a.ax.use_lds = 0;
   a.ax.image = nullptr;
   a.ax.image_bytes = 0;
+  for (int d = 0; d < N; ++d)
+    a.crec[d] = (g.kind == kRectilinear && g.axis_crec_bytes)
+                    ? reinterpret_cast<const CubicCellRecord<T>*>(static_cast<const unsigned char*>(g.axis_image) + g.axis_crec_off[d]) : nullptr;
   if (g.kind == kRectilinear) {
     (void)fill_axis_args<T, N>(g, a.ax);
     if (a.ax.use_lds && (a.ax.image_bytes > kCubicSweepAxisLds || (long long)(cubic_sweep_wave_lds(g) + a.ax.image_bytes) > g.cfg.lds_per_cu)) a.ax.use_lds = 0;

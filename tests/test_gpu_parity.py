@@ -2238,6 +2238,92 @@ def _step_cell_case(oracle, steps, starts, fma, dtype):
         it.close()
 
 
+def _awkward_values(vals, n, dtype, tiny, huge, rng):
+    sl = lambda lo, hi: tuple(slice(lo, hi) for _ in range(n))
+    vals[sl(0, 4)] = dtype(0.375)                       # equal neighbours
+    z = np.zeros_like(vals[sl(4, 8)])
+    z[rng.random(z.shape) < 0.5] = -0.0
+    vals[sl(4, 8)] = z                                  # zeros of both signs
+    vals[sl(2, 6)][..., 0] *= dtype(tiny)               # tiny beside ordinary values
+    vals[tuple(slice(6, 8) for _ in range(n - 1)) + (slice(None),)] *= dtype(huge)
+    flat = vals.reshape(-1)
+    flat[rng.integers(0, flat.size, 3)] = np.inf
+    flat[rng.integers(0, flat.size, 2)] = np.nan
+    flat[rng.integers(0, flat.size, 2)] = -np.inf
+    return flat
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("axis,ratios", [([40, 36], "plain"), ([40, 36], "extreme"), ([40, 36], "quantized"), ([20, 17, 33], "plain"), ([20, 17, 33], "extreme"),
+                                         ([20, 17, 33], "quantized"), ([9, 8, 10, 11], "plain"), ([9, 8, 10, 11], "quantized")],
+                         ids=["2d", "2d_extreme_ratios", "2d_quantized", "3d", "3d_extreme_ratios", "3d_quantized", "4d", "4d_quantized"])
+@pytest.mark.parametrize("records", ["1", "0"], ids=["cell_records", "no_records"])
+def test_rectilinear_cubic_short_divisions_on_awkward_values(oracle, monkeypatch, records, axis, ratios, fma, dtype):
+    """The rectilinear multicubic node on the fully overlapped tile table takes its two spacing-ratio divisions per node as a
+    reciprocal-and-correction sequence where the operands allow it and evaluates the wave again with the divide sequences
+    where they do not (interpn_device.h::cubic_rect_node_fast; multicubic/rectilinear.rs:413-545, mod.rs:103-117).  Here the
+    grid values and spacings are what that form must hand back: equal neighbours (differences +0), zeros of both signs, blocks
+    of tiny and of huge magnitude (differences outside the admitted exponent window, products that overflow), infinities and
+    NaN among the values, and axes whose neighbouring spacings differ by more than the admitted ratio; "quantized": values on
+    a lattice of 1/4, so that every wave meets differences that are exactly +0 and none that the short form refuses (the short
+    form's own results are what is compared).  With the per-cell records of the axes (cubic_cell_record.h: the seven divisions
+    of a dimension's setup done once at creation, t from the record's reciprocal) and without them.  In place and through
+    the sweep kernel, bit for bit against the oracle."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    monkeypatch.setenv("INTERPN_HIP_CUBIC_RECORDS", records)
+    dev = torch.device("cuda:0")
+    n = len(axis)
+    f64 = dtype == np.float64
+    case = synthetic_case("cubic", "rectilinear", n, axis, 120_003, 4400 + sum(axis), dtype, linearize=bool(n % 2), extrap=0.2, specials=True)
+    rng = np.random.default_rng(77 + n)
+    if ratios == "extreme":
+        for d in range(n):
+            g = case.grids[d].astype(np.float64)
+            k = 3 + 2 * d
+            gap = (1e-160 if f64 else 1e-7) * max(1.0, abs(g[k]))  # f64: h ratio 1e158 > 2^128 (the sum g + gap must still differ from g)
+            if f64:
+                g = g - g[k]  # the pair straddles zero so that the tiny spacing is representable
+                g[k + 1] = gap
+            else:
+                g[k + 1] = np.float32(g[k]) + np.float32(max(gap, np.spacing(np.float32(g[k]))))
+                g[-1] = g[-2] + 3e4  # spacing ratio 3e4 / 0.03 > 2^16
+            g = g.astype(dtype)
+            assert np.all(np.diff(g) > 0)
+            case.grids[d] = g
+    if ratios == "quantized":
+        case.vals = (np.round(case.vals.astype(np.float64) * 4) / 4 + 0.0).astype(dtype)  # (+ 0.0: no negative zeros)
+    vals = case.vals.reshape(axis).copy()
+    tiny, huge = (1e-300, 1e200) if f64 else (1e-36, 1e30)
+    if ratios != "quantized":
+        vals = _awkward_values(vals, n, dtype, tiny, huge, rng)
+    case.vals = vals.reshape(-1).astype(dtype)
+    with np.errstate(all="ignore"):
+        want = run_oracle(oracle, case, fma)
+    it = interpn_amd.Interpolator.rectilinear("cubic", case.grids, case.vals, linearize_extrapolation=case.linearize, fma=fma)
+    try:
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        modes = (0, 1) if n in (2, 3) else (0,)
+        for sweep in modes:
+            it.set_option("sweep", sweep)
+            got = it.eval_tensors(obs).cpu().numpy()
+            name = it.kernel_name()
+            it.finish()
+            if sweep == 0:
+                assert it.last_path == "in_place" and name.startswith("interpn::k_cubic_brick<") and name.endswith("1, 1>"), name
+            elif it.last_path != "sweep":
+                continue  # (a handle without the table the sweep kernel reads)
+            same = (got == want) & (np.signbit(got) == np.signbit(want)) | (np.isnan(got) & np.isnan(want))
+            assert np.all(same), (sweep, name, int((~same).sum()), np.flatnonzero(~same)[:5])
+        assert np.isfinite(want).all() if ratios == "quantized" else np.isfinite(want).sum() > want.size // 2
+    finally:
+        it.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
 @pytest.mark.parametrize("linearize", [False, True], ids=["cubic_extrap", "linearized"])

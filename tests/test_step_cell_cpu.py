@@ -181,3 +181,32 @@ def test_f32_cell_index_from_the_reciprocal():
             assert np.floor(qt) == np.floor(a0 / b), (float(a0).hex(), float(b).hex())
             checked += 1
     assert checked > 50_000
+
+
+# ---- zero numerators (interpn_device.h::fast_numerator admits +0, not -0) ----
+def fma_signed_zero(a, b, c):
+    """fma with IEEE's sign rule for an exact zero sum under round-to-nearest: -0 only if both addends are -0."""
+    exact = Fraction(a) * Fraction(b) + Fraction(c)
+    if exact != 0:
+        return float(exact)
+    prod_negative = (math.copysign(1.0, a) * math.copysign(1.0, b)) < 0
+    if Fraction(a) * Fraction(b) == 0 and Fraction(c) == 0:
+        return -0.0 if (prod_negative and math.copysign(1.0, c) < 0) else 0.0
+    return 0.0  # x + (-x)
+
+
+def test_zero_numerators_of_the_short_division():
+    """The rectilinear multicubic node divides value differences by a positive spacing ratio; equal neighbours give +0.
+    With b > 0 the short form returns +0 = +0 / b; a numerator -0 would come back as +0 (wrong sign), which is why
+    fast_numerator refuses it."""
+    def short(a, b):
+        rb = 1.0 / b
+        q0 = a * rb
+        r0 = fma_signed_zero(-b, q0, a)
+        q1 = fma_signed_zero(r0, rb, q0)
+        r1 = fma_signed_zero(-b, q1, a)
+        return fma_signed_zero(r1, rb, q1)
+
+    for b in (1.5, float.fromhex("0x1p-128"), float.fromhex("0x1.fffffffffffffp127"), 3.0e-7):
+        assert same(short(0.0, b), 0.0 / b)
+        assert not same(short(-0.0, b), -0.0 / b)  # (+0 where the division gives -0)
