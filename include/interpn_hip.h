@@ -78,8 +78,9 @@
  *                                       measured, 1 = no clock)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
- *       INTERPN_HIP_CUBIC_RECORDS=0     rectilinear multicubic (creation only): no per-cell records of the axes; the kernels then do the
- *                                       dimension setup's divisions per point (cubic_cell_record.h)
+ *       INTERPN_HIP_CUBIC_RECORDS=n     rectilinear multicubic (creation only): per-cell records of the axes (cubic_cell_record.h: a
+ *                                       dimension's setup without divisions) while they take at most n KiB (default 40; 0: never —
+ *                                       the kernels then do the setup's divisions per point)
  *       INTERPN_HIP_BIN_SCRAMBLE=1      testing: the sort misplaces every 5th point by one bin (results must not change)
  *       options without an environment variable: "fma" (the handle's flavour), "stage_timing" (interpn_hip_stage_ms),
  *                                       "debug_stamps" + "debug_stamps_bytes" (address and size of a device buffer for the column

@@ -243,17 +243,22 @@ int create_rectilinear(int method, const T* const* grids, const size_t* grid_len
       for (auto& r : recs) r.clear();
     }
   }
-  // Per-cell records of a multicubic handle (interpn_host.h: axis_crec_*; INTERPN_HIP_CUBIC_RECORDS=0: none)
+  // Per-cell records of a multicubic handle (interpn_host.h: axis_crec_*) while they stay L1-sized: the kernels read them
+  // per point through the vector caches (profiles/r05_rect_cubic.txt: 3-D 64^3 f64, 18 KiB: 0.83 -> 0.74 ms per 1e7 points,
+  // 128^3, 36 KiB: 0.84 -> 0.80; 2-D 512^2, 96 KiB: 0.30 -> 0.34, slower than the divisions they replace).
+  // INTERPN_HIP_CUBIC_RECORDS=n: that bound in KiB (default 40; 0: never).
   std::vector<std::vector<CubicCellRecord<T>>> crecs(ngrids);
   g.axis_crec_bytes = 0;
   {
     const char* env = getenv("INTERPN_HIP_CUBIC_RECORDS");
-    bool build = method == kCubic && !(env && atoi(env) == 0);
+    const long cap_kib = env ? atol(env) : 40;
+    bool build = method == kCubic && cap_kib > 0;
     size_t total_bytes = 0;
     for (size_t i = 0; i < ngrids && build; ++i) {
       if (grid_lens[i] < 4) build = false;
       total_bytes += (grid_lens[i] - 1) * sizeof(CubicCellRecord<T>);
     }
+    if (build && total_bytes > (size_t)cap_kib * 1024) build = false;
     if (build && bytes + total_bytes < 0xFFFFFF00ull) {
       for (size_t i = 0; i < ngrids; ++i) {
         build_cubic_cell_records<T>(grids[i], (int)grid_lens[i], crecs[i]);

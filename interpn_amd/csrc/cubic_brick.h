@@ -131,10 +131,10 @@ __device__ __forceinline__ T cubic_node_sel(T v0, T v1, T v2, T v3, const typena
 }
 
 // Gather one (i, j) footprint plane at table offset `delta` for all lanes, reduce dims 0 and 1.
-template <typename T, bool RECT, bool FMA>
+template <typename T, bool RECT, bool FMA, bool FAST = false>
 __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta, T __attribute__((may_alias))* lds_data,
                                           unsigned group, unsigned me, const typename CubicDimSel<T, RECT>::type* dim,
-                                          unsigned interior) {
+                                          unsigned interior, bool* okp = nullptr) {
   T val[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) val[r] = table_load<T>(bricks, toff[r], delta);  // byte offsets
@@ -159,9 +159,12 @@ __device__ __forceinline__ T gather_plane(__amdgpu_buffer_rsrc_t bricks, const u
     if (interior & 2u) return cubic_regular_node_interior<FMA, T>(w[0], w[1], w[2], w[3], dim[1].tt);
     return cubic_regular_node<FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
   } else {
+    bool ok = FAST ? *okp : true;
 #pragma unroll
-    for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_node_sel<RECT, FMA, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0]);
-    return cubic_node_sel<RECT, FMA, T>(w[0], w[1], w[2], w[3], dim[1]);
+    for (int ej = 0; ej < 4; ++ej) w[ej] = cubic_node_sel<RECT, FMA, FAST, T>(v[ej], v[4 + ej], v[8 + ej], v[12 + ej], dim[0], ok);
+    const T r = cubic_node_sel<RECT, FMA, FAST, T>(w[0], w[1], w[2], w[3], dim[1], ok);
+    if constexpr (FAST) *okp = ok;
+    return r;
   }
 }
 
@@ -284,26 +287,30 @@ __device__ __forceinline__ T reduce_planes_dma(__amdgpu_buffer_rsrc_t bricks, co
 }
 
 // Reduce plane dimensions D..2 (D = N-1 outermost): 4 sub-results along dim D, then its node.
-template <typename T, int D, bool RECT, bool FMA, bool DMA>
+// FAST: see cubic_node_sel (`*okp` as in reduce_planes_dma).
+template <typename T, int D, bool RECT, bool FMA, bool DMA, bool FAST = false>
 struct PlaneReduce {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned* plane_stride, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
-                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior, bool* okp = nullptr) {
     T s[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-      s[o] = PlaneReduce<T, D - 1, RECT, FMA, DMA>::run(bricks, toff, delta + (unsigned)o * plane_stride[D] * (unsigned)sizeof(T), plane_stride,
-                                                        lds_data, group, me, dim, interior);
-    return cubic_node_sel<RECT, FMA, T>(s[0], s[1], s[2], s[3], dim[D]);
+      s[o] = PlaneReduce<T, D - 1, RECT, FMA, DMA, FAST>::run(bricks, toff, delta + (unsigned)o * plane_stride[D] * (unsigned)sizeof(T), plane_stride,
+                                                              lds_data, group, me, dim, interior, okp);
+    bool ok = FAST ? *okp : true;
+    const T r = cubic_node_sel<RECT, FMA, FAST, T>(s[0], s[1], s[2], s[3], dim[D], ok);
+    if constexpr (FAST) *okp = ok;
+    return r;
   }
 };
-template <typename T, bool RECT, bool FMA, bool DMA>
-struct PlaneReduce<T, 1, RECT, FMA, DMA> {
+template <typename T, bool RECT, bool FMA, bool DMA, bool FAST>
+struct PlaneReduce<T, 1, RECT, FMA, DMA, FAST> {
   __device__ __forceinline__ static T run(__amdgpu_buffer_rsrc_t bricks, const unsigned* toff, unsigned delta,
                                           const unsigned*, T __attribute__((may_alias))* lds_data, unsigned group, unsigned me,
-                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior) {
+                                          const typename CubicDimSel<T, RECT>::type* dim, unsigned interior, bool* okp = nullptr) {
     static_assert(!DMA, "the LDS-DMA form runs reduce_planes_dma");
-    return gather_plane<T, RECT, FMA>(bricks, toff, delta, lds_data, group, me, dim, interior);
+    return gather_plane<T, RECT, FMA, FAST>(bricks, toff, delta, lds_data, group, me, dim, interior, okp);
   }
 };
 
@@ -351,13 +358,9 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
       if constexpr (RECT) {
         const T x = live ? stream_load(a.obs[d] + i0) : (T)0;
         const Axis<T> ax = make_axis<T, N>(a.ax, axis_base, d);
-        if constexpr (DMA) {
-          xs[d] = x;
-          if (a.crec[0]) loc[d] = cubic_rect_locate_rec<T>(ax, a.crec[d], x, a.linearize, dim[d]);  // (wave-uniform)
-          else loc[d] = cubic_rect_locate<T, true>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);
-        } else {
-          loc[d] = cubic_rect_locate<T>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
-        }
+        xs[d] = x;
+        if (a.crec[0]) loc[d] = cubic_rect_locate_rec<T>(ax, a.crec[d], x, a.linearize, dim[d]);  // (wave-uniform)
+        else loc[d] = cubic_rect_locate<T, true>(ax, x, a.linearize, /*fma_linear=*/false, dim[d]);  // multicubic/rectilinear.rs:366-408
       } else {
         const T x = live ? stream_load(a.obs[d] + i0) : a.start[d];
         T floc;
@@ -419,20 +422,22 @@ __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, 
         if (__builtin_amdgcn_ballot_w64(dim[d].sat != kSatNone || dim[d].linear != 0) == 0) interior |= 1u << d;
     }
     T res;
-    if constexpr (DMA && RECT) {
+    if constexpr (RECT) {
       // the nodes' spacing-ratio divisions first without divide sequences; a wave with a lane whose operands that form
       // does not take (a ratio or a numerator outside its exponent window, a -0) evaluates once more as the reference writes it
       bool fast = true;
 #pragma unroll
       for (int d = 0; d < N; ++d) fast = fast && dim[d].fast;
-      res = reduce_planes_dma<T, N, RECT, FMA, true>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior, &fast);
+      if constexpr (DMA) res = reduce_planes_dma<T, N, RECT, FMA, true>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior, &fast);
+      else res = PlaneReduce<T, N - 1, RECT, FMA, false, true>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior, &fast);
       if (__any(!fast)) {
         if (a.crec[0]) {  // (the records' t and coefficients were the short forms': this wave's again, by division)
 #pragma unroll
           for (int d = 0; d < N; ++d)
             (void)cubic_rect_locate<T>(make_axis<T, N>(a.ax, axis_base, d), xs[d], a.linearize, /*fma_linear=*/false, dim[d]);
         }
-        res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);
+        if constexpr (DMA) res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);
+        else res = PlaneReduce<T, N - 1, RECT, FMA, false>::run(rsrc, toff, 0u, a.plane_stride, lds_data, group, me, dim, interior);
       }
     } else if constexpr (DMA)
       res = reduce_planes_dma<T, N, RECT, FMA>(rsrc, toff, a.plane_stride, lds_wave, lane & 63u, dim, interior);

@@ -2258,7 +2258,7 @@ def _awkward_values(vals, n, dtype, tiny, huge, rng):
 @pytest.mark.parametrize("axis,ratios", [([40, 36], "plain"), ([40, 36], "extreme"), ([40, 36], "quantized"), ([20, 17, 33], "plain"), ([20, 17, 33], "extreme"),
                                          ([20, 17, 33], "quantized"), ([9, 8, 10, 11], "plain"), ([9, 8, 10, 11], "quantized")],
                          ids=["2d", "2d_extreme_ratios", "2d_quantized", "3d", "3d_extreme_ratios", "3d_quantized", "4d", "4d_quantized"])
-@pytest.mark.parametrize("records", ["1", "0"], ids=["cell_records", "no_records"])
+@pytest.mark.parametrize("records", ["64", "0"], ids=["cell_records", "no_records"])
 def test_rectilinear_cubic_short_divisions_on_awkward_values(oracle, monkeypatch, records, axis, ratios, fma, dtype):
     """The rectilinear multicubic node on the fully overlapped tile table takes its two spacing-ratio divisions per node as a
     reciprocal-and-correction sequence where the operands allow it and evaluates the wave again with the divide sequences
