@@ -198,12 +198,12 @@ __device__ __forceinline__ T col_node(T v0, T v1, T v2, T v3, const ColDim<T>& d
   } else if constexpr (FORM == kFormLow) {   // InsideLow / OutsideLow without linearisation: regular.rs:507-527
     const T dy = v0 - v1;
     const T k0 = -((v2 - v0) / two);
-    const T k1 = two * dy - k0;              // == two.mul_add(dy, -k0): 2 dy is exact
+    const T k1 = mul_add<FMA>(two, dy, -k0);  // regular.rs:525-528
     return hermite<FMA>(d.tt, v1, dy, k0, k1);
   } else if constexpr (FORM == kFormHigh) {  // InsideHigh / OutsideHigh without linearisation: regular.rs:563-582
     const T dy = v3 - v2;
     const T k0 = (v3 - v1) / two;
-    const T k1 = two * dy - k0;
+    const T k1 = mul_add<FMA>(two, dy, -k0);
     return hermite<FMA>(d.tt, v2, dy, k0, k1);
   } else {
     return cubic_regular_node<FMA, T>(v0, v1, v2, v3, col_full_dim<T>(d));
@@ -254,12 +254,12 @@ __device__ __forceinline__ HermiteCoef<T> col_node_coef(int form, T v0, T v1, T 
   } else if (form == kFormLow) {   // regular.rs:507-527
     const T dy = v0 - v1;
     const T k0 = -((v2 - v0) / two);
-    const T k1 = two * dy - k0;
+    const T k1 = mul_add<FMA>(two, dy, -k0);
     return hermite_coef<T>(v1, dy, k0, k1);
   } else {                         // regular.rs:563-582
     const T dy = v3 - v2;
     const T k0 = (v3 - v1) / two;
-    const T k1 = two * dy - k0;
+    const T k1 = mul_add<FMA>(two, dy, -k0);
     return hermite_coef<T>(v2, dy, k0, k1);
   }
 }

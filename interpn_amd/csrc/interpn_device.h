@@ -487,6 +487,11 @@ struct CubicDimRegular {
   T tt;        // t (None), -t (Low), t-1 (High)
   int sat;     // Sat
   int linear;  // OutsideLow/OutsideHigh with linearize_extrapolation
+  // the reference's recursive arm writes OutsideLow's k1 as `two * dy - k0` also under its `fma` feature
+  // (regular_recursive.rs:536; every other saturated class, and every class of the flattened arm, is two.mul_add(dy, -k0):
+  // regular.rs:525-528, :546-549, :580-583, :602-605, regular_recursive.rs:516-519, :567-570, :589-592).  2 dy is exact, so the two
+  // forms differ only where 2 dy overflows.  Read by cubic_regular_node<FMA, T, true> alone (the runtime-N kernels).
+  int k1_plain = 0;
 };
 
 // The same node when the saturation class is known to be None (interior cell, no linearized
@@ -553,7 +558,7 @@ __device__ __forceinline__ void cubic_tile_dim0_interior(const T (&v)[16], T t, 
   }
 }
 
-template <bool FMA, typename T>
+template <bool FMA, typename T, bool ARMS = false>
 __device__ __forceinline__ T cubic_regular_node(T v0, T v1, T v2, T v3, const CubicDimRegular<T>& d) {
   const T two = (T)2, one = (T)1;
   const bool low = d.sat == kSatLow;
@@ -565,7 +570,10 @@ __device__ __forceinline__ T cubic_regular_node(T v0, T v1, T v2, T v3, const Cu
   T k0 = cd / two;
   k0 = low ? -k0 : k0;
   T k1n = (v3 - v1) / two;
-  T k1e = two * dy - k0;
+  T k1e = mul_add<FMA>(two, dy, -k0);  // regular.rs:525-528: fused under the `fma` feature (the same bits unless 2 dy overflows)
+  if constexpr (ARMS && FMA) {
+    if (d.k1_plain) k1e = two * dy - k0;
+  }
   T k1 = (low || high) ? k1e : k1n;
   if (d.linear) {
     T y1 = ya;  // vals[0] (low) / vals[3] (high)

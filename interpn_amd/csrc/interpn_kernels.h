@@ -359,7 +359,7 @@ struct GenericArgs {
   unsigned long long stride[kMaxDims];
   int linearize;
   int fma_index;   // linear regular: index_zero_loc fused (flattened arm, N <= 6)
-  int fma_linear;  // cubic rectilinear: linearized branch fused (recursive arm, N >= 5)
+  int fma_linear;  // the reference's recursive arm (N >= 5): cubic rectilinear's linearized branch is fused; cubic regular's OutsideLow k1 is not
 };
 
 // Out-of-line node evaluators for the runtime-N kernel (keeps its code size bounded).
@@ -412,6 +412,7 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
           const T t = (x - iol) / a.step[d];
           dreg[d].sat = sat;
           dreg[d].linear = (outside && a.linearize) ? 1 : 0;
+          dreg[d].k1_plain = (a.fma_linear != 0 && sat == kSatLow && outside) ? 1 : 0;  // recursive arm's OutsideLow (regular_recursive.rs:536)
           dreg[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
         }
       } else {
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(kBlock) k_generic(const GenericArgs<T> a) {
         const T dy = v[1] - y0;
         return mul_add<FMA>(tlin[d], dy, y0);
       } else if constexpr (KIND == kRegular) {
-        return cubic_regular_node<FMA, T>(v[0], v[1], v[2], v[3], dreg[d]);
+        return cubic_regular_node<FMA, T, true>(v[0], v[1], v[2], v[3], dreg[d]);
       } else {
         return cubic_rect_node_ool<FMA, T>(v[0], v[1], v[2], v[3], rc_sat[d], rc_lin[d], a.fma_linear, rc_t[d],
                                            rc_r0[d], rc_a0[d], rc_c0[d], rc_r1[d], rc_a1[d], rc_c1[d]);
@@ -516,6 +517,7 @@ __global__ void __launch_bounds__(kBlock) k_generic_n(const GenericArgs<T> a) {
           const T t = (x - iol) / a.step[d];
           dreg[d].sat = sat;
           dreg[d].linear = (outside && a.linearize) ? 1 : 0;
+          dreg[d].k1_plain = (a.fma_linear != 0 && sat == kSatLow && outside) ? 1 : 0;  // recursive arm's OutsideLow (regular_recursive.rs:536)
           dreg[d].tt = sat == kSatLow ? -t : (sat == kSatHigh ? t - (T)1 : t);
         }
       } else {
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(kBlock) k_generic_n(const GenericArgs<T> a) {
 
     auto node = [&](T v0, T v1, T v2, T v3, int j) -> T {
       if constexpr (METHOD == kLinear) return mul_add<FMA>(tlin[j], v1 - v0, v0);
-      else if constexpr (KIND == kRegular) return cubic_regular_node<FMA, T>(v0, v1, v2, v3, dreg[j]);
+      else if constexpr (KIND == kRegular) return cubic_regular_node<FMA, T, true>(v0, v1, v2, v3, dreg[j]);
       else return cubic_rect_node<FMA, T>(v0, v1, v2, v3, drect[j]);
     };
     T result;

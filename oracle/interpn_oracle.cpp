@@ -126,10 +126,12 @@ inline T centered_difference_nonuniform(T y0, T y1, T y2, T h01, T h12) {
 }
 
 // src/multicubic/regular.rs:474-623 (flattened) and regular_recursive.rs:470-609 (recursive).
-// `two.mul_add(dy, -k0)` and `two * dy - k0` round identically (2*dy is exact), so the
-// recursive arm's non-FMA OutsideLow k1 (regular_recursive.rs:536) needs no switch.
+// `two.mul_add(dy, -k0)` and `two * dy - k0` round identically while 2*dy is finite (the product is exact); where it
+// overflows they do not, so the one place the recursive arm keeps the unfused form under the `fma` feature —
+// OutsideLow, regular_recursive.rs:536 — is followed (`recursive_arm`: N >= 5; every other saturated class of both arms is
+// cfg-switched: regular.rs:525-528, :546-549, :580-583, :602-605, regular_recursive.rs:516-519, :567-570, :589-592).
 template <bool FMA, typename T>
-inline T cubic_regular_inner(const T* vals, T t, Sat sat, bool linearize) {
+inline T cubic_regular_inner(const T* vals, T t, Sat sat, bool linearize, bool recursive_arm) {
   const T one = (T)1, two = (T)2;
   switch (sat) {
     case SatNone: {
@@ -146,7 +148,7 @@ inline T cubic_regular_inner(const T* vals, T t, Sat sat, bool linearize) {
       T y1 = vals[0];
       T dy = vals[0] - vals[1];
       T k0 = -(vals[2] - vals[0]) / two;
-      T k1 = mul_add<FMA>(two, dy, -k0);
+      T k1 = (recursive_arm && sat == OutsideLow) ? two * dy - k0 : mul_add<FMA>(two, dy, -k0);
       if (sat == OutsideLow && linearize) return mul_add<FMA>(k1, tt - one, y1);  // regular.rs:553-561
       return normalized_hermite_spline<FMA>(tt, y0, dy, k0, k1);
     }
@@ -191,7 +193,7 @@ inline T cubic_rectilinear_inner(const T* vals, const T* g, T x, Sat sat, bool l
       T h01 = g[1] - g[0];
       T h12 = g[2] - g[1];
       T k0 = -centered_difference_nonuniform<FMA>(vals[0], vals[1], vals[2], one, h12 / h01);
-      T k1 = two * dy - k0;  // exact product: same bits fused or not
+      T k1 = two * dy - k0;  // rectilinear.rs:471,493,515,532: never fused, with or without the `fma` feature
       T t = -(x - g[1]) / h01;
       if (sat == OutsideLow && linearize) {
         if (FMA && fma_linearize) return std::fma(k1, t - one, y1);
@@ -386,8 +388,9 @@ int cubic_regular(const size_t* dims, size_t ndims, const T* starts, size_t nsta
   Point<T> p;
   fill_dimprod(p, dims, n);
   const bool lin = linearize != 0;
-  auto node = [lin](const T* v, int d, const Point<T>& q) -> T {
-    return cubic_regular_inner<FMA>(v, q.dts[d], q.sat[d], lin);
+  const bool recursive_arm = n > 4;  // regular.rs:52-136: N = 1..4 flattened, above that the recursive arm
+  auto node = [lin, recursive_arm](const T* v, int d, const Point<T>& q) -> T {
+    return cubic_regular_inner<FMA>(v, q.dts[d], q.sat[d], lin, recursive_arm);
   };
   for (size_t k = 0; k < nout; ++k) {
     for (int i = 0; i < n; ++i) {

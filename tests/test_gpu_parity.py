@@ -2238,6 +2238,54 @@ def _step_cell_case(oracle, steps, starts, fma, dtype):
         it.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("fma", [True, False], ids=["fma", "nofma"])
+@pytest.mark.parametrize("axis,layout", [([9, 12], None), ([9, 12], "11"), ([12, 9, 14], None), ([12, 9, 14], "11"), ([12, 9, 14], "24"), ([21, 38, 7, 22], "22"),
+                                         ([8, 9, 7, 10], "11"), ([6, 7, 5, 6, 4], None), ([5, 4, 6, 4, 5, 4], None)], ids=str)
+def test_regular_cubic_boundary_slope_where_two_dy_overflows(oracle, monkeypatch, axis, layout, fma, dtype):
+    """The saturated classes' second slope is `two.mul_add(dy, -k0)` under the reference's `fma` feature and `two * dy - k0`
+    without it (multicubic/regular.rs:525-528, :546-549, :580-583, :602-605; the recursive arm, N >= 5, the same except
+    OutsideLow, which stays unfused: regular_recursive.rs:536).  The product is exact, so the forms agree until 2 dy overflows:
+    grid values near the top of the type's range and points far outside the grid (cubic extrapolation) reach that, and the
+    kernels must then return the infinities and NaNs the reference's form gives.  Every regular multicubic kernel family: the
+    C-order kernels, the tiled ones, the binned / column evaluation, the sweep kernel, the runtime-N kernels of both arms."""
+    import torch
+
+    import interpn_amd
+
+    if layout:
+        monkeypatch.setenv("INTERPN_HIP_BRICKS", layout)
+    dev = torch.device("cuda:0")
+    n = len(axis)
+    nobs = 30_011 if n <= 4 else 4_001
+    case = synthetic_case("cubic", "regular", n, axis, nobs, 600 + sum(axis), dtype, linearize=False, extrap=2.0, specials=n <= 4 and min(axis) >= 8)
+    rng = np.random.default_rng(9 + n)
+    v = case.vals.astype(np.float64)
+    k = int(rng.integers(0, v.size // 2))
+    v[k:k + v.size // 3] *= 1e307 if dtype == np.float64 else 1e37
+    with np.errstate(all="ignore"):
+        case.vals = v.astype(dtype)
+        want = run_oracle(oracle, case, fma)
+    assert np.isinf(want).sum() + np.isnan(want).sum() > 0 and np.isfinite(want).sum() > 0
+    it = interpn_amd.Interpolator.regular("cubic", case.dims, case.starts, case.steps, case.vals, linearize_extrapolation=False, fma=fma)
+    try:
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        modes = [("binned", 0), ("binned", 1)] if (layout and n <= 4) else [("binned", 0)]
+        if n in (2, 3) and layout == "11":
+            modes.append(("sweep", 1))
+        for opt, val in modes:
+            it.set_option("binned", 0)
+            it.set_option("sweep", 0)
+            it.set_option(opt, val)
+            got = it.eval_tensors(obs).cpu().numpy()
+            name = it.kernel_name()
+            it.finish()
+            same = (got == want) | (np.isnan(got) & np.isnan(want))
+            assert np.all(same), (opt, val, name, int((~same).sum()), [(float(got[i]), float(want[i])) for i in np.flatnonzero(~same)[:3]])
+    finally:
+        it.close()
+
+
 def _awkward_values(vals, n, dtype, tiny, huge, rng):
     sl = lambda lo, hi: tuple(slice(lo, hi) for _ in range(n))
     vals[sl(0, 4)] = dtype(0.375)                       # equal neighbours

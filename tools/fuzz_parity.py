@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD", "INTERPN_HIP_CUBIC_RECORDS")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -135,6 +135,15 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 env["INTERPN_HIP_SWEEP_PERIOD"] = str(int(rng.choice([0, 0, 1, 300, 2500])))
                 env.pop("INTERPN_HIP_FORCE_GENERIC", None)
             if kind == "rectilinear" and rng.random() < 0.3: env["INTERPN_HIP_AXIS_RECORDS"] = "0"
+            # round 5, last session: rectilinear multicubic with / without the per-cell records of the axes (or a bound they
+            # exceed), and 2-D / 3-D multicubic through the sweep kernel
+            if method == "cubic" and kind == "rectilinear" and rng.random() < 0.4: env["INTERPN_HIP_CUBIC_RECORDS"] = str(int(rng.choice([0, 0, 1, 64])))
+            if method == "cubic" and N in (2, 3) and rng.random() < 0.3:
+                env["INTERPN_HIP_SWEEP"] = "1"
+                env["INTERPN_HIP_SWEEP_PERIOD"] = str(int(rng.choice([0, 1, 1500])))
+                env["INTERPN_HIP_BRICKS"] = "11"
+                env.pop("INTERPN_HIP_FORCE_GENERIC", None)
+                env.pop("INTERPN_HIP_BINNED", None)
             # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
             if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
             for k in KNOBS:
@@ -142,6 +151,23 @@ def run(budget: float, seed: int, max_cases: int = 0):
             os.environ.update(env)
             case = synthetic_case(method, kind, N, axis, nobs, int(rng.integers(0, 2**31)), dtype, linearize=linearize,
                                   extrap=extrap, specials=bool(rng.integers(0, 2)))
+            if method == "cubic" and rng.random() < 0.3:
+                # grid values the rectilinear node's short divisions must hand back: a lattice (differences that are exactly +0),
+                # blocks of tiny / huge magnitude, zeros of both signs
+                v = case.vals.astype(np.float64)
+                mode = int(rng.integers(0, 3))
+                if mode == 0:
+                    v = np.round(v * 4) / 4 + 0.0
+                elif mode == 1:
+                    k = int(rng.integers(0, v.size))
+                    v[k:k + v.size // 7 + 1] *= (1e-300 if dtype == np.float64 else 1e-36) if rng.random() < 0.5 else (1e200 if dtype == np.float64 else 1e30)
+                else:
+                    k = int(rng.integers(0, v.size))
+                    z = np.zeros(min(v.size - k, v.size // 5 + 1))
+                    z[rng.random(z.size) < 0.5] = -0.0
+                    v[k:k + z.size] = z
+                with np.errstate(all="ignore"):
+                    case.vals = v.astype(dtype)
             if kind == "rectilinear" and rng.random() < 0.3:
                 # inject NaN / inf / huge coordinates: rectilinear never errors, results must still match
                 for _ in range(3):
@@ -189,6 +215,10 @@ def run(budget: float, seed: int, max_cases: int = 0):
             if not same:
                 n_fail += 1
                 nbad = int(np.sum(~((got == want) | (np.isnan(got) & np.isnan(want)))))
+                if os.environ.get("FUZZ_DUMP"):
+                    ib = np.flatnonzero(~((got == want) | (np.isnan(got) & np.isnan(want))))[:4]
+                    print("   DUMP vals abs min/max", float(np.nanmin(np.abs(case.vals))), float(np.nanmax(np.abs(case.vals))), "zeros", int((case.vals == 0).sum()),
+                          "bad:", [(int(i), float(got[i]), float(want[i]), [float(o[i]) for o in case.obs]) for i in ib], flush=True)
                 print(f"FAIL method={method} kind={kind} N={N} axis={axis} nobs={nobs} dtype={np.dtype(dtype).name} "
                       f"linearize={linearize} fma={fma} device_path={device_path} extrap={extrap} env={env} nbad={nbad} err_oracle={err_o!r} err_hip={err_g!r}", flush=True)
     finally:
