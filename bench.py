@@ -267,6 +267,29 @@ L2_HIT_LINES_PER_S = 2.7e11  # 128 channels x 1 line per clock (DESIGN.md sectio
 L2_MISS_LINES_PER_S = 5.5e10  # random 128-B lines from the Infinity Cache / HBM (tools/tune_sector)
 
 
+def configs_summary(rows):
+    """Per configuration: kernel ms, roofline fraction, bitwise check against the oracle, fabric traffic over algorithmic."""
+    out = []
+    for r in rows:
+        if "error" in r:
+            out.append({"error": r["error"]})
+            continue
+        name = str(r.get("config", r.get("name", "")))
+        e = {"cfg": name.split(" ")[0] + (" lin" if "linearize_extrapolation=true" in name else ""),
+             "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"),
+             "bitwise_equal": (r.get("oracle_check") or {}).get("bitwise_equal")}
+        t = r.get("traffic") or {}
+        if t.get("ratio_to_algorithmic") is not None:
+            e["traffic_ratio"] = t.get("ratio_to_algorithmic")
+        if t.get("fabric_requests_per_point") is not None:
+            e["fabric_requests_per_point"] = t.get("fabric_requests_per_point")
+        st = (r.get("binned") or {}).get("stage_ms")
+        if st:
+            e["stage_ms"] = st
+        out.append(e)
+    return out
+
+
 def cubic4_bound(row, P, kernel_stage_ms, unsorted_ms, spec):
     """What bounds cfg4 ('cfg4 is not HBM-bound by construction ... report additionally
     L2/MALL gather GB/s and FP64-VALU utilization so the number is interpretable')."""
@@ -670,6 +693,35 @@ def sharding_text(world, bcast):
 
 
 # ---------------------------------------------------------------------------------------------
+def device_identity(torch):
+    """(current device index, PCI domain, bus, device) of this rank's GPU; -1 where the runtime does not say."""
+    idx = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(idx)
+    return [idx, int(getattr(props, "pci_domain_id", -1)), int(getattr(props, "pci_bus_id", -1)),
+            int(getattr(props, "pci_device_id", -1))]
+
+
+def gather_devices(torch, dist, rank, world, coll_dev, ident=None):
+    """One all-gather of every rank's (rank, device index, PCI domain, bus, device); `dist` None: a single process."""
+    mine = [rank] + (ident if ident is not None else device_identity(torch))
+    if dist is None or world == 1:
+        rows = [mine]
+    else:
+        got = [torch.zeros(5, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(got, torch.tensor(mine, dtype=torch.int64, device=coll_dev))
+        rows = [[int(v) for v in g.tolist()] for g in got]
+    return [{"rank": r[0], "cuda_device": r[1], "pci": "%04x:%02x:%02x" % (r[2], r[3], r[4]) if min(r[2:]) >= 0 else None}
+            for r in rows]
+
+
+def check_distinct_devices(devices, world):
+    """A world of N ranks must sit on N distinct GPUs: by PCI address where every rank has one, else by device index."""
+    keys = [d["pci"] for d in devices] if all(d["pci"] for d in devices) else [d["cuda_device"] for d in devices]
+    if len(set(keys)) != world:
+        raise SystemExit(f"bench.py: {world} ranks on {len(set(keys))} distinct device(s) {sorted(set(map(str, keys)))}: "
+                         "not a multi-GPU measurement (pass --same-device to share one GPU on purpose)")
+
+
 def dry_run(args):
     """Spawn / rendezvous check without a GPU: what the launcher contract gives every rank."""
     import torch
@@ -679,18 +731,27 @@ def dry_run(args):
     rank = int(os.environ.get("RANK", "0"))
     if os.environ.get("INTERPN_BENCH_DRY_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    # no GPU here: the identity a rank would report is made up from LOCAL_RANK (INTERPN_BENCH_DRY_SAME_PCI: every rank
+    # claims the same GPU, the case the real run must refuse)
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    ident = [0, 0, 7, 0] if os.environ.get("INTERPN_BENCH_DRY_SAME_PCI") else [lr, 0, 0x10 + lr, 0]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         world = dist.get_world_size()
         got = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(got, torch.tensor([rank, int(os.environ.get("LOCAL_RANK", "-1"))], dtype=torch.int64))
+        devices = gather_devices(torch, dist, rank, world, torch.device("cpu"), ident=ident)
         dist.barrier()
         ranks = [[int(x[0]), int(x[1])] for x in got]
         dist.destroy_process_group()
     else:
-        ranks = [[0, int(os.environ.get("LOCAL_RANK", "0"))]]
+        ranks = [[0, lr]]
+        devices = gather_devices(torch, None, rank, world, torch.device("cpu"), ident=ident)
     if rank == 0:
+        if not args.same_device:
+            check_distinct_devices(devices, world)
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks, "steps": args.steps,
+                          "config": {"devices": devices},
                           "spawned": bool(os.environ.get("INTERPN_BENCH_SPAWNED"))}), flush=True)
 
 
@@ -728,6 +789,12 @@ def worker(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         world = dist.get_world_size()  # what the process group actually is
     coll_dev = dev if (use_dist and dist.get_backend() == "nccl") else torch.device("cpu")
+    # Which physical device did every rank land on?  (rank, torch's current device, PCI domain / bus / device as the
+    # HIP runtime reports them for that device) from every rank; rank 0 refuses to report a multi-GPU figure measured on
+    # fewer distinct devices than ranks (unless --same-device asked for exactly that).
+    devices = gather_devices(torch, dist if use_dist else None, rank, world, coll_dev)
+    if rank == 0 and not args.same_device:
+        check_distinct_devices(devices, world)
 
     P = args.points
     NDIMS = 3
@@ -896,6 +963,7 @@ def worker(args):
                 "process_group": {"initialised": True, "backend": dist.get_backend(), "world_size": dist.get_world_size()}
                                  if use_dist else {"initialised": False},
                 "grid_broadcast": m["broadcast"],
+                "devices": devices,
                 "barrier_ms_before_timed_region": round(m["barrier_ms"], 3),
                 "launched_by": "bench.py spawn" if os.environ.get("INTERPN_BENCH_SPAWNED") else
                                ("external launcher" if world > 1 else "single process"),
@@ -992,6 +1060,8 @@ def worker(args):
                 except Exception as e:
                     rows.append({"error": repr(e)})
                 rec["configs"] = rows
+                # the same rows in short inside a key every parser of this line keeps
+                rec["roofline"]["configs_summary"] = configs_summary(rows)
                 try:
                     rec["host_path"] = host_path_block(interpn_amd, local_rank)
                 except Exception as e:

@@ -307,7 +307,8 @@ enum {
   INTERPN_HIP_WHY_SMALL_OR_OFF = 1,  /* batch below the break-even size, or option "binned" = 0 */
   INTERPN_HIP_WHY_CAPTURE = 2,       /* `stream` is being captured into a graph */
   INTERPN_HIP_WHY_NO_SCRATCH = 3,    /* no reserved scratch block is free / large enough and allocation was not allowed */
-  INTERPN_HIP_WHY_ALLOC_FAILED = 4   /* the scratch allocation failed */
+  INTERPN_HIP_WHY_ALLOC_FAILED = 4,  /* the scratch allocation failed */
+  INTERPN_HIP_WHY_MISALIGNED = 5     /* sweep evaluation only: `out` or a coordinate array is not 16-byte aligned (its streams are 16-byte accesses) */
 };
 int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, size_t nobs, void* out,
                                size_t npoints, void* stream, unsigned flags, int* path_taken, int* why);

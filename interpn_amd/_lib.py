@@ -29,7 +29,8 @@ FLAVOUR_FMA, FLAVOUR_NO_FMA = 0x100, 0x200  # OR-ed into `method` of interpn_hip
 PATH_IN_PLACE, PATH_BINNED, PATH_SWEEP = 0, 1, 2
 EVAL_NO_ALLOC = 1
 WHY = {0: "", 1: "batch below the break-even size or option binned = 0", 2: "stream under graph capture",
-       3: "no reserved scratch block free and allocation not allowed", 4: "scratch allocation failed"}
+       3: "no reserved scratch block free and allocation not allowed", 4: "scratch allocation failed",
+       5: "out or a coordinate array is not 16-byte aligned (sweep evaluation)"}
 
 _lib = None
 

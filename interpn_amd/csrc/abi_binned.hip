@@ -111,12 +111,14 @@ interpn_hip_interp::BinSlot* take_bin_slot(interpn_hip_interp* h, size_t need, h
       if (!ok) {
         if (freed) { pick->scratch = nullptr; pick->bytes = 0; pick->recorded = false; }  // else the old block stays as it was
         pick->totals_clean = false;
+        pick->sweep_clean = false;
         *why = INTERPN_HIP_WHY_ALLOC_FAILED;
         return nullptr;
       }
       pick->scratch = fresh;
       pick->bytes = need;
       pick->totals_clean = false;
+        pick->sweep_clean = false;
       pick->recorded = false;
       h->scratch_allocs.fetch_add(1);
     }
@@ -234,6 +236,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       BinExtras extras3;
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras3, (unsigned)q3, stage, slot->totals_clean);
       slot->totals_clean = err == hipSuccess;
+      slot->sweep_clean = false;
       if (err != hipSuccess) break;
       if (g.dtype == kF64)
         err = launch_cubic3_column<double>(*use, plan, extras3, index, reinterpret_cast<double*>(dst), count, max_parts3, h->first_bad, begin, stream);
@@ -257,6 +260,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
       }
       err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, &extras, (unsigned)q, stage, slot->totals_clean);
       slot->totals_clean = err == hipSuccess;
+      slot->sweep_clean = false;
       if (err != hipSuccess) break;
       if (g.dtype == kF64)
         err = launch_cubic_column<double>(*use, plan, extras, index, reinterpret_cast<double*>(dst), count, max_parts, h->first_bad, begin, stream);
@@ -266,6 +270,7 @@ int eval_device_binned(interpn_hip_interp* h, const void* const* obs, void* out,
     }
     err = bin_points(g, plan, src, count, slot->scratch, sorted, &index, stream, nullptr, 0, stage, slot->totals_clean);
     slot->totals_clean = err == hipSuccess;
+      slot->sweep_clean = false;
     if (err != hipSuccess) break;
     if (g.dtype == kF64)
       err = launch_cubic_brick<double>(*use, reinterpret_cast<const double* const*>(sorted), reinterpret_cast<double*>(dst), count,
@@ -331,7 +336,9 @@ int interpn_hip_eval_device_ex(interpn_hip_interp* h, const void* const* obs, si
   if (st < 0 && sweep_applies(h->desc, npoints)) {  // 3-D f64 multilinear: the sweep kernel for large batches (linear_sweep.h)
     int why_sweep = INTERPN_HIP_WHY_NONE;
     const int ss = eval_device_sweep(h, obs, out, npoints, static_cast<hipStream_t>(stream), flags, &why_sweep);
-    if (why_out) *why_out = why_sweep;
+    // the sweep's reason replaces the sorted path's only where that path had none, or where the sweep's is one of the
+    // specific ones (capture, no scratch, allocation failed, misaligned arrays)
+    if (why_out && (why == INTERPN_HIP_WHY_NONE || why_sweep > INTERPN_HIP_WHY_SMALL_OR_OFF)) *why_out = why_sweep;
     if (ss > 0) {
       std::lock_guard<std::mutex> lk(h->marks_mu);
       h->sync_device_at_destroy = true;
@@ -407,6 +414,7 @@ int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {
     sl.scratch = nullptr;
     sl.bytes = 0;
     sl.totals_clean = false;
+    sl.sweep_clean = false;
     sl.recorded = false;
     hipError_t e = pool_alloc(h->device, &sl.scratch, need);
     if (e != hipSuccess) { (void)hipGetLastError(); sl.scratch = nullptr; return INTERPN_HIP_ERR_OUT_OF_MEMORY; }

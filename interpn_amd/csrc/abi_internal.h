@@ -149,6 +149,10 @@ struct interpn_hip_interp {
     hipStream_t last_stream = nullptr;
     unsigned long long stamp = 0;  // use counter value of the last use (LRU)
     bool totals_clean = false;     // the block's bin counters are zero (left so by the last complete sort's scan)
+    // the block's first sweep_work_bytes() are a SweepWork a complete sweep launch left behind (round counters zero, the
+    // measured period kept for the next launch).  The two invariants exclude each other: the period word lies inside the
+    // sort's histogram (totals[291]), so whichever path uses a block clears the other path's flag.
+    bool sweep_clean = false;
     hipEvent_t stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // option stage_timing: start | hist | scan | scatter | kernel
     bool staged = false;           // the last use recorded them (single slice)
   };

@@ -277,9 +277,14 @@ int maybe_build_bricks(interpn_hip_interp* h) {
       t.brick_step[1] = wj;
       for (int k = 0; k < 3; ++k) t.brick_nb[k] = nbs[k];
       t.brick_nb[3] = 0;
-      HIP_TRY(build_bricks(t, h->sweep_owned, nullptr));
-      HIP_TRY(hipStreamSynchronize(nullptr));
-      g.sweep_bricks = h->sweep_owned;
+      // the second table is optional: a failure to build it leaves the handle on its brick kernel
+      if (build_bricks(t, h->sweep_owned, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess) {
+        g.sweep_bricks = h->sweep_owned;
+      } else {
+        (void)hipGetLastError();
+        pool_free(h->device, h->sweep_owned);
+        h->sweep_owned = nullptr;
+      }
     } else {
       (void)hipGetLastError();
       h->sweep_owned = nullptr;

@@ -157,6 +157,19 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
   if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_sweep")) { *value = h->evals_sweep.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "sweep_table_bytes")) { *value = h->desc.sweep_bricks ? (long long)h->desc.sweep_table_bytes : 0; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "sweep_cell")) { *value = h->desc.sweep_bricks ? h->desc.sweep_cell : 0; return INTERPN_HIP_OK; }  // 0: 2 x 2 x KW bricks, 2: 2 x 4 x 4 (f32)
+  if (!strcmp(name, "dev_pci")) {  // read-only: (domain << 16) | (bus << 8) | device of the GPU the handle lives on; -1 if unknown
+    int dom = 0, bus = 0, dv = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->device) != hipSuccess ||
+        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->device) != hipSuccess ||
+        hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, h->device) != hipSuccess) {
+      (void)hipGetLastError();
+      *value = -1;
+    } else {
+      *value = ((long long)dom << 16) | ((long long)(bus & 0xFF) << 8) | (long long)(dv & 0xFF);
+    }
+    return INTERPN_HIP_OK;
+  }
   if (!strcmp(name, "sweep_layout")) { *value = h->desc.sweep_bricks ? h->desc.sweep_step[0] * 10 + h->desc.sweep_step[1] : 0; return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_allocs")) { *value = h->scratch_allocs.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "scratch_bytes")) {

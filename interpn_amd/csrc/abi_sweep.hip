@@ -21,18 +21,21 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
   *why = INTERPN_HIP_WHY_NONE;
   const int applies = sweep_applies(g, npoints);
   if (applies < 2) { *why = applies ? INTERPN_HIP_WHY_SMALL_OR_OFF : INTERPN_HIP_WHY_NONE; return -1; }
-  if (reinterpret_cast<uintptr_t>(out) % 16) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
+  if (reinterpret_cast<uintptr_t>(out) % 16) { *why = INTERPN_HIP_WHY_MISALIGNED; return -1; }
   for (int d = 0; d < g.ndims; ++d)
-    if (reinterpret_cast<uintptr_t>(obs[d]) % 16) { *why = INTERPN_HIP_WHY_SMALL_OR_OFF; return -1; }
+    if (reinterpret_cast<uintptr_t>(obs[d]) % 16) { *why = INTERPN_HIP_WHY_MISALIGNED; return -1; }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
   if (cs != hipStreamCaptureStatusNone) { *why = INTERPN_HIP_WHY_CAPTURE; return -1; }
   interpn_hip_interp::BinSlot* slot = take_bin_slot(h, sweep_work_bytes(), stream, !(flags & INTERPN_HIP_EVAL_NO_ALLOC), why);
   if (!slot) return -1;
   hipError_t err = hipSuccess;
-  if (!slot->totals_clean) err = hipMemsetAsync(slot->scratch, 0, sweep_work_bytes(), stream);  // first use of the block; the kernel leaves the words zero
+  // first use of the block by this path, or the sorted path has used it since: reset the work words (a complete launch leaves
+  // its counters zero and its measured period in place; that period word is one of the sort's bin counters)
+  if (!slot->sweep_clean) err = hipMemsetAsync(slot->scratch, 0, sweep_work_bytes(), stream);
   if (err == hipSuccess) err = launch_linear_sweep(g, obs, out, npoints, h->first_bad, slot->scratch, stream);
-  slot->totals_clean = err == hipSuccess;
+  slot->sweep_clean = err == hipSuccess;
+  slot->totals_clean = false;
   {
     std::lock_guard<std::mutex> lk(h->bin_mu);
     if (hipEventRecord(slot->event, stream) == hipSuccess) {

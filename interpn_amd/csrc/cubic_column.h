@@ -100,6 +100,11 @@ struct CubicColumnArgs {
   // (k_bin_points.hip::column_key; regular grids, slices of at most 2^24 points): the local sort's
   // first pass reads those 4 bytes per point instead of the 32-byte records
   int index_keys;
+#ifdef INTERPN_COLUMN_CREC_VARIANT
+  // Regression build only (tools/libinterpn_colvariant.so, profiles/NOTES.md section H): the argument and the
+  // never-taken branch that made round 5's compiler mis-structure the node's three class arms (see cubic_rect_node).
+  const CubicCellRecord<T>* crec[4];
+#endif
 };
 
 constexpr int kColPerThread = 32;  // points of a part per thread of its group at most (the local sort's key registers)
@@ -884,6 +889,10 @@ k_cubic_column(const CubicColumnArgs<T> a) {
           int loc[4];
 #pragma unroll
           for (int d = 0; d < 4; ++d)  // multicubic/rectilinear.rs:366-408 (never fails: NaN takes cell 0 and propagates)
+#ifdef INTERPN_COLUMN_CREC_VARIANT
+            if (a.crec[0]) loc[d] = cubic_rect_locate_rec<T>(make_axis<T, 4>(a.ax, axis_base, d), a.crec[d], rcur[d], a.linearize, dim[d]);
+            else
+#endif
             loc[d] = cubic_rect_locate<T>(make_axis<T, 4>(a.ax, axis_base, d), rcur[d], a.linearize, /*fma_linear=*/false, dim[d]);
           const int rel2 = loc[2] - (int)row0;
           const bool in_rows = rel2 >= 0 && rel2 <= row_top;

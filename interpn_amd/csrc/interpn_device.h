@@ -605,14 +605,23 @@ struct CubicDimRect {
   bool fast;
 };
 
+// Control flow of the class arms (here and in the two node functions below): ONE two-way branch — interior or saturated —
+// with the saturated classes Low and High told apart by selects on the operands of a single body.  Written as three
+// arms (`if None ... else if Low ... else High`) the chain becomes a switch on `sat` whose default arm is reachable from
+// both halves of the lowered decision tree, and ROCm 7.2's StructurizeCFG (amdclang 22: the pass hoists zero-cost
+// incoming values of such an arm's phis and then routes one of its two entries past them) gave the High lanes that
+// enter from the `sat >= 1` side the LOW arm's y0 and an undefined y1 in one build of the 4-D column kernel
+// (profiles/NOTES.md section H; found because every High-class point of dim 1 was wrong, round 5).  Every operation a
+// lane's result depends on is the reference's for that lane's class, on the same operands, in the same order.
 template <typename T, bool RECIP = false, typename GridPtr>
 __device__ __forceinline__ void cubic_rect_dim_setup(GridPtr g, int loc, T x, CubicDimRect<T>& d) {
   const T one = (T)1;
   T g0 = g[loc], g1 = g[loc + 1], g2 = g[loc + 2], g3 = g[loc + 3];
   d.r1 = one; d.a1 = one; d.c1 = one;
   d.rr0 = one; d.rr1 = one; d.fast = false;
+  const T h12 = g2 - g1;
   if (d.sat == kSatNone) {
-    T h01 = g1 - g0, h12 = g2 - g1, h23 = g3 - g2;
+    T h01 = g1 - g0, h23 = g3 - g2;
     d.r0 = h01 / h12;  // (hA, hB) = (r0, 1)
     d.a0 = d.r0 / (d.r0 + one);
     d.c0 = one / (one + d.r0);
@@ -620,18 +629,17 @@ __device__ __forceinline__ void cubic_rect_dim_setup(GridPtr g, int loc, T x, Cu
     d.a1 = one / (one + d.r1);
     d.c1 = d.r1 / (d.r1 + one);
     d.t = (x - g1) / h12;
-  } else if (d.sat == kSatLow) {
-    T h01 = g1 - g0, h12 = g2 - g1;
-    d.r0 = h12 / h01;  // (hA, hB) = (1, r0)
-    d.a0 = one / (one + d.r0);
-    d.c0 = d.r0 / (d.r0 + one);
-    d.t = -(x - g1) / h01;
   } else {
-    T h12 = g2 - g1, h23 = g3 - g2;
-    d.r0 = h12 / h23;  // (hA, hB) = (r0, 1)
-    d.a0 = d.r0 / (d.r0 + one);
-    d.c0 = one / (one + d.r0);
-    d.t = (x - g2) / h23;
+    // Low : r0 = h12 / h01, (hA, hB) = (1, r0): a0 = 1 / (1 + r0), c0 = r0 / (r0 + 1), t = -(x - g1) / h01
+    // High: r0 = h12 / h23, (hA, hB) = (r0, 1): a0 = r0 / (r0 + 1), c0 = 1 / (1 + r0), t = (x - g2) / h23
+    const bool low = d.sat == kSatLow;
+    const T ho = low ? g1 - g0 : g3 - g2;
+    d.r0 = h12 / ho;
+    const T wr = d.r0 / (d.r0 + one), w1 = one / (one + d.r0);
+    d.a0 = low ? w1 : wr;
+    d.c0 = low ? wr : w1;
+    const T num = x - (low ? g1 : g2);
+    d.t = (low ? -num : num) / ho;
   }
   if constexpr (RECIP) {
     d.rr0 = one / d.r0;
@@ -667,6 +675,31 @@ __device__ __forceinline__ T cd_unit_a(T y0, T y1, T y2, T r, T a, T c) {
   }
 }
 
+// The saturated classes' first slope and Hermite operands (the select form of the note above cubic_rect_dim_setup):
+//   Low : y0 = v1, y1 = v0, dy = v0 - v1, k0 = -cd_unit_a(v0, v1, v2): b = (v2 - v1) / r0, dd = v1 - v0
+//   High: y0 = v2, y1 = v3, dy = v3 - v2, k0 =  cd_unit_b(v1, v2, v3): b = v3 - v2, dd = (v2 - v1) / r0
+// — the one real division has the same operands in both.
+template <bool FMA, typename T>
+__device__ __forceinline__ void cubic_rect_saturated(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d, T& y0, T& y1, T& dy, T& k0) {
+  const bool low = d.sat == kSatLow;
+  const T q = (v2 - v1) / d.r0;
+  const T up = v3 - v2, dn = v1 - v0;
+  const T b = low ? q : up;
+  const T dd = low ? dn : q;
+  T k;
+  if constexpr (FMA) {
+    k = dev_fma<T>(d.a0, b, d.c0 * dd);
+  } else {
+    T ab = d.a0 * b;
+    T cdd = d.c0 * dd;
+    k = ab + cdd;
+  }
+  k0 = low ? -k : k;
+  y0 = low ? v1 : v2;
+  y1 = low ? v0 : v3;
+  dy = low ? v0 - v1 : up;
+}
+
 template <bool FMA, typename T>
 __device__ __forceinline__ T cubic_rect_node(T v0, T v1, T v2, T v3, const CubicDimRect<T>& d) {
   const T two = (T)2, one = (T)1;
@@ -678,13 +711,7 @@ __device__ __forceinline__ T cubic_rect_node(T v0, T v1, T v2, T v3, const Cubic
     return hermite<FMA>(d.t, y0, dy, k0, k1);
   }
   T y0, y1, dy, k0;
-  if (d.sat == kSatLow) {
-    y0 = v1; y1 = v0; dy = v0 - v1;
-    k0 = -cd_unit_a<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
-  } else {
-    y0 = v2; y1 = v3; dy = v3 - v2;
-    k0 = cd_unit_b<FMA>(v1, v2, v3, d.r0, d.a0, d.c0);
-  }
+  cubic_rect_saturated<FMA, T>(v0, v1, v2, v3, d, y0, y1, dy, k0);
   T k1 = two * dy - k0;
   if (d.linear) {
     if (FMA && d.fma_linear) return dev_fma<T>(k1, d.t - one, y1);
@@ -746,14 +773,8 @@ __device__ __forceinline__ HermiteCoef<T> cubic_rect_node_coef(T v0, T v1, T v2,
     T k1 = cd_unit_a<FMA>(v1, v2, v3, d.r1, d.a1, d.c1);
     return hermite_coef<T>(v1, dy, k0, k1);
   }
-  T y0, dy, k0;
-  if (d.sat == kSatLow) {
-    y0 = v1; dy = v0 - v1;
-    k0 = -cd_unit_a<FMA>(v0, v1, v2, d.r0, d.a0, d.c0);
-  } else {
-    y0 = v2; dy = v3 - v2;
-    k0 = cd_unit_b<FMA>(v1, v2, v3, d.r0, d.a0, d.c0);
-  }
+  T y0, y1, dy, k0;
+  cubic_rect_saturated<FMA, T>(v0, v1, v2, v3, d, y0, y1, dy, k0);
   T k1 = two * dy - k0;
   return hermite_coef<T>(y0, dy, k0, k1);
 }

@@ -202,6 +202,9 @@ hipError_t launch_cubic_column(const GridDesc& g, const BinPlan& plan, const Bin
   a.pitch = cp.pitch;
   a.index_keys = extras.key_q3 > 0 ? 1 : 0;
   a.perm_pad = cp.perm_pad;
+#ifdef INTERPN_COLUMN_CREC_VARIANT
+  for (int d = 0; d < 4; ++d) a.crec[d] = nullptr;
+#endif
   if (g.kind == kRectilinear) {
     fill_axis_args<T, 4>(g, a.ax);  // offsets, lengths, bucket tables; the kernel stages the image itself
     a.ax.use_rec = 0;

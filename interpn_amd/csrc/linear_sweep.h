@@ -82,6 +82,7 @@ struct SweepLds {
   static constexpr unsigned kWorkgroup = 16;  // behind the waves' regions: ticks | rounds | waves done | -
   static_assert(kRow + kPark >= 64u * (K + KL) * sizeof(T), "the result exchange spans the row buffer and the parked rows' bytes");
   static_assert(64u * 4u * 2u <= kOff, "the sort's counters live in the piece offsets' bytes");
+  static_assert(64u * (K + KL) * 2u <= kRow, "the 16-bit source-index exchange of a round stays inside the row buffer (the parked coordinates sit right behind it)");
 };
 
 // RECT: rectilinear grids, the cell search exactly as in the brick kernel — axes of at most 64

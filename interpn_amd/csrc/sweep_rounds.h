@@ -52,6 +52,7 @@ struct SweepRoundsLds {
   static constexpr unsigned kWave = kRow + kPark + kCnt;
   static constexpr unsigned kWorkgroup = 16;
   static_assert(kRow + kPark >= 64u * (K + KL) * sizeof(T), "the result exchange spans the row buffer and the parked rows' bytes");
+  static_assert(64u * (K + KL) * 2u <= kRow, "the 16-bit source-index exchange of a round stays inside the row buffer (the parked coordinates sit right behind it)");
 };
 
 // Call with the whole workgroup, once, after whatever the kernel stages into LDS behind the waves' regions (the barrier in here

@@ -125,14 +125,29 @@ class Interpolator:
 
     def table_layout(self):
         """(bytes, step_i, step_j) of the re-laid grid copy the kernels read; (0, 0, 0) = C order.
-        After an evaluation that took the sweep kernel: that kernel's table (a handle may keep two
-        brick tables, e.g. 64^3 f64: (1,2) for the brick kernel, (1,1) for the sweep)."""
+        After an evaluation that took the 3-D multilinear sweep kernel (`k_linear_sweep<`): that kernel's table (a handle
+        may keep two brick tables, e.g. 64^3 f64: (1,2) for the brick kernel, (1,1) for the sweep).  The steps alone do
+        not tell the f64 2 x 2 x KW bricks from the f32 2 x 4 x 4 ones (both report (1, 1)): `sweep_brick_form()` does.
+        The 2-D, nearest-neighbour and multicubic sweep kernels read the handle's one table (brick / C order / tile):
+        for them this returns that table, as for the one-pass kernels."""
         if self.kernel_name().startswith("interpn::k_linear_sweep<"):
             lay = self.get_option("sweep_layout")
             return self.get_option("sweep_table_bytes"), lay // 10, lay % 10
         si, sj = ctypes.c_int(0), ctypes.c_int(0)
         nbytes = _lib.load().interpn_hip_table_bytes(self._h, ctypes.byref(si), ctypes.byref(sj))
         return int(nbytes), int(si.value), int(sj.value)
+
+    def sweep_brick_form(self) -> str:
+        """Brick shape of the 3-D multilinear sweep kernel's table: "2x2xKW" (f64; f32 with KW = 8), "2x4x4" (f32), or ""
+        when the handle has no such table."""
+        if not self.get_option("sweep_table_bytes"):
+            return ""
+        return "2x4x4" if self.get_option("sweep_cell") == 2 else "2x2xKW"
+
+    def pci_address(self):
+        """(domain, bus, device) of the GPU this interpolator lives on, or None if the runtime does not say."""
+        v = self.get_option("dev_pci")
+        return None if v < 0 else (v >> 16, (v >> 8) & 0xFF, v & 0xFF)
 
     def _check_same_device(self, what: str, tensor) -> None:
         """Kernels run under the handle's device with the grid resident there: a tensor on another

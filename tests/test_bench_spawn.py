@@ -63,3 +63,26 @@ def test_external_launcher_is_respected():
 def test_failing_rank_fails_the_run():
     p = run(["--gpus", "2", "--dry-run", "--spawn-timeout", "60"], {"INTERPN_BENCH_DRY_FAIL_RANK": "1"})
     assert p.returncode != 0
+
+
+def test_record_names_the_devices_of_all_ranks():
+    """Every rank contributes (rank, device index, PCI address) to one all-gather; rank 0 writes them as config.devices
+    (round-5 review: the record must prove that N ranks sat on N distinct GPUs)."""
+    p = run(["--gpus", "8", "--steps", "3", "--dry-run"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    devs = rec["config"]["devices"]
+    assert [d["rank"] for d in devs] == list(range(8))
+    assert [d["cuda_device"] for d in devs] == list(range(8))
+    assert len({d["pci"] for d in devs}) == 8 and all(d["pci"] for d in devs)
+
+
+def test_ranks_sharing_a_device_fail_the_run_unless_asked_for():
+    same = {"INTERPN_BENCH_DRY_SAME_PCI": "1"}
+    p = run(["--gpus", "2", "--dry-run", "--spawn-timeout", "60"], same)
+    assert p.returncode != 0
+    assert "distinct device" in (p.stderr + p.stdout)
+    p = run(["--gpus", "2", "--dry-run", "--same-device"], same)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len({d["pci"] for d in rec["config"]["devices"]}) == 1

@@ -2883,3 +2883,199 @@ def test_column_evaluation_3d_only_on_request(oracle, monkeypatch):
             assert np.array_equal(got[idx].cpu().numpy(), w)
         finally:
             it.close()
+
+
+# ---- the sweep family on observation sets that are not i.i.d. uniform (round 6) -------------------------------------
+_SWEEP_SHAPES = {
+    # name: (method, kind, dims, the dimension whose cell index is the per-wave sort key)
+    "linear3": ("linear", "regular", [40, 19, 23], 0),
+    "linear3_rect": ("linear", "rectilinear", [40, 19, 23], 0),
+    "linear3_rect_long": ("linear", "rectilinear", [130, 9, 11], 0),
+    "linear2": ("linear", "regular", [200, 40], 0),
+    "nearest3": ("nearest", "regular", [40, 19, 23], 0),
+    "nearest2": ("nearest", "regular", [300, 9], 0),
+    "cubic3": ("cubic", "regular", [12, 11, 90], 2),
+    "cubic3_rect": ("cubic", "rectilinear", [12, 11, 90], 2),
+    "cubic2": ("cubic", "regular", [150, 40], 0),
+}
+
+
+def structured_obs(case, dist, keydim, seed):
+    """Observation sets that drive the per-wave counting sort of the sweep kernels (sweep_rounds.h, linear_sweep.h) through
+    its corners, in place in `case.obs`:
+      one_cell   every point of the first half inside ONE interior cell, of the second half in the top cell and beyond it
+                 (one bin per wave: all 1024 points of a round rank into the same counter);
+      sorted     i.i.d. points ordered by the key dimension's coordinate (every wave's points in a narrow band of bins, bands
+                 moving with the wave's place in the batch: no two waves sweep the same slab);
+      lattice    a regular lattice finer than the grid in C order (re-gridding: long runs of one key, neighbours share lines);
+      on_planes  every coordinate exactly a grid coordinate (x - izl == 0: the division-free forms refuse every point, the whole
+                 batch takes the wave-uniform divide sequences; cubic: every class boundary);
+      half_nan   the second half of the batch with NaN in a random dimension of every other point (regular grids: the first
+                 failing index and the prefix; rectilinear: NaN propagates)."""
+    rng = np.random.default_rng(seed)
+    n = len(case.grids)
+    nobs = case.obs[0].size
+    dtype = case.vals.dtype
+    if dist == "one_cell":
+        h = nobs // 2
+        for d in range(n):
+            g = case.grids[d].astype(np.float64)
+            c = int(rng.integers(1, max(2, g.size - 2)))
+            case.obs[d][:h] = rng.uniform(g[c], g[c + 1], h).astype(dtype)
+            case.obs[d][h:] = rng.uniform(g[-2], g[-1] + 0.7 * (g[-1] - g[-2]), nobs - h).astype(dtype)
+    elif dist == "sorted":
+        order = np.argsort(case.obs[keydim], kind="stable")
+        for d in range(n):
+            case.obs[d][:] = case.obs[d][order]
+    elif dist == "lattice":
+        m = int(np.ceil(nobs ** (1.0 / n)))
+        axes = [np.linspace(float(case.grids[d][0]) - 0.02, float(case.grids[d][-1]) + 0.02, m) for d in range(n)]
+        mesh = np.meshgrid(*axes, indexing="ij")
+        for d in range(n):
+            case.obs[d][:] = mesh[d].ravel()[:nobs].astype(dtype)
+    elif dist == "on_planes":
+        for d in range(n):
+            case.obs[d][:] = case.grids[d][rng.integers(0, case.grids[d].size, nobs)]
+    elif dist == "half_nan":
+        h = nobs // 2
+        idx = np.arange(h, nobs, 2)
+        dim = rng.integers(0, n, idx.size)
+        for d in range(n):
+            case.obs[d][idx[dim == d]] = np.nan
+    else:
+        raise ValueError(dist)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("dist", ["one_cell", "sorted", "lattice", "on_planes", "half_nan"])
+@pytest.mark.parametrize("shape", list(_SWEEP_SHAPES), ids=list(_SWEEP_SHAPES))
+def test_sweep_family_on_structured_observation_sets(oracle, shape, dist, dtype):
+    """Every sweep kernel (3-D / 2-D multilinear, nearest, 3-D / 2-D multicubic; regular and rectilinear grids) forced onto
+    batches whose points are NOT i.i.d. uniform — all in one cell, already ordered by the kernel's own key, a lattice finer than
+    the grid, every point on grid planes, half the batch NaN — against the oracle and, bit for bit, against the one-pass
+    kernel, with the clock and without.  The reference also measures un-shuffled grids of points
+    (benches/bench.rs:554-571); a point's result depends on its own coordinates only (multilinear/regular.rs:276-280)."""
+    import torch
+
+    import interpn_amd
+
+    method, kind, dims, keydim = _SWEEP_SHAPES[shape]
+    dev = torch.device("cuda:0")
+    nobs = 150_011
+    case = synthetic_case(method, kind, len(dims), dims, nobs, 6100 + sum(dims), dtype, linearize=True, extrap=0.1, specials=False)
+    clean = [o.copy() for o in case.obs]
+    structured_obs(case, dist, keydim, 6200 + sum(dims))
+    fails = dist == "half_nan" and kind == "regular"
+    if fails:  # the oracle stops at the first NaN like the reference: expected values from the points without them
+        keep = case.obs
+        case.obs = clean
+        want = run_oracle(oracle, case, True)
+        case.obs = keep
+        first_bad = int(min(np.flatnonzero(np.isnan(o))[0] for o in case.obs if np.isnan(o).any()))
+    else:
+        want = run_oracle(oracle, case, True)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals, linearize_extrapolation=True)
+    else:
+        it = interpn_amd.Interpolator.rectilinear(method, case.grids, case.vals, linearize_extrapolation=True)
+    try:
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        for period in (0, 1, 900):
+            it.set_option("sweep", 1)
+            it.set_option("sweep_period", period)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            assert "_sweep<" in it.kernel_name(), it.kernel_name()
+            if fails:
+                with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                    it.finish()
+                assert ei.value.first_bad_index == first_bad
+                g = got.cpu().numpy()[:first_bad]
+                assert np.array_equal(g, want[:first_bad]), period
+                continue
+            it.finish()
+            it.set_option("sweep", 0)
+            ref = it.eval_tensors(obs)
+            assert it.last_path == "in_place", it.last_path
+            it.finish()
+            g, r = got.cpu().numpy(), ref.cpu().numpy()
+            assert np.all((g == r) | (np.isnan(g) & np.isnan(r))), (period, "sweep != one-pass kernel")
+            same = (g == want) | (np.isnan(g) & np.isnan(want))
+            assert np.all(same), (period, int((~same).sum()))
+    finally:
+        it.close()
+
+
+def test_column_kernel_build_that_was_miscompiled():
+    """Round 5 found a build of the rectilinear 4-D column kernel (k_cubic_column<float, true, ...>) that differed from the
+    product by an unused kernel argument and a never-taken branch and returned wrong values for every point whose class along
+    dim 1 is High.  Cause (profiles/NOTES.md section H): the node's three class arms formed a switch whose default arm (High)
+    is entered from both halves of the lowered decision tree, and the compiler's StructurizeCFG gave the High lanes entering
+    from the `sat >= 1` side the Low arm's y0 and an undefined y1.  The nodes are now one two-way branch with selects
+    (interpn_device.h::cubic_rect_saturated); this test runs the binned 4-D rectilinear cases through THAT build
+    (tools/libinterpn_colvariant.so: the product's objects with the column kernel compiled with
+    -DINTERPN_COLUMN_CREC_VARIANT) in a child process (multicubic/rectilinear.rs:509-542 are the arms in question)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "libinterpn_colvariant.so")
+    if not os.path.exists(lib):
+        pytest.skip("tools/libinterpn_colvariant.so not built (make -C interpn_amd/csrc colvariant)")
+    ids = [f"tests/test_gpu_parity.py::test_binned_multicubic_evaluation[{axis}-11-rectilinear-{t}]"
+           for axis in ("[5, 6, 4, 7]", "[40, 37, 5, 4]") for t in ("f32", "f64")]
+    env = dict(os.environ, INTERPN_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ids, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "4 passed" in r.stdout, r.stdout[-1000:]
+
+
+@pytest.mark.parametrize("order", ["sweep_then_sorted", "sorted_then_sweep"])
+def test_sweep_and_sorted_evaluation_share_a_scratch_block(oracle, monkeypatch, order):
+    """One handle, one stream, both paths through the same scratch block: a sweep launch of at least four rounds per wave
+    leaves its measured period inside the block's work words — bytes that are one of the sort's bin counters — so each
+    path has its own "block is clean" flag and clears the other's (abi_internal.h::BinSlot).  Sweep first, then the sorted
+    evaluation (the order that started the sort from a non-zero counter before round 6), and the reverse; the results are
+    the in-place kernel's bit for bit and the oracle's on a sample."""
+    import torch
+
+    import interpn_amd
+
+    monkeypatch.setenv("INTERPN_HIP_BRICKS", "11")
+    dev = torch.device("cuda:0")
+    nobs = 9_000_000
+    case = synthetic_case("cubic", "regular", 3, [24, 22, 26], nobs, 6400, np.float64, linearize=True, extrap=0.1, specials=True)
+    it = _make_interp(interpn_amd, case)
+    try:
+        obs = [torch.from_numpy(o).to(dev) for o in case.obs]
+        it.set_option("sweep", 0)
+        it.set_option("binned", 0)
+        ref = it.eval_tensors(obs).clone()
+        it.finish()
+        assert it.last_path == "in_place"
+        sample = np.random.default_rng(5).choice(nobs, 100_000, replace=False)
+        sub = kat.Case("s", "cubic", "regular", case.grids, case.vals, [o[sample] for o in case.obs], np.zeros(sample.size), 0.0, linearize=True)
+        assert np.array_equal(ref.cpu().numpy()[sample], run_oracle(oracle, sub, True))
+
+        def sweep():
+            it.set_option("binned", 0)
+            it.set_option("sweep", 1)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "sweep", (it.last_path, it.last_path_reason)
+            it.finish()
+            assert torch.equal(got, ref)
+
+        def sorted_():
+            it.set_option("sweep", 0)
+            it.set_option("binned", 1)
+            got = it.eval_tensors(obs)
+            assert it.last_path == "binned", (it.last_path, it.last_path_reason)
+            it.finish()
+            assert torch.equal(got, ref)
+
+        for step in ((sweep, sweep, sorted_, sorted_, sweep, sorted_) if order == "sweep_then_sorted" else (sorted_, sweep, sweep, sorted_)):
+            step()
+    finally:
+        it.close()
