@@ -102,6 +102,7 @@ interpn_hip_interp::BinSlot* take_bin_slot(interpn_hip_interp* h, size_t need, h
       bool ok = !recorded || hipEventSynchronize(ev) == hipSuccess;
       if (ok) {
         pool_free(h->device, old);
+        h->last_probe_word = nullptr;
         freed = true;
         ok = pool_alloc(h->device, &fresh, need) == hipSuccess;
       }
@@ -411,6 +412,7 @@ int interpn_hip_reserve(interpn_hip_interp* h, size_t npoints, int nstreams) {
     if (sl.bytes >= need || sl.busy) continue;
     if (sl.recorded) HIP_TRY(hipEventSynchronize(sl.event));
     pool_free(h->device, sl.scratch);
+    h->last_probe_word = nullptr;
     sl.scratch = nullptr;
     sl.bytes = 0;
     sl.totals_clean = false;

@@ -161,6 +161,7 @@ struct interpn_hip_interp {
   unsigned long long bin_uses = 0;
   interpn_hip_interp() { bin_slots.reserve(kMaxBinSlots); }
   std::atomic<long long> evals_binned{0}, evals_in_place{0}, evals_sweep{0}, scratch_allocs{0};
+  const void* last_probe_word = nullptr;  // device word holding the verdict of the most recent gated launch's sampling kernel (option "sweep_probe_took_brick"; tests, bench)
 };
 
 namespace interpn_abi {

@@ -41,6 +41,8 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"axis_records", &c.axis_records, 0, 1},
       {"sweep", &c.sweep, -1, 1},
       {"sweep_period", &c.sweep_period, 0, 1000000},
+      {"sweep_probe", &c.sweep_probe, 0, 1},
+      {"gated_iters", &c.gated_iters, 0, 4096},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -83,7 +85,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble", "sweep", "sweep_period"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble", "sweep", "sweep_period", "sweep_probe", "gated_iters"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
@@ -157,6 +159,17 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
   if (!strcmp(name, "evals_in_place")) { *value = h->evals_in_place.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "evals_sweep")) { *value = h->evals_sweep.load(); return INTERPN_HIP_OK; }
   if (!strcmp(name, "sweep_table_bytes")) { *value = h->desc.sweep_bricks ? (long long)h->desc.sweep_table_bytes : 0; return INTERPN_HIP_OK; }
+  if (!strcmp(name, "sweep_probe_took_brick")) {  // read-only, synchronises the device: 1 / 0 = what the last gated launch's sample decided, -1 = the last sweep launch was not gated
+    *value = -1;
+    if (h->last_probe_word) {
+      DeviceGuard guard(h->device);
+      if (!guard.ok()) return INTERPN_HIP_ERR_NO_DEVICE;
+      unsigned w = 0;
+      if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&w, h->last_probe_word, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return INTERPN_HIP_ERR_INVALID_ARGUMENT; }
+      *value = w ? 1 : 0;
+    }
+    return INTERPN_HIP_OK;
+  }
   if (!strcmp(name, "sweep_cell")) { *value = h->desc.sweep_bricks ? h->desc.sweep_cell : 0; return INTERPN_HIP_OK; }  // 0: 2 x 2 x KW bricks, 2: 2 x 4 x 4 (f32)
   if (!strcmp(name, "dev_pci")) {  // read-only: (domain << 16) | (bus << 8) | device of the GPU the handle lives on; -1 if unknown
     int dom = 0, bus = 0, dv = 0;

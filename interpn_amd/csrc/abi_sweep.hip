@@ -33,7 +33,18 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
   // first use of the block by this path, or the sorted path has used it since: reset the work words (a complete launch leaves
   // its counters zero and its measured period in place; that period word is one of the sort's bin counters)
   if (!slot->sweep_clean) err = hipMemsetAsync(slot->scratch, 0, sweep_work_bytes(), stream);
-  if (err == hipSuccess) err = launch_linear_sweep(g, obs, out, npoints, h->first_bad, slot->scratch, stream);
+  // 3-D multilinear in automatic mode: the device decides between this kernel and the brick kernel (k_linear_sweep.hip::k_sweep_probe)
+  const bool probe = g.method == kLinear && g.ndims == 3 && g.cfg.sweep < 0 && g.cfg.sweep_probe != 0 && g.bricks != nullptr;
+  if (probe && err == hipSuccess) err = launch_sweep_probe(g, obs, npoints, slot->scratch, stream);
+  if (err == hipSuccess) err = launch_linear_sweep(g, obs, out, npoints, h->first_bad, slot->scratch, stream, probe);
+  if (probe && err == hipSuccess) {
+    const unsigned* gate = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(slot->scratch) + sweep_probe_word_offset());
+    const KernelTag primary = g.tag;  // the handle reports the sweep kernel (which of the pair ran is known on the device only: option sweep_probe_took_brick)
+    err = g.dtype == kF64 ? launch_linear_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npoints, h->first_bad, stream, gate)
+                          : launch_linear_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npoints, h->first_bad, stream, gate);
+    g.tag = primary;
+  }
+  h->last_probe_word = probe ? static_cast<const unsigned char*>(slot->scratch) + sweep_probe_word_offset() : nullptr;
   slot->sweep_clean = err == hipSuccess;
   slot->totals_clean = false;
   {

@@ -52,6 +52,8 @@ struct LaunchConfig {
   long long debug_stamps_bytes = 0;  // ... and the size of that buffer: a launch whose parts need more than it holds writes no stamps
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
   int sweep = -1;          // 3-D f64 multilinear, device-pointer evaluation: the sweep kernel (linear_sweep.h) -1 where it pays, 0 never, 1 whenever the handle has its table
+  int gated_iters = 16;    // rows of 256 lanes per workgroup of the gated brick launch behind an automatic sweep launch (an empty workgroup costs dispatch time)
+  int sweep_probe = 1;     // automatic 3-D multilinear sweep launches: sample the batch on the device first and let the brick kernel take coherent batches (0: the sweep kernel whatever the points look like)
   int sweep_period = 0;    // sweep evaluation: ticks of 10 ns per sweep of the leading index (0: what the previous launch measured; 1: no clock, rows in sorted order; tests / tuning)
 };
 
@@ -221,7 +223,11 @@ int cubic_sweep_applies(const GridDesc& g, size_t npts);   // k_cubic_sweep.hip 
 hipError_t launch_cubic_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
                               void* work, hipStream_t stream);
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                               void* work, hipStream_t stream);
+                               void* work, hipStream_t stream, bool gated = false);
+// 3-D multilinear, automatic path: the sampling kernel whose verdict (a word of the scratch block, at this offset) gates the
+// sweep launch (gated = true) and the brick launch (launch_linear_brick's `gate`) enqueued behind it
+hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream);
+size_t sweep_probe_word_offset();
 
 template <typename T>
 hipError_t launch_linear_regular(const GridDesc& g, const T* const* obs, T* out, size_t npts,
@@ -250,7 +256,7 @@ void brick_j4_geometry(const GridDesc& g, unsigned nb[3], size_t* bytes);  // f3
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                               unsigned long long* first_bad, hipStream_t stream);
+                               unsigned long long* first_bad, hipStream_t stream, const unsigned* gate = nullptr);
 
 // 1-D multilinear-rectilinear from per-bucket records (k_linear1_records.hip).
 size_t records1_bytes(const GridDesc& g, int M);

@@ -129,6 +129,8 @@ template <typename T, int N, int PPL>
 static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds, size_t axis_lds, size_t npts, hipStream_t stream) {
   const int axr = lane_axes_mode(g);  // axes in lanes (lane_axes.h) or 0 = LDS / L2 search
   a.iters = brick_iters(g, npts, PPL, /*setup=*/g.kind != kRectilinear ? 0 : (axr == 0 ? 2 : 1));
+  // a gated launch mostly returns at once (unordered points: the sweep kernel has the batch): few, fat workgroups
+  if (a.gate && g.cfg.gated_iters > 0 && a.iters < (unsigned)g.cfg.gated_iters) a.iters = (unsigned)g.cfg.gated_iters;
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;
   const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);
@@ -150,9 +152,10 @@ static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds,
 
 template <typename T, int N>
 static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
-                           hipStream_t stream) {
+                           hipStream_t stream, const unsigned* gate) {
   typedef typename LeafVec<T, 2>::type P;
   BrickArgs<T, N> a;
+  a.gate = gate;
   a.bricks = static_cast<const T*>(g.bricks);
   a.out = out;
   a.first_bad = first_bad;
@@ -197,17 +200,17 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
 
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                               unsigned long long* first_bad, hipStream_t stream) {
+                               unsigned long long* first_bad, hipStream_t stream, const unsigned* gate) {
   switch (g.ndims) {
-    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream);
-    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream);
-    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream);
-    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream);
+    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream, gate);
+    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream, gate);
+    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream, gate);
+    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream, gate);
     default: return hipErrorInvalidValue;
   }
 }
 
-template hipError_t launch_linear_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
-template hipError_t launch_linear_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_linear_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t, const unsigned*);
+template hipError_t launch_linear_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t, const unsigned*);
 
 }  // namespace interpn

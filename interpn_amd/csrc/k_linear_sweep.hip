@@ -118,12 +118,94 @@ static hipError_t go_layout(const GridDesc& g, const SweepArgs<T>& s, unsigned b
   }
 }
 
+// ---- which kernel for a large batch: decided on the device from a sample -----------------------------------------------
+// The sweep kernel is the faster one on points in no particular order (it makes the locality they lack); on batches that are
+// coherent as they stand — re-gridding onto a finer lattice with the last dimension fastest, clustered points — the one-pass
+// brick kernel is (neighbouring lanes already share lines and it runs eight waves per SIMD: 64^3 f64, 1e8 points: lattice
+// 0.72 against 0.88 ms, one cell 0.66 against 0.80; profiles/r06_obs_distributions.jsonl).  The host cannot look at the points
+// without a synchronisation, so an automatic launch is three: this kernel samples kProbeRows rows of 64 consecutive points
+// spread over the batch, counts how often a point's table line differs from its predecessor's, and leaves the verdict in the
+// scratch block; the sweep kernel and the brick kernel behind it are both enqueued, and the one the verdict is against
+// returns at once.  Unordered points change line at every step (63 of 63), a fine lattice at a few per row.
+constexpr unsigned kProbeRows = 256;
+template <typename T>
+struct ProbeArgs {
+  const T* obs[3];
+  size_t npts;
+  T start[3], scale[3];  // ~ cell index = (x - start) * scale (a hint, like the sweep's sort key)
+  int top[3];            // n - 2
+  int sk;                // cells along the last dimension that share a brick line
+  SweepWork* work;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_probe(const ProbeArgs<T> p) {
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const unsigned rows = gridDim.x * 4u;
+  // row r: 64 consecutive points starting at a multiple of 64 near r / rows of the batch
+  const size_t slots = p.npts / 64u;  // >= rows (the host launches this for large batches only)
+  const size_t at = (size_t)((unsigned long long)row * (slots - 1u) / (rows > 1u ? rows - 1u : 1u)) * 64u + lane;
+  unsigned id = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const T u = (p.obs[d][at] - p.start[d]) * p.scale[d];
+    const int c = u >= (T)1 ? (u < (T)p.top[d] ? (int)u : p.top[d]) : 0;  // (NaN: 0)
+    id = id * 0x9E3779B1u + (unsigned)(d == 2 ? c / p.sk : c);
+  }
+  const unsigned prev = (unsigned)__shfl_up((int)id, 1);
+  const unsigned changes = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane > 0 && id != prev));
+  if (lane == 0) {
+    const unsigned r1 = atomicAdd(&p.work->probe_changes, changes);
+    asm volatile("" ::"v"(r1));  // (returning form, answer consumed: performed before `probe_done` is touched)
+    if (atomicAdd(&p.work->probe_done, 1u) == rows - 1u) {
+      const unsigned total = atomicAdd(&p.work->probe_changes, 0u);
+      // coherent: fewer than a quarter of the sampled points start a new line
+      atomicExch(&p.work->take_brick, total * 4u < rows * 63u ? 1u : 0u);
+      atomicExch(&p.work->probe_changes, 0u);
+      atomicExch(&p.work->probe_done, 0u);
+    }
+  }
+}
+
+template <typename T>
+static hipError_t probe_t(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream) {
+  ProbeArgs<T> p;
+  for (int d = 0; d < 3; ++d) {
+    p.obs[d] = static_cast<const T*>(obs[d]);
+    if (g.kind == kRectilinear) {
+      const double span = g.bound_hi[d] - g.bound_lo[d];
+      p.start[d] = (T)g.bound_lo[d];
+      p.scale[d] = span > 0 ? (T)((double)(g.n[d] - 1) / span) : (T)0;
+    } else {
+      p.start[d] = (T)g.start[d];
+      p.scale[d] = (T)(1.0 / g.step[d]);
+    }
+    if (!(p.scale[d] > 0) || !(p.scale[d] < (T)1e30)) p.scale[d] = 0;
+    p.top[d] = g.n[d] - 2;
+  }
+  p.sk = g.dtype == kF64 ? BrickGeom<double, 0>::SK : (g.brick_cell == 2 ? BrickGeom<float, 2>::SK : BrickGeom<float, 0>::SK);
+  p.npts = npts;
+  p.work = static_cast<SweepWork*>(work);
+  hipLaunchKernelGGL(k_sweep_probe<T>, dim3(kProbeRows / 4), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream) {
+  if (g.method != kLinear || g.ndims != 3 || !work || npts < (size_t)kProbeRows * 64) return hipErrorInvalidValue;
+  return g.dtype == kF64 ? probe_t<double>(g, obs, npts, work, stream) : probe_t<float>(g, obs, npts, work, stream);
+}
+
+size_t sweep_probe_word_offset() { return offsetof(SweepWork, take_brick); }
+
 // `work`: a zeroed SweepWork block that no other launch in flight uses (abi_sweep.hip).
 template <typename T>
 static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                           void* work, hipStream_t stream) {
+                           void* work, hipStream_t stream, bool gated) {
   SweepArgs<T> s;
+  s.gated = gated ? 1u : 0u;
   BrickArgs<T, 3>& a = s.b;
+  a.gate = nullptr;
   a.bricks = static_cast<const T*>(g.sweep_bricks);
   a.out = static_cast<T*>(out);
   a.first_bad = first_bad;
@@ -194,7 +276,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
 }
 
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                               void* work, hipStream_t stream) {
+                               void* work, hipStream_t stream, bool gated) {
   if (g.method == kNearest) return launch_nearest_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kCubic) return launch_cubic_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kLinear && g.ndims == 2) return launch_linear2_sweep(g, obs, out, npts, first_bad, work, stream);
@@ -202,8 +284,8 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
   for (int d = 0; d < 3; ++d)
     if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)
   if (reinterpret_cast<uintptr_t>(out) % 16) return hipErrorInvalidValue;
-  if (g.dtype == kF64) return launch_t<double>(g, obs, out, npts, first_bad, work, stream);
-  return launch_t<float>(g, obs, out, npts, first_bad, work, stream);
+  if (g.dtype == kF64) return launch_t<double>(g, obs, out, npts, first_bad, work, stream, gated);
+  return launch_t<float>(g, obs, out, npts, first_bad, work, stream, gated);
 }
 
 }  // namespace interpn

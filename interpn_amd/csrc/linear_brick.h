@@ -54,6 +54,9 @@ struct BrickArgs {
   unsigned lead_stride[N > 3 ? N - 3 : 1];  // elements of the brick table per unit of a leading index
   unsigned nbj, nbk;
   unsigned iters;  // kBlock-wide iterations per workgroup
+  // Gated launch (abi_sweep.hip: a large 3-D batch whose path — this kernel or the sweep kernel — a sampling kernel
+  // in front decides on the device): null, or a word that must be non-zero for this launch to do anything.
+  const unsigned* gate;
 };
 
 template <typename T, int SI, int SJ, int CELL = 0>
@@ -222,6 +225,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   typedef BrickGeom<T, CELL> Geom;
   constexpr int L = N - 3;
   constexpr int SK = Geom::SK;
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (workgroup-uniform)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]

@@ -46,7 +46,11 @@ struct SweepWork {
   unsigned long long ticks;    // sum over waves of the ticks spent in rounds ...
   unsigned rounds;             // ... and of the rounds they took
   unsigned period;             // ticks per sweep for the next launch (0: the launch's default)
-  unsigned pad[28];
+  // the sampling kernel in front of an automatic launch (k_linear_sweep.hip::k_sweep_probe): its counters (left zero)
+  // and its verdict for the two gated launches behind it — non-zero: the batch is coherent as it stands, the brick
+  // kernel takes it and the sweep kernel's waves return at once
+  unsigned probe_changes, probe_done, take_brick;
+  unsigned pad[25];
 };
 static_assert(sizeof(SweepWork) == 10 * 128, "one line per counter");
 
@@ -61,6 +65,7 @@ struct SweepArgs {
   unsigned per_shard;  // rounds per shard (8 shards)
   unsigned period;     // > 0: ticks per sweep, overriding the measured one; 1: rows in sorted order (no clock)
   unsigned period_default;  // before anything has been measured
+  unsigned gated;           // != 0: do nothing if work->take_brick is set (see SweepWork)
   SweepWork* work;
   unsigned long long* stamps;  // STAMPS builds (tools/): 8 words per wave, see the kernel's end
 };
@@ -109,6 +114,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   constexpr int SK = Geom::SK;
   typedef SweepLds<T, K, KL> L;
   const BrickArgs<T, 3>& a = s.b;
+  if (s.gated && __hip_atomic_load(&s.work->take_brick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // (launch-uniform: no work word is touched)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = threadIdx.x >> 6;

@@ -3079,3 +3079,75 @@ def test_sweep_and_sorted_evaluation_share_a_scratch_block(oracle, monkeypatch, 
             step()
     finally:
         it.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["regular", "rectilinear"])
+def test_automatic_path_samples_the_batch_on_the_device(oracle, kind, dtype):
+    """Large 3-D multilinear batches in automatic mode: a sampling kernel in front decides on the device whether the sweep
+    kernel (unordered points) or the one-pass brick kernel (points that are coherent as they stand: a fine lattice, a cluster)
+    evaluates the batch; both launches are enqueued and one returns at once (k_linear_sweep.hip::k_sweep_probe,
+    abi_sweep.hip).  Either way the results are the forced kernels' bit for bit and the oracle's on a sample, the verdict is
+    the expected one, and an unrepresentable coordinate is reported with its index whichever kernel ran
+    (multilinear/regular.rs:268-283)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = 128
+    P = 20_000_000
+    td = torch.float64 if dtype == np.float64 else torch.float32
+    case = synthetic_case("linear", kind, 3, [n] * 3, 64, 6500, dtype, extrap=0.0, specials=False)
+    if kind == "regular":
+        it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    else:
+        it = interpn_amd.Interpolator.rectilinear("linear", case.grids, case.vals)
+    try:
+        m = 272
+        ax = torch.linspace(-1.02, 1.02, m, dtype=td, device=dev)
+        lat = [t.reshape(-1)[:P].contiguous() for t in torch.meshgrid(ax, ax, ax, indexing="ij")]
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(11)
+        rnd = [torch.rand(P, dtype=td, device=dev, generator=gen) * 2.1 - 1.05 for _ in range(3)]
+        half = [torch.cat([a[:P // 2], b[P // 2:]]) for a, b in zip(lat, rnd)]
+        sample = np.random.default_rng(7).choice(P, 50_000, replace=False)
+        for name, obs, verdict in (("lattice", lat, 1), ("random", rnd, 0), ("half", half, None)):
+            it.set_option("sweep", 1)
+            a = it.eval_tensors(obs).clone()
+            it.finish()
+            assert it.last_path == "sweep" and it.get_option("sweep_probe_took_brick") == -1
+            it.set_option("sweep", 0)
+            b = it.eval_tensors(obs).clone()
+            it.finish()
+            assert torch.equal(a, b), name
+            it.set_option("sweep", -1)
+            out = torch.full_like(a, -7.0)
+            it.eval_tensors(obs, out)
+            it.finish()
+            assert it.last_path == "sweep", (name, it.last_path, it.last_path_reason)
+            took = it.get_option("sweep_probe_took_brick")
+            assert took in (0, 1) and (verdict is None or took == verdict), (name, took)
+            assert torch.equal(out, a), name
+            sub = kat.Case("s", "linear", kind, case.grids, case.vals, [o[sample].cpu().numpy() for o in obs], np.zeros(sample.size, dtype), 0.0)
+            assert np.array_equal(out[sample].cpu().numpy(), run_oracle(oracle, sub, True)), name
+            # the sample's verdict can be switched off: then the sweep kernel takes the batch whatever it looks like
+            it.set_option("sweep_probe", 0)
+            it.eval_tensors(obs, out)
+            it.finish()
+            assert it.get_option("sweep_probe_took_brick") == -1 and torch.equal(out, a)
+            it.set_option("sweep_probe", 1)
+        if kind == "regular":  # the first failing index, through the gated pair
+            for obs in (lat, rnd):
+                bad = [o.clone() for o in obs]
+                bad[1][P - 5] = float("nan")
+                bad[2][7_000_003] = float("inf")
+                good = it.eval_tensors(obs).clone()
+                it.finish()
+                out = it.eval_tensors(bad)
+                with pytest.raises(AssertionError, match="Unrepresentable coordinate value") as ei:
+                    it.finish()
+                assert ei.value.first_bad_index == 7_000_003
+                assert torch.equal(out[:7_000_003], good[:7_000_003])
+    finally:
+        it.close()

@@ -87,6 +87,7 @@ int ablate_launch(void* handle, int mode, const double* x, const double* y, cons
   for (const void* p : {(const void*)x, (const void*)y, (const void*)z, (const void*)out})
     if (reinterpret_cast<uintptr_t>(p) % 16) return (int)hipErrorInvalidValue;  // the two-points-per-lane form
   BrickArgs<double, 3> a;
+  a.gate = nullptr;
   a.bricks = h->bricks;
   a.obs[0] = x; a.obs[1] = y; a.obs[2] = z;
   a.out = out;
@@ -132,6 +133,8 @@ int ablate_launch_sweep(void* handle, const double* x, const double* y, const do
     if (reinterpret_cast<uintptr_t>(p) % 16) return (int)hipErrorInvalidValue;
   SweepArgs<double> s;
   BrickArgs<double, 3>& a = s.b;
+  a.gate = nullptr;
+  s.gated = 0;
   a.bricks = h->bricks;
   a.obs[0] = x; a.obs[1] = y; a.obs[2] = z;
   a.out = out;
