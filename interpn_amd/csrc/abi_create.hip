@@ -485,6 +485,7 @@ void interpn_hip_destroy(interpn_hip_interp* h) {
   }
   pool_free(h->device, h->first_bad);
   pool_return_pinned_word(h->device, h->finish_word);
+  pool_return_pinned_word(h->device, h->probe_host);
   pool_free(h->device, h->grids_owned);
   pool_free(h->device, h->bricks_owned);
   pool_free(h->device, h->bricks11_owned);

@@ -161,6 +161,14 @@ struct interpn_hip_interp {
   unsigned long long bin_uses = 0;
   interpn_hip_interp() { bin_slots.reserve(kMaxBinSlots); }
   std::atomic<long long> evals_binned{0}, evals_in_place{0}, evals_sweep{0}, scratch_allocs{0};
+  // thinning the sample out (option sweep_probe = 2; guarded by bin_mu): the sampling kernel also stores (seq << 1 | coherent)
+  // into this pinned word; the host looks at it before the next launch — no synchronisation, a verdict that has not landed
+  // yet simply is not known yet
+  unsigned long long* probe_host = nullptr;
+  unsigned* probe_host_dev = nullptr;
+  unsigned probe_seq = 0, probe_seen = 0;
+  int probe_streak = 0;     // samples in a row that came out unordered
+  int probe_skipped = 0;    // automatic launches since the last sample
   const void* last_probe_word = nullptr;  // device word holding the verdict of the most recent gated launch's sampling kernel (option "sweep_probe_took_brick"; tests, bench)
 };
 

@@ -41,7 +41,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"axis_records", &c.axis_records, 0, 1},
       {"sweep", &c.sweep, -1, 1},
       {"sweep_period", &c.sweep_period, 0, 1000000},
-      {"sweep_probe", &c.sweep_probe, 0, 1},
+      {"sweep_probe", &c.sweep_probe, 0, 2},
       {"gated_iters", &c.gated_iters, 0, 4096},
   };
   if (!name || !value) return false;

@@ -33,16 +33,60 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
   // first use of the block by this path, or the sorted path has used it since: reset the work words (a complete launch leaves
   // its counters zero and its measured period in place; that period word is one of the sort's bin counters)
   if (!slot->sweep_clean) err = hipMemsetAsync(slot->scratch, 0, sweep_work_bytes(), stream);
-  // 3-D multilinear in automatic mode: the device decides between this kernel and the brick kernel (k_linear_sweep.hip::k_sweep_probe)
-  const bool probe = g.method == kLinear && g.ndims == 3 && g.cfg.sweep < 0 && g.cfg.sweep_probe != 0 && g.bricks != nullptr;
-  if (probe && err == hipSuccess) err = launch_sweep_probe(g, obs, npoints, slot->scratch, stream);
-  if (err == hipSuccess) err = launch_linear_sweep(g, obs, out, npoints, h->first_bad, slot->scratch, stream, probe);
+  // automatic mode: the device decides between the sweep kernel and the one-pass kernel (k_linear_sweep.hip::k_sweep_probe:
+  // a sampling kernel in front, verdict 1 / 0 in the scratch block); both launches work from private copies of the
+  // description that carry the gate (the handle's own is shared by threads)
+  bool probe = sweep_probe_applies(g) && npoints >= 256u * 64u;
+  unsigned* host_word = nullptr;
+  unsigned seq = 0;
+  if (probe && g.cfg.sweep_probe == 2) {
+    // Thinned-out sampling: a handle whose last three samples all said "unordered" is sampled on every 16th automatic
+    // launch only (the sample and the gated launch behind the sweep kernel cost ~1.5 % of a 1e8-point launch); one
+    // "coherent" verdict brings every launch's sample back.  Whichever kernel runs, the results are the same bits.
+    std::lock_guard<std::mutex> lk(h->bin_mu);
+    if (!h->probe_host) {
+      void* dp = nullptr;
+      if (pool_take_pinned_word(h->device, &h->probe_host) == hipSuccess && h->probe_host &&
+          hipHostGetDevicePointer(&dp, h->probe_host, 0) == hipSuccess && dp) {
+        *(volatile unsigned long long*)h->probe_host = 0;
+        h->probe_host_dev = static_cast<unsigned*>(dp);
+      } else {
+        (void)hipGetLastError();
+        h->probe_host_dev = nullptr;  // no host view of the verdicts: every launch is sampled
+      }
+    }
+    if (h->probe_host_dev) {
+      const unsigned w = (unsigned)*(volatile unsigned long long*)h->probe_host;
+      if ((w >> 1) != h->probe_seen && (w >> 1) != 0) {
+        h->probe_seen = w >> 1;
+        h->probe_streak = (w & 1u) ? 0 : h->probe_streak + 1;
+      }
+      if (h->probe_streak >= 3 && h->probe_skipped < 15) {
+        ++h->probe_skipped;
+        probe = false;
+      } else {
+        h->probe_skipped = 0;
+        h->probe_seq = h->probe_seq >= 0x7FFFFFFEu ? 1u : h->probe_seq + 1u;
+        host_word = h->probe_host_dev;
+        seq = h->probe_seq;
+      }
+    }
+  }
+  if (probe && err == hipSuccess) err = launch_sweep_probe(g, obs, npoints, slot->scratch, stream, host_word, seq);
+  if (err == hipSuccess) {
+    if (probe) {
+      GridDesc gs = g;
+      gs.sweep_gated = true;
+      err = launch_linear_sweep(gs, obs, out, npoints, h->first_bad, slot->scratch, stream);
+      g.tag = gs.tag;  // the handle reports the sweep kernel (which of the pair ran is known on the device only: option sweep_probe_took_brick)
+    } else {
+      err = launch_linear_sweep(g, obs, out, npoints, h->first_bad, slot->scratch, stream);
+    }
+  }
   if (probe && err == hipSuccess) {
-    const unsigned* gate = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(slot->scratch) + sweep_probe_word_offset());
-    const KernelTag primary = g.tag;  // the handle reports the sweep kernel (which of the pair ran is known on the device only: option sweep_probe_took_brick)
-    err = g.dtype == kF64 ? launch_linear_brick<double>(g, reinterpret_cast<const double* const*>(obs), static_cast<double*>(out), npoints, h->first_bad, stream, gate)
-                          : launch_linear_brick<float>(g, reinterpret_cast<const float* const*>(obs), static_cast<float*>(out), npoints, h->first_bad, stream, gate);
-    g.tag = primary;
+    GridDesc gb = g;
+    gb.launch_gate = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(slot->scratch) + sweep_probe_word_offset());
+    err = launch_any(gb, obs, out, npoints, h->first_bad, stream);
   }
   h->last_probe_word = probe ? static_cast<const unsigned char*>(slot->scratch) + sweep_probe_word_offset() : nullptr;
   slot->sweep_clean = err == hipSuccess;

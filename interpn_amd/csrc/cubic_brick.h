@@ -46,6 +46,7 @@ struct CubicBrickArgs {
   // coordinate reports index_base + scatter[k].  nullptr = points are evaluated in place.
   const unsigned* scatter;
   size_t index_base;
+  const unsigned* gate;  // gated launch (GridDesc::launch_gate): null, or a word that must be non-zero for this launch to do anything
   // Binned evaluation, dealing the sorted order out to the XCDs: workgroups with equal
   // blockIdx % 8 (one XCD under the observed round-robin placement; speed only) walk one
   // contiguous eighth of the points, `eighth` points long (a multiple of 256; 0 = off), so that
@@ -317,6 +318,7 @@ struct PlaneReduce<T, 1, RECT, FMA, DMA, FAST> {
 template <typename T, int N, bool RECT, bool FMA, int SI, int SJ>
 __global__ void __launch_bounds__(kBlock) k_cubic_brick(const CubicBrickArgs<T, N> a) {
   typedef typename CubicDimSel<T, RECT>::type DimT;
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (launch-uniform)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // One region, used first for the offset transpose (u32) and then for the data transposes (T).
   typedef T __attribute__((may_alias)) lds_T;

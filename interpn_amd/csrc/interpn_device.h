@@ -49,6 +49,15 @@ __device__ __forceinline__ void stream_store(V* p, V v) { __builtin_nontemporal_
 // LDS words that are also accessed through another element type (type-based alias analysis off).
 typedef unsigned __attribute__((may_alias)) lds_u32;
 
+// made-up coordinates of the measurement builds (tools/: ABL forms of the brick and sweep kernels)
+template <typename T>
+__device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int n) {
+  unsigned h = (unsigned)i * 2654435761u + (unsigned)(i >> 32) * 40503u + (unsigned)d * 0x9E3779B9u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return start + step * ((T)(n - 1) * ((T)(h >> 8) * (T)(1.0 / 16777216.0)));
+}
+
+
 // ---------------------------------------------------------------------------
 // Scalar helpers
 template <typename T> __device__ __forceinline__ T dev_fma(T a, T b, T c);

@@ -53,7 +53,7 @@ struct LaunchConfig {
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
   int sweep = -1;          // 3-D f64 multilinear, device-pointer evaluation: the sweep kernel (linear_sweep.h) -1 where it pays, 0 never, 1 whenever the handle has its table
   int gated_iters = 16;    // rows of 256 lanes per workgroup of the gated brick launch behind an automatic sweep launch (an empty workgroup costs dispatch time)
-  int sweep_probe = 1;     // automatic 3-D multilinear sweep launches: sample the batch on the device first and let the brick kernel take coherent batches (0: the sweep kernel whatever the points look like)
+  int sweep_probe = 2;     // automatic sweep launches: sample the batch on the device first and let the one-pass kernel take coherent batches — 0: never (the sweep kernel whatever the points look like), 1: every launch, 2: every launch until three samples in a row came out unordered, then every 16th (abi_sweep.hip)
   int sweep_period = 0;    // sweep evaluation: ticks of 10 ns per sweep of the leading index (0: what the previous launch measured; 1: no clock, rows in sorted order; tests / tuning)
 };
 
@@ -76,6 +76,11 @@ struct KernelTag {
 };
 
 struct GridDesc {
+  // Per-LAUNCH settings (set on a private copy of the handle's description by abi_sweep.hip, never on the handle's own):
+  // an automatic sweep launch is a sampling kernel + the sweep kernel + the one-pass kernel, the latter two gated by the
+  // sample's verdict word in device memory (k_linear_sweep.hip::k_sweep_probe).
+  const unsigned* launch_gate = nullptr;  // one-pass kernels: do nothing unless this word is non-zero (few, fat workgroups)
+  bool sweep_gated = false;               // sweep kernels: do nothing if the scratch block's verdict word is set
   int method = kLinear;
   int kind = kRegular;
   int dtype = kF64;
@@ -223,10 +228,13 @@ int cubic_sweep_applies(const GridDesc& g, size_t npts);   // k_cubic_sweep.hip 
 hipError_t launch_cubic_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
                               void* work, hipStream_t stream);
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                               void* work, hipStream_t stream, bool gated = false);
-// 3-D multilinear, automatic path: the sampling kernel whose verdict (a word of the scratch block, at this offset) gates the
-// sweep launch (gated = true) and the brick launch (launch_linear_brick's `gate`) enqueued behind it
-hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream);
+                               void* work, hipStream_t stream);
+// Automatic sweep launches of the handles sweep_probe_applies() names: the sampling kernel whose verdict (a word of the
+// scratch block, at this offset) gates the sweep launch (GridDesc::sweep_gated) and the one-pass launch
+// (GridDesc::launch_gate) enqueued behind it
+bool sweep_probe_applies(const GridDesc& g);
+hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream,
+                              unsigned* host_word = nullptr, unsigned seq = 0);
 size_t sweep_probe_word_offset();
 
 template <typename T>
@@ -256,7 +264,7 @@ void brick_j4_geometry(const GridDesc& g, unsigned nb[3], size_t* bytes);  // f3
 hipError_t build_bricks(const GridDesc& g, void* bricks, hipStream_t stream);
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                               unsigned long long* first_bad, hipStream_t stream, const unsigned* gate = nullptr);
+                               unsigned long long* first_bad, hipStream_t stream);
 
 // 1-D multilinear-rectilinear from per-bucket records (k_linear1_records.hip).
 size_t records1_bytes(const GridDesc& g, int M);

@@ -83,6 +83,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
     a.crec[d] = (g.kind == kRectilinear && g.axis_crec_bytes)
                     ? reinterpret_cast<const CubicCellRecord<T>*>(static_cast<const unsigned char*>(g.axis_image) + g.axis_crec_off[d]) : nullptr;
   unsigned blocks = grid_blocks(npts, 1, g.cfg);
+  a.gate = scatter ? nullptr : g.launch_gate;
   a.eighth = 0;
   if (scatter && g.cfg.deal && blocks >= 64) {
     blocks &= ~7u;  // eight equal XCD shares; the grid-stride loop covers what the rounding drops

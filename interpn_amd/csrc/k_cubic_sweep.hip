@@ -121,6 +121,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
   r.out = a.out;
   r.npts = npts;
   a.scatter = nullptr;
+  a.gate = nullptr;
   a.index_base = 0;
   a.eighth = 0;
   a.linearize = g.linearize;
@@ -164,6 +165,8 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
   while (((g.n[KD] - 2) >> r.key_shift) >= 64) ++r.key_shift;
   r.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
   r.period_default = 4000;  // 40 us: a round of ten cubic rows (the kernel measures from its first launch on)
+  r.gated = g.sweep_gated ? 1u : 0u;
+  r.stamps = nullptr;
   r.work = static_cast<SweepWork*>(work);
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   if (g.kind == kRegular) return g.fma ? go<T, N, false, true>(g, s, cus, stream) : go<T, N, false, false>(g, s, cus, stream);

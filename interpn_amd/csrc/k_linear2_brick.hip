@@ -36,6 +36,7 @@ struct Brick2Args {
   int n[2];
   AxisArgs<T, 2> ax;
   unsigned nbj;
+  const unsigned* gate;  // gated launch (GridDesc::launch_gate): null, or a word that must be non-zero for this launch to do anything
 };
 
 // swap with the neighbouring lane (lane ^ 1): quad_perm [1,0,3,2]
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(kBlock) k_linear2_brick(const Brick2Args<T> a)
   typedef T T2 __attribute__((ext_vector_type(2)));
   constexpr int KW = Brick2Geom<T>::KW;
   constexpr int SJ = Brick2Geom<T>::SJ;
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (launch-uniform)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   LaneAxes<T, 2> la;
   if constexpr (RECT && AXR != 0) la = load_lane_axes<T, 2, AXR>(a.ax);
@@ -299,7 +301,9 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   bool aligned = (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0;
   for (int d = 0; d < 2; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
   const int ppl = (aligned && g.cfg.ppl != 1) ? 2 : 1;
-  const unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1)) : grid_blocks(npts, ppl, g.cfg);
+  unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1)) : grid_blocks(npts, ppl, g.cfg);
+  a.gate = g.launch_gate;
+  if (a.gate && g.cfg.gated_iters > 1) blocks = (blocks + (unsigned)g.cfg.gated_iters - 1) / (unsigned)g.cfg.gated_iters;  // few, fat workgroups: mostly they return at once
 #define GO2(RECT, FMA, AXR, PPL) do { g.tag.set("k_linear2_brick", {RECT, FMA, AXR, PPL}, 0b0011u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA, AXR, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
 #define GO(RECT, FMA, AXR) do { if (ppl == 2) GO2(RECT, FMA, AXR, 2); else GO2(RECT, FMA, AXR, 1); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
@@ -378,6 +382,8 @@ static hipError_t launch2_t(const GridDesc& g, const void* const* obs, void* out
   r.per_shard = (r.rounds + 7u) / 8u;
   r.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
   r.period_default = 2500;
+  r.gated = g.sweep_gated ? 1u : 0u;
+  r.stamps = nullptr;
   r.work = static_cast<SweepWork*>(work);
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   unsigned blocks = cus;

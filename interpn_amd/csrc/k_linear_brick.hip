@@ -152,10 +152,10 @@ static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds,
 
 template <typename T, int N>
 static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_t npts, unsigned long long* first_bad,
-                           hipStream_t stream, const unsigned* gate) {
+                           hipStream_t stream) {
   typedef typename LeafVec<T, 2>::type P;
   BrickArgs<T, N> a;
-  a.gate = gate;
+  a.gate = g.launch_gate;
   a.bricks = static_cast<const T*>(g.bricks);
   a.out = out;
   a.first_bad = first_bad;
@@ -200,17 +200,17 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
 
 template <typename T>
 hipError_t launch_linear_brick(const GridDesc& g, const T* const* obs, T* out, size_t npts,
-                               unsigned long long* first_bad, hipStream_t stream, const unsigned* gate) {
+                               unsigned long long* first_bad, hipStream_t stream) {
   switch (g.ndims) {
-    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream, gate);
-    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream, gate);
-    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream, gate);
-    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream, gate);
+    case 3: return launch_n<T, 3>(g, obs, out, npts, first_bad, stream);
+    case 4: return launch_n<T, 4>(g, obs, out, npts, first_bad, stream);
+    case 5: return launch_n<T, 5>(g, obs, out, npts, first_bad, stream);
+    case 6: return launch_n<T, 6>(g, obs, out, npts, first_bad, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-template hipError_t launch_linear_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t, const unsigned*);
-template hipError_t launch_linear_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t, const unsigned*);
+template hipError_t launch_linear_brick<double>(const GridDesc&, const double* const*, double*, size_t, unsigned long long*, hipStream_t);
+template hipError_t launch_linear_brick<float>(const GridDesc&, const float* const*, float*, size_t, unsigned long long*, hipStream_t);
 
 }  // namespace interpn

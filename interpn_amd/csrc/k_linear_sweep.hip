@@ -10,15 +10,27 @@ namespace {
 
 constexpr int kSweepRows = 12;       // f64: rows of 64 points per wave and round in registers: three waves per SIMD at 168 VGPRs ...
 constexpr int kSweepParked = 4;      // ... + rows parked in LDS between the sort and their turn (linear_sweep.h KL): 156 of a CU's 160 KiB; 64^3: 0.925 (two rows) -> 0.90 ms
-constexpr int kSweepParkedRect = 2;  // rectilinear grids, axes in lanes: the cell search's registers leave room for two (four spill 7)
-constexpr int kSweepRowsF32 = 24;    // f32: half the registers per point
+#ifndef INTERPN_SWEEP_RECT_PARKED
+#define INTERPN_SWEEP_RECT_PARKED 2
+#endif
+#ifndef INTERPN_SWEEP_RECT_ROWS
+#define INTERPN_SWEEP_RECT_ROWS 12
+#endif
+constexpr int kSweepParkedRect = INTERPN_SWEEP_RECT_PARKED;  // rectilinear grids, axes in lanes: the cell search's registers leave room for two (four spill 7)
+#ifndef INTERPN_SWEEP_F32_ROWS
+#define INTERPN_SWEEP_F32_ROWS 24
+#endif
+#ifndef INTERPN_SWEEP_F32_PARKED
+#define INTERPN_SWEEP_F32_PARKED 0
+#endif
+constexpr int kSweepRowsF32 = INTERPN_SWEEP_F32_ROWS;    // f32: half the registers per point
 constexpr int kSweepThreads = 768;   // one workgroup per CU
 constexpr int kSweepRowsF32Rect = 20;  // ... less the registers of the cell search (24 rows spill 6-29 VGPRs there)
-template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? kSweepRows : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
-template <typename T, bool RECT = false> constexpr int sweep_parked() { return sizeof(T) == 8 ? (RECT ? kSweepParkedRect : kSweepParked) : 0; }
+template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? (RECT ? INTERPN_SWEEP_RECT_ROWS : kSweepRows) : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
+template <typename T, bool RECT = false> constexpr int sweep_parked() { return sizeof(T) == 8 ? (RECT ? kSweepParkedRect : kSweepParked) : (RECT ? 0 : INTERPN_SWEEP_F32_PARKED); }
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
 constexpr size_t kSweepPointsPerCu = (size_t)(kSweepRows + kSweepParked) * kSweepThreads;
-constexpr size_t kSweepPointsPerCuF32 = (size_t)kSweepRowsF32 * kSweepThreads;
+constexpr size_t kSweepPointsPerCuF32 = (size_t)(kSweepRowsF32 + INTERPN_SWEEP_F32_PARKED) * kSweepThreads;
 // LDS the axis image of a rectilinear grid may take beside the waves' regions (92 KiB of a CU's 160): what
 // fill_axis_args allows the brick kernels (20 KiB) — per-bucket records of up to ~500 coordinates per axis
 constexpr size_t kSweepAxisLds = 20 * 1024;
@@ -65,7 +77,7 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if (g.sweep_table_bytes >= (1ull << 32)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
   const size_t lds = g.kind == kRectilinear
-                         ? (size_t)SweepLds<double, kSweepRows, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParkedRect>::kWorkgroup + kSweepAxisLds
+                         ? (size_t)SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWorkgroup + kSweepAxisLds
                          : (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup;  // (the f32 shapes need no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
@@ -79,7 +91,7 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   // (f64 32^3 / 48^3: 0.92-0.95 against 0.99-1.01 ms per 1e8 points, f32 48^3 / 64^3: 0.65-0.66 against 0.78-0.79).
   const bool beyond_l2 = g.sweep_table_bytes > thresholds(g.cfg).table_l2_sized;
   const size_t cus = (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
-  const size_t per_cu = g.dtype == kF64 ? (size_t)(kSweepRows + (g.kind == kRectilinear ? kSweepParkedRect : kSweepParked)) * kSweepThreads : kSweepPointsPerCuF32;
+  const size_t per_cu = g.dtype == kF64 ? (size_t)(g.kind == kRectilinear ? INTERPN_SWEEP_RECT_ROWS + kSweepParkedRect : kSweepRows + kSweepParked) * kSweepThreads : kSweepPointsPerCuF32;
   const size_t rounds = g.dtype == kF64 ? (beyond_l2 ? 4 : 8) : (beyond_l2 ? 3 : 6);  // (f32, third session: 80^3 from 9e6 points, 128^3 from 6e6; 64^3 — L2-resident — from 2.4e7)
   if (npts < rounds * per_cu * cus) return 1;
   return 2;
@@ -119,27 +131,33 @@ static hipError_t go_layout(const GridDesc& g, const SweepArgs<T>& s, unsigned b
 }
 
 // ---- which kernel for a large batch: decided on the device from a sample -----------------------------------------------
-// The sweep kernel is the faster one on points in no particular order (it makes the locality they lack); on batches that are
-// coherent as they stand — re-gridding onto a finer lattice with the last dimension fastest, clustered points — the one-pass
-// brick kernel is (neighbouring lanes already share lines and it runs eight waves per SIMD: 64^3 f64, 1e8 points: lattice
-// 0.72 against 0.88 ms, one cell 0.66 against 0.80; profiles/r06_obs_distributions.jsonl).  The host cannot look at the points
-// without a synchronisation, so an automatic launch is three: this kernel samples kProbeRows rows of 64 consecutive points
-// spread over the batch, counts how often a point's table line differs from its predecessor's, and leaves the verdict in the
-// scratch block; the sweep kernel and the brick kernel behind it are both enqueued, and the one the verdict is against
-// returns at once.  Unordered points change line at every step (63 of 63), a fine lattice at a few per row.
+// The sweep kernels are the faster ones on points in no particular order (they make the locality such points lack); on
+// batches that are coherent as they stand — re-gridding onto a finer lattice with the last dimension fastest, clustered
+// points — the one-pass kernels are (neighbouring lanes already share lines and they run eight waves per SIMD: 64^3 f64
+// multilinear, 1e8 points: lattice 0.72 against 0.88 ms, one cell 0.66 against 0.80; nearest 128^3 0.54 against 0.69, 1000^2
+// 0.41 against 0.56; 2-D multilinear 0.52 against 0.57; 2-D multicubic 0.34 against 0.38; profiles/r06_obs_*.jsonl).  The
+// host cannot look at the points without a synchronisation, so an automatic launch is three: this kernel samples kProbeRows
+// rows of 64 consecutive points spread over the batch, counts how often a point's table line differs from its
+// predecessor's, and leaves the verdict in the scratch block; the sweep kernel and the one-pass kernel behind it are both
+// enqueued, and the one the verdict is against returns at once (+0.8 % on unordered points).  Unordered points change
+// line at every step (63 of 63), a fine lattice at a few per row.
 constexpr unsigned kProbeRows = 256;
-template <typename T>
+template <typename T, int N>
 struct ProbeArgs {
-  const T* obs[3];
+  const T* obs[N];
   size_t npts;
-  T start[3], scale[3];  // ~ cell index = (x - start) * scale (a hint, like the sweep's sort key)
-  int top[3];            // n - 2
-  int sk;                // cells along the last dimension that share a brick line
+  T start[N], scale[N];  // ~ cell index = (x - start) * scale (a hint, like the sweep's sort key)
+  int top[N];            // n - 2
+  int sk;                // cells along the last dimension that share a line of the one-pass kernel's table (at least)
   SweepWork* work;
+  // the verdict for the HOST as well (abi_sweep.hip: it thins the sampling out once the batches of a handle keep coming out
+  // unordered): (seq << 1 | coherent) into a pinned word, or null
+  unsigned* host_word;
+  unsigned seq;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256) k_sweep_probe(const ProbeArgs<T> p) {
+template <typename T, int N>
+__global__ void __launch_bounds__(256) k_sweep_probe(const ProbeArgs<T, N> p) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6);
   const unsigned rows = gridDim.x * 4u;
@@ -148,10 +166,10 @@ __global__ void __launch_bounds__(256) k_sweep_probe(const ProbeArgs<T> p) {
   const size_t at = (size_t)((unsigned long long)row * (slots - 1u) / (rows > 1u ? rows - 1u : 1u)) * 64u + lane;
   unsigned id = 0;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
+  for (int d = 0; d < N; ++d) {
     const T u = (p.obs[d][at] - p.start[d]) * p.scale[d];
     const int c = u >= (T)1 ? (u < (T)p.top[d] ? (int)u : p.top[d]) : 0;  // (NaN: 0)
-    id = id * 0x9E3779B1u + (unsigned)(d == 2 ? c / p.sk : c);
+    id = id * 0x9E3779B1u + (unsigned)(d == N - 1 ? c / p.sk : c);
   }
   const unsigned prev = (unsigned)__shfl_up((int)id, 1);
   const unsigned changes = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane > 0 && id != prev));
@@ -161,17 +179,21 @@ __global__ void __launch_bounds__(256) k_sweep_probe(const ProbeArgs<T> p) {
     if (atomicAdd(&p.work->probe_done, 1u) == rows - 1u) {
       const unsigned total = atomicAdd(&p.work->probe_changes, 0u);
       // coherent: fewer than a quarter of the sampled points start a new line
-      atomicExch(&p.work->take_brick, total * 4u < rows * 63u ? 1u : 0u);
+      const unsigned coherent = total * 4u < rows * 63u ? 1u : 0u;
+      atomicExch(&p.work->take_brick, coherent);
+      if (p.host_word) __hip_atomic_store(p.host_word, (p.seq << 1) | coherent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicExch(&p.work->probe_changes, 0u);
       atomicExch(&p.work->probe_done, 0u);
     }
   }
 }
 
-template <typename T>
-static hipError_t probe_t(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream) {
-  ProbeArgs<T> p;
-  for (int d = 0; d < 3; ++d) {
+template <typename T, int N>
+static hipError_t probe_t(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream, unsigned* host_word, unsigned seq) {
+  ProbeArgs<T, N> p;
+  p.host_word = host_word;
+  p.seq = seq;
+  for (int d = 0; d < N; ++d) {
     p.obs[d] = static_cast<const T*>(obs[d]);
     if (g.kind == kRectilinear) {
       const double span = g.bound_hi[d] - g.bound_lo[d];
@@ -184,16 +206,30 @@ static hipError_t probe_t(const GridDesc& g, const void* const* obs, size_t npts
     if (!(p.scale[d] > 0) || !(p.scale[d] < (T)1e30)) p.scale[d] = 0;
     p.top[d] = g.n[d] - 2;
   }
-  p.sk = g.dtype == kF64 ? BrickGeom<double, 0>::SK : (g.brick_cell == 2 ? BrickGeom<float, 2>::SK : BrickGeom<float, 0>::SK);
+  const int per_line = (int)(128 / sizeof(T));
+  if (g.method == kLinear && N == 3) p.sk = g.dtype == kF64 ? BrickGeom<double, 0>::SK : (g.brick_cell == 2 ? BrickGeom<float, 2>::SK : BrickGeom<float, 0>::SK);
+  else if (g.method == kLinear) p.sk = per_line / 2 - 1;  // 2 x KW bricks stepped KW - 1 (k_linear2_brick.hip)
+  else if (g.method == kNearest) p.sk = per_line;         // the C-ordered grid
+  else p.sk = 1;                                          // tiles: a footprint per point (cubic_brick.h)
   p.npts = npts;
   p.work = static_cast<SweepWork*>(work);
-  hipLaunchKernelGGL(k_sweep_probe<T>, dim3(kProbeRows / 4), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((k_sweep_probe<T, N>), dim3(kProbeRows / 4), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 
-hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream) {
-  if (g.method != kLinear || g.ndims != 3 || !work || npts < (size_t)kProbeRows * 64) return hipErrorInvalidValue;
-  return g.dtype == kF64 ? probe_t<double>(g, obs, npts, work, stream) : probe_t<float>(g, obs, npts, work, stream);
+// Which handles' automatic sweep launches are gated by a sample: those whose one-pass kernel wins on coherent batches
+// (measured: 3-D / 2-D multilinear, nearest-neighbour, 2-D multicubic; the 3-D multicubic sweep wins on lattices too).
+bool sweep_probe_applies(const GridDesc& g) {
+  if (g.cfg.sweep >= 0 || g.cfg.sweep_probe == 0) return false;  // (sweep_probe: 1 = every automatic launch, 2 = thinned out by the host, abi_sweep.hip)
+  if (g.ndims != 2 && g.ndims != 3) return false;
+  if (g.method == kCubic) return g.ndims == 2;
+  return g.method == kLinear ? g.bricks != nullptr : g.method == kNearest;
+}
+
+hipError_t launch_sweep_probe(const GridDesc& g, const void* const* obs, size_t npts, void* work, hipStream_t stream, unsigned* host_word, unsigned seq) {
+  if ((g.ndims != 2 && g.ndims != 3) || !work || npts < (size_t)kProbeRows * 64) return hipErrorInvalidValue;
+  if (g.ndims == 3) return g.dtype == kF64 ? probe_t<double, 3>(g, obs, npts, work, stream, host_word, seq) : probe_t<float, 3>(g, obs, npts, work, stream, host_word, seq);
+  return g.dtype == kF64 ? probe_t<double, 2>(g, obs, npts, work, stream, host_word, seq) : probe_t<float, 2>(g, obs, npts, work, stream, host_word, seq);
 }
 
 size_t sweep_probe_word_offset() { return offsetof(SweepWork, take_brick); }
@@ -201,9 +237,9 @@ size_t sweep_probe_word_offset() { return offsetof(SweepWork, take_brick); }
 // `work`: a zeroed SweepWork block that no other launch in flight uses (abi_sweep.hip).
 template <typename T>
 static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                           void* work, hipStream_t stream, bool gated) {
+                           void* work, hipStream_t stream) {
   SweepArgs<T> s;
-  s.gated = gated ? 1u : 0u;
+  s.gated = g.sweep_gated ? 1u : 0u;
   BrickArgs<T, 3>& a = s.b;
   a.gate = nullptr;
   a.bricks = static_cast<const T*>(g.sweep_bricks);
@@ -276,7 +312,7 @@ static hipError_t launch_t(const GridDesc& g, const void* const* obs, void* out,
 }
 
 hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* out, size_t npts, unsigned long long* first_bad,
-                               void* work, hipStream_t stream, bool gated) {
+                               void* work, hipStream_t stream) {
   if (g.method == kNearest) return launch_nearest_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kCubic) return launch_cubic_sweep(g, obs, out, npts, first_bad, work, stream);
   if (g.method == kLinear && g.ndims == 2) return launch_linear2_sweep(g, obs, out, npts, first_bad, work, stream);
@@ -284,8 +320,8 @@ hipError_t launch_linear_sweep(const GridDesc& g, const void* const* obs, void* 
   for (int d = 0; d < 3; ++d)
     if (reinterpret_cast<uintptr_t>(obs[d]) % 16) return hipErrorInvalidValue;  // the caller checked (abi_sweep.hip)
   if (reinterpret_cast<uintptr_t>(out) % 16) return hipErrorInvalidValue;
-  if (g.dtype == kF64) return launch_t<double>(g, obs, out, npts, first_bad, work, stream, gated);
-  return launch_t<float>(g, obs, out, npts, first_bad, work, stream, gated);
+  if (g.dtype == kF64) return launch_t<double>(g, obs, out, npts, first_bad, work, stream);
+  return launch_t<float>(g, obs, out, npts, first_bad, work, stream);
 }
 
 }  // namespace interpn

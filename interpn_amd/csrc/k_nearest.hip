@@ -23,6 +23,7 @@ struct NearestArgs {
   int n[N];
   unsigned long long stride[N];
   AxisArgs<T, N> ax;
+  const unsigned* gate;  // gated launch (GridDesc::launch_gate): null, or a word that must be non-zero for this launch to do anything
 };
 
 template <typename T, int N, bool RECT, bool FMA, bool LDS, int AXR, int PPL>
@@ -117,6 +118,7 @@ __device__ __forceinline__ void nearest_body(const NearestArgs<T, N>& a, const u
 // aligned to 2*sizeof(T); the launcher checks).
 template <typename T, int N, bool RECT, bool FMA, int AXR = 0, int PPL = 1>
 __global__ void __launch_bounds__(kBlock) k_nearest(const NearestArgs<T, N> a) {
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (launch-uniform)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if constexpr (RECT && AXR != 0) {
     nearest_body<T, N, RECT, FMA, false, AXR, PPL>(a, nullptr);
@@ -209,8 +211,11 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   for (int d = 0; d < N; ++d) aligned = aligned && (reinterpret_cast<uintptr_t>(obs[d]) % (2 * sizeof(T))) == 0;
   const int ppl = (aligned && g.cfg.ppl != 1) ? 2 : 1;
   // lane-resident axes cost six small loads per wave: four rows per wave amortise them
-  const unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1))
-                                                                            : grid_blocks(npts, ppl, g.cfg);
+  unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1))
+                                                                      : grid_blocks(npts, ppl, g.cfg);
+  a.gate = g.launch_gate;
+  // few, fat workgroups: mostly they return at once (half the brick kernels' factor: at 16 this kernel loses 5 % on the lattices it is for)
+  if (a.gate && g.cfg.gated_iters > 3) blocks = (blocks + (unsigned)(g.cfg.gated_iters / 2) - 1) / (unsigned)(g.cfg.gated_iters / 2);
 #define GO2(RECT, FMA, AXR, PPL) do { g.tag.set("k_nearest", {N, RECT, FMA, AXR, PPL}, 0b00110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA, AXR, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
 #define GO(RECT, FMA, AXR) do { if (ppl == 2) GO2(RECT, FMA, AXR, 2); else GO2(RECT, FMA, AXR, 1); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }
@@ -301,6 +306,8 @@ static hipError_t launch_sweep_n(const GridDesc& g, const void* const* obs, void
   r.per_shard = (r.rounds + 7u) / 8u;
   r.period = g.cfg.sweep_period > 0 ? (unsigned)g.cfg.sweep_period : 0u;
   r.period_default = 2000;
+  r.gated = g.sweep_gated ? 1u : 0u;
+  r.stamps = nullptr;
   r.work = static_cast<SweepWork*>(work);
   const unsigned cus = (unsigned)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256);
   unsigned blocks = cus;

@@ -210,12 +210,6 @@ struct LeadReduce<T, 0, FMA> {
 //             (PPL = 2, regular grids, full rows only — the harness launches whole rows).  Correct
 //             results; kept out of the library because it measured no gain.
 // Their outputs are meaningless by construction.
-template <typename T>
-__device__ __forceinline__ T ablate_coord(size_t i, int d, T start, T step, int n) {
-  unsigned h = (unsigned)i * 2654435761u + (unsigned)(i >> 32) * 40503u + (unsigned)d * 0x9E3779B9u;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return start + step * ((T)(n - 1) * ((T)(h >> 8) * (T)(1.0 / 16777216.0)));
-}
 
 template <typename T, int N, bool RECT, bool FMA, int SI, int SJ, int PPL, int AXR = 0, int ABL = 0, int CELL = 0>
 __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a) {
@@ -225,7 +219,7 @@ __global__ void __launch_bounds__(kBlock) k_linear_brick(const BrickArgs<T, N> a
   typedef BrickGeom<T, CELL> Geom;
   constexpr int L = N - 3;
   constexpr int SK = Geom::SK;
-  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (workgroup-uniform)
+  if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (launch-uniform)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   P* lds_piece = reinterpret_cast<P*>(smem_raw);                                               // [quad][r][kPieceRow]
   lds_u32* lds_off = reinterpret_cast<lds_u32*>(smem_raw + kBlock * kPieceRow * sizeof(P));  // [quad][piece][r]

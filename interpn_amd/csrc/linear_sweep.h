@@ -34,25 +34,11 @@
 #pragma once
 
 #include "linear_brick.h"
+#include "sweep_rounds.h"  // SweepWork; the scaffold the other sweep kernels share (this kernel keeps its own copy: see below)
 
 namespace interpn {
 
-// Work words of the launches through one scratch block (device memory).  Zero before the first
-// launch; the last wave of every launch leaves everything but `period` zero again, so launches that
-// follow each other on a stream need no reset in between.
-struct SweepWork {
-  unsigned head[8][32];        // next round of shard x (one 128-byte line each)
-  unsigned done[32];           // waves that have finished
-  unsigned long long ticks;    // sum over waves of the ticks spent in rounds ...
-  unsigned rounds;             // ... and of the rounds they took
-  unsigned period;             // ticks per sweep for the next launch (0: the launch's default)
-  // the sampling kernel in front of an automatic launch (k_linear_sweep.hip::k_sweep_probe): its counters (left zero)
-  // and its verdict for the two gated launches behind it — non-zero: the batch is coherent as it stands, the brick
-  // kernel takes it and the sweep kernel's waves return at once
-  unsigned probe_changes, probe_done, take_brick;
-  unsigned pad[25];
-};
-static_assert(sizeof(SweepWork) == 10 * 128, "one line per counter");
+// (SweepWork — the work words of the launches through one scratch block — lives in sweep_rounds.h)
 
 template <typename T>
 struct SweepArgs {
@@ -65,7 +51,7 @@ struct SweepArgs {
   unsigned per_shard;  // rounds per shard (8 shards)
   unsigned period;     // > 0: ticks per sweep, overriding the measured one; 1: rows in sorted order (no clock)
   unsigned period_default;  // before anything has been measured
-  unsigned gated;           // != 0: do nothing if work->take_brick is set (see SweepWork)
+  unsigned gated;           // != 0: do nothing if work->take_brick is set (see SweepWork, sweep_rounds.h)
   SweepWork* work;
   unsigned long long* stamps;  // STAMPS builds (tools/): 8 words per wave, see the kernel's end
 };

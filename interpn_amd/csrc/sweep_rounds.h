@@ -5,16 +5,37 @@
 // rounds on demand from eight counters; every launch measures the period for the next (read linear_sweep.h's head for the
 // why and the measurements) — as ONE function with the row left to the caller: `row_fn(integral_constant<int, k>, xr, gi)`
 // evaluates the wave's row k (xr: the lane's point, gi: its index in the batch) and returns the lane's result.
-// Used by cubic_sweep.h (3-D multicubic), k_linear2_brick.hip (2-D multilinear) and k_nearest.hip (2-D / 3-D nearest
-// neighbour).  linear_sweep.h — the headline kernel, written first — keeps its own copy: its code generation (registers to the
-// last one: 168, no spills) was tuned with the rows in place and is not to move.
+// Used by cubic_sweep.h (3-D / 2-D multicubic), k_linear2_brick.hip (2-D multilinear) and k_nearest.hip (2-D / 3-D nearest
+// neighbour).  linear_sweep.h — the headline kernel, written first — keeps its own copy of these lines.  Round 6 moved it
+// onto this function (it compiles, 259 sweep tests bit-identical, the f64 shapes free of scratch with OPAQUE_LANE = 1) and
+// measured it on one box against the copy: cfg2 +0.6 % and +1.3 % on two boxes, the f32 shapes 2-9 % slower (24 rows in
+// registers spill 3-24 here, 20 + 4 parked do not) — the copy stays (profiles/REJECTED.md); the ABL / STAMPS hooks and the
+// CNT_BYTES / OPAQUE_LANE parameters that the move needed stay too.
 #pragma once
 
 #include <type_traits>
 
-#include "linear_sweep.h"  // SweepWork
+#include "interpn_device.h"
 
 namespace interpn {
+
+// Work words of the launches through one scratch block (device memory).  Zero before the first
+// launch; the last wave of every launch leaves everything but `period` zero again, so launches that
+// follow each other on a stream need no reset in between.
+struct SweepWork {
+  unsigned head[8][32];        // next round of shard x (one 128-byte line each)
+  unsigned done[32];           // waves that have finished
+  unsigned long long ticks;    // sum over waves of the ticks spent in rounds ...
+  unsigned rounds;             // ... and of the rounds they took
+  unsigned period;             // ticks per sweep for the next launch (0: the launch's default)
+  // the sampling kernel in front of an automatic launch (k_linear_sweep.hip::k_sweep_probe): its counters (left zero)
+  // and its verdict for the two gated launches behind it — non-zero: the batch is coherent as it stands, the one-pass
+  // kernel takes it and the sweep kernel's waves return at once
+  unsigned probe_changes, probe_done, take_brick;
+  unsigned pad[25];
+};
+static_assert(sizeof(SweepWork) == 10 * 128, "one line per counter");
+
 
 // f(integral_constant<int, I>) for I = FROM .. TO - 1 (a row's index must be a constant: its coordinates live in registers)
 template <int FROM, int TO, typename F>
@@ -38,17 +59,26 @@ struct SweepRounds {
   unsigned per_shard;      // rounds per shard (8 shards)
   unsigned period;         // > 0: ticks of 10 ns per sweep, overriding the measured one; 1: rows in sorted order (no clock)
   unsigned period_default; // before anything has been measured
+  unsigned gated;          // != 0: do nothing if work->take_brick is set (see SweepWork)
   SweepWork* work;
+  // measurement builds only (tools/): ABL == 2 makes the coordinates up from the point index on this grid and stores
+  // nothing; STAMPS leaves 8 words per wave (start | end | ticks outside the rows | ticks in rows | XCD | last first row |
+  // rounds | period)
+  T fake_start[N], fake_step[N];
+  int fake_n[N];
+  unsigned long long* stamps;
 };
 
 // LDS per wave: a row buffer (the sort's and the results' exchange; MIN_ROW_BYTES: what the caller's rows need of the same
 // bytes in between, e.g. a tile image), the parked rows, the sort's counters.  Behind the waves' regions: 16 bytes of the scaffold.
-template <typename T, int N, int K, int KL, unsigned MIN_ROW_BYTES = 0>
+// CNT_BYTES: the counters' region, larger where the caller's rows use those bytes too (linear_sweep.h: 1 KiB of piece offsets).
+template <typename T, int N, int K, int KL, unsigned MIN_ROW_BYTES = 0, unsigned CNT_BYTES = 64u * 4u * 2u>
 struct SweepRoundsLds {
   static constexpr unsigned kRowOnly = 64u * K * sizeof(T);
   static constexpr unsigned kRow = kRowOnly > MIN_ROW_BYTES ? kRowOnly : MIN_ROW_BYTES;
   static constexpr unsigned kPark = 64u * KL * (unsigned)N * sizeof(T);
-  static constexpr unsigned kCnt = 64u * 4u * 2u;
+  static constexpr unsigned kCnt = CNT_BYTES;
+  static_assert(CNT_BYTES >= 64u * 4u * 2u, "64 counters + 64 first positions");
   static constexpr unsigned kWave = kRow + kPark + kCnt;
   static constexpr unsigned kWorkgroup = 16;
   static_assert(kRow + kPark >= 64u * (K + KL) * sizeof(T), "the result exchange spans the row buffer and the parked rows' bytes");
@@ -57,8 +87,11 @@ struct SweepRoundsLds {
 
 // Call with the whole workgroup, once, after whatever the kernel stages into LDS behind the waves' regions (the barrier in here
 // is the only one).  KEYDIM: the coordinate the points are ordered by.
-template <typename T, int N, int K, int KL, int THREADS, int KEYDIM, typename L, typename RowFn>
+// OPAQUE_LANE: see the round's first lines (a per-kernel choice: it trades registers held across the persistent loop for a few
+// dozen integer instructions per round; which way a shape spills less is found by compiling it, tools/kernel_resources.py)
+template <typename T, int N, int K, int KL, int THREADS, int KEYDIM, typename L, int ABL = 0, bool STAMPS = false, int OPAQUE_LANE = 0, typename RowFn>
 __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsigned char* smem_raw, RowFn&& row_fn) {
+  if (sr.gated && __hip_atomic_load(&sr.work->take_brick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // (launch-uniform: no work word is touched)
   constexpr int PPV = 16 / (int)sizeof(T);
   constexpr int KT = K + KL;
   static_assert(KT % PPV == 0 && KT % 2 == 0 && K >= PPV && KT <= 32, "rows per wave and round");
@@ -92,6 +125,8 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
     return v;
   };
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_mark = t_begin, st_other = 0, st_rows = 0;
+  unsigned st_rot = 0;
   unsigned my_rounds = 0;
   unsigned ticket = take(shard);
   while (true) {
@@ -110,6 +145,13 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
     const unsigned r = shard * sr.per_shard + rr;
     ticket = take(shard);
     ++my_rounds;
+    // a copy of the lane id the optimiser cannot see through: what is derived from it inside a round (exchange addresses,
+    // source indices: ~40 per-lane constants) is then recomputed per round instead of being hoisted out of the persistent
+    // loop into registers the rows need (they spill)
+    unsigned ln = lane;
+    if constexpr (OPAQUE_LANE == 1) asm volatile("" : "+v"(ln));
+    unsigned ln2 = ln;  // (OPAQUE_LANE == 2: only the source indices of the result exchange)
+    if constexpr (OPAQUE_LANE == 2) asm volatile("" : "+v"(ln2));
     const size_t base = (size_t)r * kChunk;
     T x[KT][N];
     const bool full = base + kChunk <= sr.npts;
@@ -118,7 +160,13 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
       for (int d = 0; d < N; ++d)
 #pragma unroll
         for (int kv = 0; kv < KT / PPV; ++kv) {
-          const TV v = stream_load(reinterpret_cast<const TV*>(sr.obs[d] + base) + (kv * 64 + (int)lane));
+          TV v;
+          if constexpr (ABL == 2) {
+#pragma unroll
+            for (int h = 0; h < PPV; ++h) v[h] = ablate_coord<T>(base + (size_t)(kv * 64 + (int)ln) * PPV + h, d, sr.fake_start[d], sr.fake_step[d], sr.fake_n[d]);
+          } else {
+            v = stream_load(reinterpret_cast<const TV*>(sr.obs[d] + base) + (kv * 64 + (int)ln));
+          }
 #pragma unroll
           for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
         }
@@ -127,7 +175,7 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
       for (int d = 0; d < N; ++d)
 #pragma unroll
         for (int kv = 0; kv < KT / PPV; ++kv) {
-          const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
+          const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * ln;
           TV v;
 #pragma unroll
           for (int h = 0; h < PPV; ++h) v[h] = sr.absent[d];
@@ -142,7 +190,7 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
           for (int h = 0; h < PPV; ++h) x[PPV * kv + h][d] = v[h];
         }
     }
-    cnt[lane] = 0;
+    cnt[ln] = 0;
     wave_sync();
     unsigned pos[KT];
 #pragma unroll
@@ -154,14 +202,14 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
     }
     wave_sync();
     {
-      const unsigned mine_cnt = cnt[lane];
+      const unsigned mine_cnt = cnt[ln];
       unsigned incl = mine_cnt;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const unsigned up = (unsigned)__shfl_up((int)incl, off);
-        if (lane >= (unsigned)off) incl += up;
+        if (ln >= (unsigned)off) incl += up;
       }
-      cnt[64 + lane] = incl - mine_cnt;
+      cnt[64 + ln] = incl - mine_cnt;
     }
     wave_sync();
     unsigned rot = 0;
@@ -187,35 +235,39 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
       }
       wave_sync();
 #pragma unroll
-      for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + lane];
+      for (int k = 0; k < K; ++k) x[k][d] = row[k * 64 + ln];
       wave_sync();
     }
     unsigned src[KT / 2];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * lane + (k % PPV));
+    for (int k = 0; k < KT; ++k) row16[pos[k]] = (unsigned short)((k / PPV) * (64 * PPV) + PPV * ln2 + (k % PPV));
     wave_sync();
 #pragma unroll
-    for (int k2 = 0; k2 < KT / 2; ++k2) src[k2] = (unsigned)row16[(2 * k2) * 64 + lane] | ((unsigned)row16[(2 * k2 + 1) * 64 + lane] << 16);
+    for (int k2 = 0; k2 < KT / 2; ++k2) src[k2] = (unsigned)row16[(2 * k2) * 64 + ln] | ((unsigned)row16[(2 * k2 + 1) * 64 + ln] << 16);
     wave_sync();
+    if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
     T res[KT];
     sweep_static_for<0, KT>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       __builtin_amdgcn_sched_barrier(0);
       T xr[N];
 #pragma unroll
-      for (int d = 0; d < N; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + lane];
+      for (int d = 0; d < N; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + ln];
       const size_t gi = base + ((src[k / 2] >> (16 * (k & 1))) & 0xFFFFu);  // the point's index in the batch (>= npts: a place behind its end)
       res[k] = row_fn(kc, xr, gi);
       asm volatile("" : "+v"(res[k]));
     });
+    if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
 #pragma unroll
     for (int k = 0; k < KT; ++k) row[(src[k / 2] >> (16 * (k & 1))) & 0xFFFFu] = res[k];
     wave_sync();
 #pragma unroll
     for (int kv = 0; kv < KT / PPV; ++kv) {
-      const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * lane;
-      const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * lane]);
-      if (full || i0 + PPV - 1 < sr.npts) {
+      const size_t i0 = base + (size_t)kv * (64 * PPV) + PPV * ln;
+      const TV v = *reinterpret_cast<const TV*>(&row[kv * (64 * PPV) + PPV * ln]);
+      if constexpr (ABL == 2) {
+        if (v[0] == (T)123.456) stream_store(reinterpret_cast<TV*>(sr.out + i0), v);  // (never)
+      } else if (full || i0 + PPV - 1 < sr.npts) {
         stream_store(reinterpret_cast<TV*>(sr.out + i0), v);
       } else {
 #pragma unroll
@@ -252,6 +304,13 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
         atomicExch(&work->ticks, 0ull);
         atomicExch(&work->rounds, 0u);
         atomicExch(&work->done[0], 0u);
+      }
+    }
+    if constexpr (STAMPS) {
+      if (sr.stamps) {
+        unsigned long long* o = sr.stamps + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
+        o[0] = t_begin; o[1] = t_end; o[2] = st_other; o[3] = st_rows;
+        o[4] = xcc & 0xFu; o[5] = st_rot / 64u; o[6] = my_rounds; o[7] = period;
       }
     }
   }

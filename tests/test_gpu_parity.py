@@ -3104,6 +3104,7 @@ def test_automatic_path_samples_the_batch_on_the_device(oracle, kind, dtype):
     else:
         it = interpn_amd.Interpolator.rectilinear("linear", case.grids, case.vals)
     try:
+        it.set_option("sweep_probe", 1)  # a sample in front of every automatic launch (the default thins them out: next test)
         m = 272
         ax = torch.linspace(-1.02, 1.02, m, dtype=td, device=dev)
         lat = [t.reshape(-1)[:P].contiguous() for t in torch.meshgrid(ax, ax, ax, indexing="ij")]
@@ -3149,5 +3150,101 @@ def test_automatic_path_samples_the_batch_on_the_device(oracle, kind, dtype):
                     it.finish()
                 assert ei.value.first_bad_index == 7_000_003
                 assert torch.equal(out[:7_000_003], good[:7_000_003])
+    finally:
+        it.close()
+
+
+@pytest.mark.parametrize("method,dims,count", [("nearest", [128, 128, 128], 20_000_000), ("nearest", [1000, 1000], 20_000_000),
+                                               ("linear", [1000, 1000], 25_000_000), ("cubic", [512, 512], 30_000_000)],
+                         ids=["nearest3", "nearest2", "linear2", "cubic2"])
+def test_automatic_path_samples_the_batch_on_the_device_family(oracle, method, dims, count):
+    """The same device-side sample in front of the automatic launches of the other sweep kernels whose one-pass kernel wins on
+    coherent batches (nearest-neighbour 2-D / 3-D, 2-D multilinear, 2-D multicubic): a fine lattice goes to the one-pass
+    kernel, unordered points to the sweep kernel, the results are both forced kernels' bit for bit and the oracle's on a
+    sample (nearest/regular.rs:234-317, multilinear/regular.rs:268-283, multicubic/regular.rs:297-313)."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    nd = len(dims)
+    case = synthetic_case(method, "regular", nd, dims, 64, 6600 + sum(dims), np.float64, linearize=True, extrap=0.0, specials=False)
+    it = interpn_amd.Interpolator.regular(method, case.dims, case.starts, case.steps, case.vals, linearize_extrapolation=True)
+    try:
+        it.set_option("sweep_probe", 1)
+        m = int(np.ceil(count ** (1.0 / nd)))
+        ax = torch.linspace(-1.01, 1.01, m, dtype=torch.float64, device=dev)
+        lat = [t.reshape(-1)[:count].contiguous() for t in torch.meshgrid(*([ax] * nd), indexing="ij")]
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(12)
+        rnd = [torch.rand(count, dtype=torch.float64, device=dev, generator=gen) * 2.04 - 1.02 for _ in range(nd)]
+        sample = np.random.default_rng(8).choice(count, 50_000, replace=False)
+        for name, obs, verdict in (("lattice", lat, 1), ("random", rnd, 0)):
+            it.set_option("sweep", 1)
+            a = it.eval_tensors(obs).clone()
+            it.finish()
+            assert it.last_path == "sweep", (name, it.last_path, it.last_path_reason)
+            it.set_option("sweep", 0)
+            b = it.eval_tensors(obs).clone()
+            it.finish()
+            assert it.last_path == "in_place" and torch.equal(a, b), name
+            it.set_option("sweep", -1)
+            out = torch.full_like(a, -7.0)
+            it.eval_tensors(obs, out)
+            it.finish()
+            assert it.last_path == "sweep", (name, it.last_path, it.last_path_reason)
+            assert it.get_option("sweep_probe_took_brick") == verdict, name
+            assert torch.equal(out, a), name
+            sub = kat.Case("s", method, "regular", case.grids, case.vals, [o[sample].cpu().numpy() for o in obs], np.zeros(sample.size), 0.0, linearize=True)
+            assert np.array_equal(out[sample].cpu().numpy(), run_oracle(oracle, sub, True)), name
+    finally:
+        it.close()
+
+
+def test_automatic_path_thins_the_samples_out(oracle):
+    """Default policy of the automatic 3-D multilinear path (option sweep_probe = 2, abi_sweep.hip): the batch is sampled on
+    every launch until three samples in a row came out unordered, then on every 16th launch; one coherent verdict brings the
+    per-launch sample back.  The host learns the verdicts from a pinned word the sampling kernel writes, without ever
+    synchronising.  Whatever is skipped or taken, the results are the same bits."""
+    import torch
+
+    import interpn_amd
+
+    dev = torch.device("cuda:0")
+    n = 128
+    P = 14_000_000
+    case = synthetic_case("linear", "regular", 3, [n] * 3, 64, 6700, np.float64, extrap=0.0, specials=False)
+    it = interpn_amd.Interpolator.regular("linear", case.dims, case.starts, case.steps, case.vals)
+    try:
+        assert it.get_option("sweep_probe") == 2
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(13)
+        rnd = [torch.rand(P, dtype=torch.float64, device=dev, generator=gen) * 2.0 - 1.0 for _ in range(3)]
+        m = 242
+        ax = torch.linspace(-1.0, 1.0, m, dtype=torch.float64, device=dev)
+        lat = [t.reshape(-1)[:P].contiguous() for t in torch.meshgrid(ax, ax, ax, indexing="ij")]
+        it.set_option("sweep", 0)
+        want_rnd = it.eval_tensors(rnd).clone()
+        want_lat = it.eval_tensors(lat).clone()
+        it.finish()
+        it.set_option("sweep", -1)
+        seen = []
+        for _ in range(40):  # unordered batches: sampled at first, then mostly not
+            out = it.eval_tensors(rnd)
+            it.finish()
+            assert it.last_path == "sweep" and torch.equal(out, want_rnd)
+            seen.append(it.get_option("sweep_probe_took_brick"))
+        assert seen[0] == 0 and set(seen) <= {0, -1}
+        assert seen.count(-1) >= 20, seen          # most launches went without a sample ...
+        assert 0 in seen[8:], seen                 # ... but not all of them
+        seen = []
+        for _ in range(40):  # now a fine lattice: within 16 launches a sample finds it, from then on every launch is sampled
+            out = it.eval_tensors(lat)
+            it.finish()
+            assert torch.equal(out, want_lat)
+            seen.append(it.get_option("sweep_probe_took_brick"))
+        assert 1 in seen[:17], seen
+        first = seen.index(1)
+        assert all(v == 1 for v in seen[first + 2:]), seen
     finally:
         it.close()

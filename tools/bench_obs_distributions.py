@@ -84,6 +84,7 @@ def time_it(it, obs, out, reps=9):
 
 out = torch.empty(P, dtype=torch.float64, device=dev)
 reg = interpn_amd.Interpolator.regular("linear", [n] * 3, np.full(3, -1.0), np.full(3, step), vals)
+PROBE = int(os.environ.get("OBS_SWEEP_PROBE", "1"))  # 1: a sample in front of every automatic launch (the steady-state choice per distribution; the default, 2, thins the samples out and would carry one distribution's history into the next)
 gr = [g.copy() for _ in range(3)]
 rng = np.random.default_rng(2)
 for a in gr:
@@ -95,6 +96,7 @@ for dist in ("uniform", "one_cell", "sorted", "lattice_c", "lattice_f", "on_plan
         if dist == "half_nan" and kind == "regular":
             continue
         row = {"grid": n, "points": P, "dist": dist, "kind": kind}
+        it.set_option("sweep_probe", PROBE)
         for name, opt in (("sweep", 1), ("brick", 0), ("auto", -1)):
             it.set_option("sweep", opt)
             row[name + "_ms"] = round(time_it(it, obs, out), 4)
