@@ -982,6 +982,11 @@ def worker(args):
                 "table_MiB": round(tbytes / 2**20, 2),
                 "layout_steps": [si, sj],
                 "kernel_ms": round(kernel_ms, 4),
+                # how the automatic path chose its kernel for this batch: a device-side sample in front
+                # of the sweep launch sends coherent batches to the one-pass kernel; the host thins the samples out once they
+                # keep coming out unordered (policy 2), so most timed steps are ONE kernel, some are sample + sweep + gated launch
+                "auto_path_sample": {"policy": it.get_option("sweep_probe"),
+                                     "last_sampled_launch_took_one_pass_kernel": it.get_option("sweep_probe_took_brick")},
                 "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
                 "kernel_ms_min": round(float(np.min(m["step_ms"])), 4),
                 "kernel_ms_max": round(float(np.max(m["step_ms"])), 4),
