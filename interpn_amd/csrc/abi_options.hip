@@ -39,7 +39,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"bin_scramble", &c.bin_scramble, 0, 1},
       {"stage_timing", &c.stage_timing, 0, 1},
       {"axis_records", &c.axis_records, 0, 1},
-      {"sweep", &c.sweep, -1, 1},
+      {"sweep", &c.sweep, -1, 2},
       {"sweep_period", &c.sweep_period, 0, 1000000},
       {"sweep_probe", &c.sweep_probe, 0, 2},
       {"gated_iters", &c.gated_iters, 0, 4096},

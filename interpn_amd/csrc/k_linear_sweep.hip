@@ -220,7 +220,9 @@ static hipError_t probe_t(const GridDesc& g, const void* const* obs, size_t npts
 // Which handles' automatic sweep launches are gated by a sample: those whose one-pass kernel wins on coherent batches
 // (measured: 3-D / 2-D multilinear, nearest-neighbour, 2-D multicubic; the 3-D multicubic sweep wins on lattices too).
 bool sweep_probe_applies(const GridDesc& g) {
-  if (g.cfg.sweep >= 0 || g.cfg.sweep_probe == 0) return false;  // (sweep_probe: 1 = every automatic launch, 2 = thinned out by the host, abi_sweep.hip)
+  // option sweep: -1 automatic (thresholds, then the sample), 0 never, 1 the sweep kernel whatever the batch, 2 the sample
+  // decides whatever the batch's size (tests, the fuzzer); sweep_probe: 0 no sample, 1 every launch, 2 thinned out by the host
+  if (g.cfg.sweep == 0 || g.cfg.sweep == 1 || g.cfg.sweep_probe == 0) return false;
   if (g.ndims != 2 && g.ndims != 3) return false;
   if (g.method == kCubic) return g.ndims == 2;
   return g.method == kLinear ? g.bricks != nullptr : g.method == kNearest;

@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD", "INTERPN_HIP_CUBIC_RECORDS")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD", "INTERPN_HIP_CUBIC_RECORDS", "INTERPN_HIP_SWEEP_PROBE", "INTERPN_HIP_GATED_ITERS")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -35,7 +35,7 @@ def run_device(case, rng, dtype, fma=None):
         nobs = case.obs[0].size
         obs_t = []
         # (the sweep kernel takes 16-byte aligned streams only: mostly even element offsets when it is forced)
-        sweep = os.environ.get("INTERPN_HIP_SWEEP") == "1"
+        sweep = os.environ.get("INTERPN_HIP_SWEEP") in ("1", "2")
         for o in case.obs:
             off = int(rng.choice([0, 2, 0, 2, 1])) if sweep else int(rng.integers(0, 4))
             t = torch.empty(nobs + off, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
@@ -144,6 +144,18 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 env["INTERPN_HIP_BRICKS"] = "11"
                 env.pop("INTERPN_HIP_FORCE_GENERIC", None)
                 env.pop("INTERPN_HIP_BINNED", None)
+            # round 6: the device-side sample in front of the sweep kernels and the gated pair of launches behind it, on batches
+            # of any size from 16384 points (option sweep = 2), unordered or clustered in one cell (the sample's two verdicts)
+            clustered = False
+            if ((method == "linear" and N in (2, 3)) or (method == "nearest" and N in (2, 3) and kind == "regular") or (method == "cubic" and N == 2)) \
+                    and nobs >= 16384 and rng.random() < 0.5:
+                env["INTERPN_HIP_SWEEP"] = "2"
+                env["INTERPN_HIP_SWEEP_PROBE"] = str(int(rng.choice([1, 2])))
+                env["INTERPN_HIP_GATED_ITERS"] = str(int(rng.choice([0, 1, 3, 16, 64])))
+                env.pop("INTERPN_HIP_FORCE_GENERIC", None)
+                env.pop("INTERPN_HIP_BINNED", None)
+                if method == "cubic": env["INTERPN_HIP_BRICKS"] = "11"
+                clustered = bool(rng.random() < 0.5)
             # per-bucket records for 1-D multilinear-rectilinear, also on axes short enough for LDS
             if method == "linear" and kind == "rectilinear" and N == 1 and rng.random() < 0.5: env["INTERPN_HIP_BRICKS"] = "on"
             for k in KNOBS:
@@ -168,6 +180,13 @@ def run(budget: float, seed: int, max_cases: int = 0):
                     v[k:k + z.size] = z
                 with np.errstate(all="ignore"):
                     case.vals = v.astype(dtype)
+            if clustered:  # every point inside one cell (+ a few strays): neighbours share table lines, the one-pass kernel takes the batch
+                for d in range(N):
+                    g = case.grids[d].astype(np.float64)
+                    c = int(rng.integers(0, g.size - 1))
+                    keep = case.obs[d][::997].copy()
+                    case.obs[d][:] = rng.uniform(g[c], g[c + 1], nobs).astype(dtype)
+                    case.obs[d][::997] = keep
             if kind == "rectilinear" and rng.random() < 0.3:
                 # inject NaN / inf / huge coordinates: rectilinear never errors, results must still match
                 for _ in range(3):
