@@ -986,7 +986,9 @@ def worker(args):
                 # of the sweep launch sends coherent batches to the one-pass kernel; the host thins the samples out once they
                 # keep coming out unordered (policy 2), so most timed steps are ONE kernel, some are sample + sweep + gated launch
                 "auto_path_sample": {"policy": it.get_option("sweep_probe"),
-                                     "last_sampled_launch_took_one_pass_kernel": it.get_option("sweep_probe_took_brick")},
+                                     "unordered_verdicts_in_a_row": it.get_option("sweep_probe_streak"),
+                                     "note": "policy 2: a device-side sample in front of every automatic launch until three in a row "
+                                             "said 'unordered', then in front of every 16th; coherent batches go to the one-pass kernel"},
                 "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
                 "kernel_ms_min": round(float(np.min(m["step_ms"])), 4),
                 "kernel_ms_max": round(float(np.max(m["step_ms"])), 4),

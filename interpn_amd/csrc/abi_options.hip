@@ -170,6 +170,12 @@ int interpn_hip_get_option(const interpn_hip_interp* h, const char* name, long l
     }
     return INTERPN_HIP_OK;
   }
+  if (!strcmp(name, "sweep_probe_streak")) {  // read-only: samples in a row whose verdict was "unordered", as far as the host knows (thinned policy)
+    interpn_hip_interp* hm = const_cast<interpn_hip_interp*>(h);
+    std::lock_guard<std::mutex> lk(hm->bin_mu);
+    *value = hm->probe_streak;
+    return INTERPN_HIP_OK;
+  }
   if (!strcmp(name, "sweep_cell")) { *value = h->desc.sweep_bricks ? h->desc.sweep_cell : 0; return INTERPN_HIP_OK; }  // 0: 2 x 2 x KW bricks, 2: 2 x 4 x 4 (f32)
   if (!strcmp(name, "dev_pci")) {  // read-only: (domain << 16) | (bus << 8) | device of the GPU the handle lives on; -1 if unknown
     int dom = 0, bus = 0, dv = 0;
