@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration table (N = 1)")
     ap.add_argument("--no-ablate", action="store_true", help="skip the stream-only / gather-only ablation (N = 1)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--no-cfg5", action="store_true", help="N > 1: skip the second block on the 128^3 grid (BASELINE configs[4])")
     ap.add_argument("--sustain-seconds", type=float, default=0.5)
     ap.add_argument("--spinup-seconds", type=float, default=0.15,
@@ -493,6 +494,51 @@ def committed_traffic(kernel, points, grid, table_bytes):
         return None, (f"committed profile is for kernel={tj.get('kernel')!r} grid={tj.get('grid')} "
                       f"table_bytes={tj.get('table_bytes')}: does not match this run, not reported")
     return tj.get("hbm_bytes_per_launch"), tj.get("source", "profiles/traffic_latest.json")
+
+
+def live_traffic(kernel, n, points, timeout_s=150):
+    """Fabric-side bytes per launch of the headline kernel measured NOW: two child runs of the same workload under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: one counter per pass, kernel trace only, as MI355X_MICROARCH.md's HBM
+    section prescribes; FETCH_SIZE x 2 on gfx950 — the factor profiles/r06_calibration_pmc_*.csv re-measured at 1.99998 on
+    a stream kernel of known byte count).  After the timed region; any failure leaves the committed figure in place."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if any(k.startswith("ROCP") or k.startswith("ROCPROF") for k in os.environ):
+        return None, "this process itself runs under a profiler: no nested PMC passes"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    short = kernel.split("<")[0].split("::")[-1]
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="interpn_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp", INTERPN_BENCH_ROOT=ROOT)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "traffic_child.py"), str(n), str(points), "12"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and short + "<" in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 4:
+                return None, f"PMC pass {counter} failed (rc {r.returncode}, {len(vals)} rows): {r.stderr[-200:]!r}"
+            got[counter] = (float(np.mean(vals[2:])), len(vals) - 2)  # (the first launches: period calibration, the sample)
+    except Exception as e:  # timeout, missing tool, unreadable output ...
+        return None, "PMC passes failed: " + repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = got["FETCH_SIZE"][0] * 1024.0 * 2.0
+    wr = got["WRITE_SIZE"][0] * 1024.0
+    return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_averaged": got["FETCH_SIZE"][1],
+            "corrections": {"FETCH_SIZE": 2.0, "WRITE_SIZE": 1.0, "unit": "KiB"}}, \
+        "measured in this run: child processes of the same workload under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes)"
 
 
 def committed_config_traffic(row, spec):
@@ -1047,6 +1093,15 @@ def worker(args):
                 # the oracle here is the checker, never the thing measured on the GPU side
                 cb["gpu_matches_bitwise"] = bool(np.array_equal(out[:ncpu].cpu().numpy(), cpu_out))
                 rec["cpu_baseline"] = cb
+            if not args.no_live_traffic and workload == "cfg2" and not args.grid and P == 100_000_000:
+                lt, lsrc = live_traffic(kernel, n, P)
+                rec["roofline"]["traffic_live"] = {"result": lt, "how": lsrc}
+                if lt:
+                    rec["roofline"]["traffic_committed_profile"] = {"bytes_per_launch": rec["roofline"]["traffic"], "source": rec["roofline"]["traffic_source"]}
+                    rec["roofline"]["traffic"] = lt["bytes_per_launch"]
+                    rec["roofline"]["traffic_source"] = lsrc
+                    rec["roofline"]["traffic_measured_in_this_run"] = True
+                    rec["roofline"]["traffic_over_algorithmic"] = round(lt["bytes_per_launch"] / (P * bpp), 3)
             if not args.no_configs and P == 100_000_000:
                 rows = []
                 secs = args.sustain_seconds

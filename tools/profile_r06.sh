@@ -17,7 +17,7 @@ OUT="$R/gpurun_out/$PROF_TAG"
 rm -rf "$OUT" && mkdir -p "$OUT"
 PY=python3
 echo "A1"; date
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- $PY $R/bench.py --steps 20 --warmup 5 --no-configs --no-ablate --no-cpu-baseline > $OUT/stats_headline_bench.json 2> $OUT/stats_headline.err || echo "A1 failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- $PY $R/bench.py --steps 20 --warmup 5 --no-configs --no-ablate --no-cpu-baseline --no-live-traffic > $OUT/stats_headline_bench.json 2> $OUT/stats_headline.err || echo "A1 failed"
 echo "A2"; date
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PY $R/bench.py --steps 20 --warmup 5 > $OUT/stats_bench.json 2> $OUT/stats.err || echo "A2 failed"
 echo "B"; date
