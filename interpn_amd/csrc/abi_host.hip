@@ -216,6 +216,17 @@ int eval_host_impl(interpn_hip_interp* h, const void* const* obs, size_t nobs, v
 
 }  // namespace interpn_abi
 
+namespace {
+// The status word to the host by a one-lane kernel instead of a copy-engine transfer (round 6): ordered behind the evaluation
+// like any kernel on the stream, it stores the 8 bytes into the pinned word with ONE system-scope store (never torn), and
+// costs a dispatch (~4 us) where the 8-byte hipMemcpyAsync costs ~10.  What the host may conclude from seeing the word is
+// what it concluded from the copy: everything enqueued on the stream before it is complete on the device.
+__global__ void k_status_to_host(const unsigned long long* dev_word, unsigned long long* host_word) {
+  const unsigned long long v = __hip_atomic_load(dev_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
 extern "C" {
 
 int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_index) {
@@ -225,9 +236,23 @@ int interpn_hip_finish(interpn_hip_interp* h, void* stream, uint64_t* first_bad_
   hipStream_t s = static_cast<hipStream_t>(stream);
   // The status word lands in pinned memory: a plain DMA behind the kernel, no staging copy.
   std::lock_guard<std::mutex> lk(h->finish_mu);
-  if (!h->finish_word) HIP_TRY(pool_take_pinned_word(h->device, &h->finish_word));
+  if (!h->finish_word) {
+    HIP_TRY(pool_take_pinned_word(h->device, &h->finish_word));
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, h->finish_word, 0) == hipSuccess) h->finish_word_dev = static_cast<unsigned long long*>(dp);
+    else (void)hipGetLastError();
+  }
   *(volatile unsigned long long*)h->finish_word = kWordPending;
-  HIP_TRY(hipMemcpyAsync(h->finish_word, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool by_kernel = h->finish_word_dev && h->desc.cfg.finish_kernel != 0 &&
+                         hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+  if (by_kernel) {
+    hipLaunchKernelGGL(k_status_to_host, dim3(1), dim3(1), 0, s, (const unsigned long long*)h->first_bad, h->finish_word_dev);
+    HIP_TRY(hipGetLastError());
+  } else {
+    (void)hipGetLastError();
+    HIP_TRY(hipMemcpyAsync(h->finish_word, h->first_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(wait_status_word(s, h->finish_word));
   const unsigned long long word = *(volatile unsigned long long*)h->finish_word;
   if (word == kNoBadIndexHost) return INTERPN_HIP_OK;

@@ -105,6 +105,7 @@ struct interpn_hip_interp {
   void* sweep_owned = nullptr;     // 3-D f64 multilinear: the sweep evaluation's table when `bricks` is another layout (desc.sweep_bricks)
   unsigned long long* first_bad = nullptr;  // device word, ~0 = no failure
   unsigned long long* finish_word = nullptr;  // pinned landing word of interpn_hip_finish
+  unsigned long long* finish_word_dev = nullptr;  // ... as the device sees it (the status kernel's target), or null
   std::mutex finish_mu;
   std::mutex host_mu;  // host-pointer evaluations on one handle share its two lanes: serialised
   // Caller streams that device-pointer work was enqueued on, each with an event recorded behind

@@ -43,6 +43,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
       {"sweep_period", &c.sweep_period, 0, 1000000},
       {"sweep_probe", &c.sweep_probe, 0, 2},
       {"gated_iters", &c.gated_iters, 0, 4096},
+      {"finish_kernel", &c.finish_kernel, 0, 1},
   };
   if (!name || !value) return false;
   if (!strcmp(name, "host_chunk")) {
@@ -85,7 +86,7 @@ bool option_access(LaunchConfig& c, const char* name, long long* value, bool set
 void latch_env(LaunchConfig& c) {
   static const char* const names[] = {"blocks_per_cu", "iters_per_block", "ppl", "axis_regs", "force_generic",
                                       "generic_runtime", "generic_vec", "persistent", "axis_lds_kb", "host_chunk", "binned", "deal",
-                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble", "sweep", "sweep_period", "sweep_probe", "gated_iters"};
+                                      "bin_slice_log2", "column", "column_part", "column_threads", "column_groups", "column_cpp", "column_coef", "column_pad", "hist_wgs_per_cu", "column_keys", "column_tail", "scatter_staged", "axis_records", "bin_scramble", "sweep", "sweep_period", "sweep_probe", "gated_iters", "finish_kernel"};
   for (const char* nm : names) {
     char var[64] = "INTERPN_HIP_";
     size_t k = strlen(var);
