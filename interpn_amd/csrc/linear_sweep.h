@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
   unsigned long long st_mark = t_begin, st_other = 0, st_rows = 0;
   unsigned st_rot = 0;
   unsigned my_rounds = 0;
+  __builtin_amdgcn_s_setprio(2);  // (see the rows below)
   unsigned ticket = take(shard);
   while (true) {
     unsigned rr = __builtin_amdgcn_readfirstlane(ticket);
@@ -275,6 +276,11 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
     wave_sync();
     // -- K rows in sorted order
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
+    // Wave priority (round 6): the rows — a chain of gathers the wave mostly waits in — run at priority 0, everything around
+    // them (result exchange and stores, ticket, coordinate loads, sort) at 2: a wave that has finished its rows gets its
+    // stores out and its next round's loads under way ahead of the SIMD's other waves' row arithmetic (cfg2 -1 %, cfg3 -2 %,
+    // the 128^3 shard -1 %: tools/ab_sweep.py; priority during the loads alone, or raised during the rows: nothing).
+    __builtin_amdgcn_s_setprio(0);
     T res[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -395,6 +401,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       asm volatile("" : "+v"(res[k]));
     }
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
+    __builtin_amdgcn_s_setprio(2);
     // -- results back into the points' own order through LDS
 #pragma unroll
     for (int k = 0; k < KT; ++k) row[(src[k / 2] >> (16 * (k & 1))) & 0xFFFFu] = res[k];

@@ -128,6 +128,7 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
   unsigned long long st_mark = t_begin, st_other = 0, st_rows = 0;
   unsigned st_rot = 0;
   unsigned my_rounds = 0;
+  __builtin_amdgcn_s_setprio(2);  // wave priority: 2 around the rows, 0 inside them (linear_sweep.h has the measurements)
   unsigned ticket = take(shard);
   while (true) {
     unsigned rr = __builtin_amdgcn_readfirstlane(ticket);
@@ -246,6 +247,7 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
     for (int k2 = 0; k2 < KT / 2; ++k2) src[k2] = (unsigned)row16[(2 * k2) * 64 + ln] | ((unsigned)row16[(2 * k2 + 1) * 64 + ln] << 16);
     wave_sync();
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_other += now - st_mark; st_mark = now; st_rot = rot; }
+    __builtin_amdgcn_s_setprio(0);
     T res[KT];
     sweep_static_for<0, KT>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -258,6 +260,7 @@ __device__ __forceinline__ void sweep_rounds(const SweepRounds<T, N>& sr, unsign
       asm volatile("" : "+v"(res[k]));
     });
     if constexpr (STAMPS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); st_rows += now - st_mark; st_mark = now; }
+    __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int k = 0; k < KT; ++k) row[(src[k / 2] >> (16 * (k & 1))) & 0xFFFFu] = res[k];
     wave_sync();
