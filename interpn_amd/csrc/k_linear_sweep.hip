@@ -74,7 +74,12 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if (g.method == kCubic) return cubic_sweep_applies(g, npts);  // 3-D multicubic: cubic_sweep.h
   if (g.method == kLinear && g.ndims == 2) return linear2_sweep_applies(g, npts);  // 2-D multilinear: k_linear2_brick.hip
   if (!g.sweep_bricks || g.cfg.sweep == 0 || g.cfg.force_generic) return 0;
-  if (g.sweep_table_bytes >= (1ull << 32)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
+  if (g.sweep_table_bytes >= (1ull << 32)) return 0;
+  // the rows' index arithmetic is 24-bit (linear_brick.h::brick_line_bytes24, div_small): axes shorter than 2^20, fewer than
+  // 2^24 (i, j) bricks and bricks along k — true of every table under 4 GiB that is not a needle
+  for (int d = 0; d < 3; ++d)
+    if (g.n[d] >= (1 << 20)) return 0;
+  if ((unsigned long long)g.sweep_nb[0] * g.sweep_nb[1] >= (1ull << 24) || g.sweep_nb[2] >= (1u << 24)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
   const size_t lds = g.kind == kRectilinear
                          ? (size_t)SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWorkgroup + kSweepAxisLds

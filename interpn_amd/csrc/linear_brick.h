@@ -75,6 +75,52 @@ __device__ __forceinline__ unsigned brick_piece(unsigned nbj, unsigned nbk, int 
   return ((unsigned)(bi * (int)nbj + bj) * nbk) * (unsigned)BrickGeom<T, CELL>::ELEMS + (unsigned)((oi * 2 + oj) * KW) + kpart;
 }
 
+// x / D for a small constant D and x < 2^20, without the quarter-rate integer multiplies a division by a constant compiles
+// to: (x + 0.5) / D lies at least 0.5 / D from every integer, the f32 evaluation of x * (1 / D) + 0.5 / D errs by less than
+// 2^20 / D * 2^-23 < 0.05 (x and the fma exact up to one rounding, the two constants 2^-24 relative), so truncation gives
+// floor(x / D).  Three full-rate instructions.
+template <int D>
+__device__ __forceinline__ unsigned div_small(unsigned x) {
+  static_assert(D >= 2 && D <= 7, "0.5 / D must stay clear of the error bound");
+  return (unsigned)__builtin_fmaf((float)x, 1.0f / (float)D, 0.5f / (float)D);
+}
+
+// Byte offset of piece (0, 0) of cell (i, j, k) in the ONE-LINE-PER-CELL layouts (steps 1,1: 2 x 2 x KW bricks, or the
+// f32 2 x 4 x 4 bricks) — brick_piece<T, 1, 1, CELL>(nbj, nbk, i, j, bk * ELEMS + (k - bk * SK), 0, 0) * sizeof(T) with
+// 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate, where v_mul_lo_u32, v_mul_hi_u32 and v_mad_u64_u32 run at a
+// quarter of it: four of them per row were 16 of a sweep row's ~115 issue slots).  The host takes the sweep kernels only
+// where i * nbj + j, nbk < 2^24 and every axis is shorter than 2^20 (k_linear_sweep.hip::sweep_applies).
+// a * b + c on 24-bit operands, b wave-uniform (the compiler, left to itself, turns mul24 + add back into v_mad_u64_u32)
+__device__ __forceinline__ unsigned mad24_vsv(unsigned a, unsigned b_uniform, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+// c - a * D for a small constant D (v_mad_i32_i24 with an inline constant)
+template <int D>
+__device__ __forceinline__ unsigned msub24_const(unsigned a, unsigned c) {
+  static_assert(D >= 1 && D <= 16, "inline constant");
+  unsigned r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(-D), "v"(c));
+  return r;
+}
+
+template <typename T, int CELL>
+__device__ __forceinline__ unsigned brick_line_bytes24(unsigned nbj, unsigned nbk, int i, int j, int k) {
+  typedef BrickGeom<T, CELL> G;
+  const unsigned bk = div_small<G::SK>((unsigned)k);
+  const unsigned kin = msub24_const<G::SK>(bk, (unsigned)k);  // k - bk * SK
+  if constexpr (CELL == 2) {  // rows (oi, oj) of 4 elements; j stepped 3
+    const unsigned bj3 = div_small<3>((unsigned)j);
+    const unsigned oj3 = msub24_const<3>(bj3, (unsigned)j);
+    const unsigned line = mad24_vsv(mad24_vsv((unsigned)i, nbj, bj3), nbk, bk);
+    return (line * 32u + oj3 * 4u + kin) * (unsigned)sizeof(T);
+  } else {
+    const unsigned line = mad24_vsv(mad24_vsv((unsigned)i, nbj, (unsigned)j), nbk, bk);
+    return (line * (unsigned)G::ELEMS + kin) * (unsigned)sizeof(T);
+  }
+}
+
 #ifndef INTERPN_PIECE_ROW
 #define INTERPN_PIECE_ROW 5
 #endif

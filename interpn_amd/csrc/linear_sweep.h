@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         // Lane q of a quad loads piece q of the quad's points 0..3: their offsets come across the quad by DPP
         // (no LDS round trip in the row's dependent chain), and 32-bit byte offsets beside the table's base
         // keep the address arithmetic off the vector unit (the host takes this kernel for tables under 4 GiB only).
-        const unsigned mine_b = brick_piece<T, SI, SJ, CELL>(a.nbj, a.nbk, loc[0], loc[1], bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK), 0, 0) * (unsigned)sizeof(T);
+        const unsigned mine_b = brick_line_bytes24<T, CELL>(a.nbj, a.nbk, loc[0], loc[1], loc[2]);  // (full-rate integer arithmetic: linear_brick.h)
         const unsigned char* const tb = reinterpret_cast<const unsigned char*>(a.bricks);
         const unsigned mypiece = (CELL == 2 ? ((q >> 1) * 4u + (q & 1u)) * 4u : q * (unsigned)Geom::KW) * (unsigned)sizeof(T);
         P pc[4];
