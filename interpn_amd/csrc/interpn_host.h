@@ -53,7 +53,7 @@ struct LaunchConfig {
   int bin_slice_log2 = 25; // binned evaluation: log2 of the points sorted and evaluated per slice (bounds a scratch block)
   int sweep = -1;          // 3-D f64 multilinear, device-pointer evaluation: the sweep kernel (linear_sweep.h) -1 where it pays, 0 never, 1 whenever the handle has its table
   int finish_kernel = 1;   // interpn_hip_finish: the status word reaches the host by a one-lane kernel (0: by an 8-byte copy, as before round 6)
-  int gated_iters = 16;    // rows of 256 lanes per workgroup of the gated brick launch behind an automatic sweep launch (an empty workgroup costs dispatch time)
+  int gated_iters = 4;     // rows of 256 lanes per workgroup of the gated brick launch behind an automatic sweep launch (an empty workgroup costs dispatch time)
   int sweep_probe = 2;     // automatic sweep launches: sample the batch on the device first and let the one-pass kernel take coherent batches — 0: never (the sweep kernel whatever the points look like), 1: every launch, 2: every launch until three samples in a row came out unordered, then every 16th (abi_sweep.hip)
   // (sweep itself: -1 automatic, 0 never, 1 always, 2 always with the sample deciding between the two kernels)
   int sweep_period = 0;    // sweep evaluation: ticks of 10 ns per sweep of the leading index (0: what the previous launch measured; 1: no clock, rows in sorted order; tests / tuning)

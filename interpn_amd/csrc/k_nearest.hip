@@ -214,7 +214,9 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   unsigned blocks = ((g.kind == kRegular || axr) && !g.cfg.persistent) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1))
                                                                       : grid_blocks(npts, ppl, g.cfg);
   a.gate = g.launch_gate;
-  // few, fat workgroups: mostly they return at once (half the brick kernels' factor: at 16 this kernel loses 5 % on the lattices it is for)
+  // fewer, fatter workgroups: mostly they return at once (option gated_iters: 4 — lattices walked along the table's slowest
+  // dimension lose with fatter ones, 16: -11 %, while those along its fastest gain little beyond 4: tools/gated_iters_lattices.py)
+  // (this kernel: half that factor — 128^3 on a lattice 0.566 ms at 2, 0.59 at 4, 0.61 at 8)
   if (a.gate && g.cfg.gated_iters > 3) blocks = (blocks + (unsigned)(g.cfg.gated_iters / 2) - 1) / (unsigned)(g.cfg.gated_iters / 2);
 #define GO2(RECT, FMA, AXR, PPL) do { g.tag.set("k_nearest", {N, RECT, FMA, AXR, PPL}, 0b00110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA, AXR, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
 #define GO(RECT, FMA, AXR) do { if (ppl == 2) GO2(RECT, FMA, AXR, 2); else GO2(RECT, FMA, AXR, 1); } while (0)
