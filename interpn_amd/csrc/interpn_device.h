@@ -197,6 +197,37 @@ __device__ __forceinline__ StepCell<double> step_cell_fast(double x, double star
   return r;
 }
 
+// The two halves of step_cell_fast on their own (linear_sweep.h: the cell — what the gather's address needs — in front of
+// the loads, the quotient — what only the lerps need — behind them): identical operations, identical bits.
+template <typename T>
+struct StepCellIndex {
+  T a;       // the dividend x - izl
+  int loc;
+  bool exact;
+};
+template <bool FMA>
+__device__ __forceinline__ StepCellIndex<double> step_cell_index(double x, double start, double step, double rstep, int dimmax) {
+  StepCellIndex<double> r;
+  const double qt = (x - start) * rstep;
+  const double d = __builtin_amdgcn_fract(qt);
+  r.exact = (__builtin_fabs(d - 0.5) < 0.5 - 0x1p-20) && (__builtin_fabs(qt) < 0x1p31);
+  int li = (int)qt;
+  li = li > 0 ? li : 0;
+  li = li < dimmax ? li : dimmax;
+  r.loc = li;
+  const double izl = mul_add<FMA>(step, (double)li, start);
+  r.a = x - izl;
+  r.exact = r.exact && exponent_within_256(r.a);
+  return r;
+}
+__device__ __forceinline__ double step_cell_quotient(double a, double step, double rstep) {
+  const double q0 = a * rstep;
+  const double r0 = __builtin_fma(-step, q0, a);
+  const double q1 = __builtin_fma(r0, rstep, q0);
+  const double r1 = __builtin_fma(-step, q1, a);
+  return __builtin_fma(r1, rstep, q1);
+}
+
 // f32: the same forms with p = 24.  Admitted: 2^-16 <= |step| <= 2^16 (host) and 2^-24 <= |x - izl| < 2^24 (per
 // point): quotients in (2^-41, 2^41), remainders multiples of 2^(-16 - 23 - 41 - 23) — normal numbers.  The
 // cell index: RN(a0 rb) lies within 2^-22.4 |a0 / b| of RN(a0 / b); the short form is kept while qt is further
@@ -227,6 +258,30 @@ __device__ __forceinline__ StepCell<float> step_cell_fast(float x, float start, 
   const float r1 = __builtin_fmaf(-step, q1, a);
   r.t = __builtin_fmaf(r1, rstep, q1);
   return r;
+}
+
+template <bool FMA>
+__device__ __forceinline__ StepCellIndex<float> step_cell_index(float x, float start, float step, float rstep, int dimmax) {
+  StepCellIndex<float> r;
+  const float qt = (x - start) * rstep;
+  const float d = __builtin_amdgcn_fractf(qt);
+  const float margin = __builtin_fmaf(__builtin_fabsf(qt), 0x1p-21f, 0x1p-21f);
+  r.exact = __builtin_fabsf(d - 0.5f) + margin < 0.5f;
+  int li = (int)qt;
+  li = li > 0 ? li : 0;
+  li = li < dimmax ? li : dimmax;
+  r.loc = li;
+  const float izl = mul_add<FMA>(step, (float)li, start);
+  r.a = x - izl;
+  r.exact = r.exact && exponent_within_24(r.a);
+  return r;
+}
+__device__ __forceinline__ float step_cell_quotient(float a, float step, float rstep) {
+  const float q0 = a * rstep;
+  const float r0 = __builtin_fmaf(-step, q0, a);
+  const float q1 = __builtin_fmaf(r0, rstep, q0);
+  const float r1 = __builtin_fmaf(-step, q1, a);
+  return __builtin_fmaf(r1, rstep, q1);
 }
 
 // The two short forms on their own (cubic_sweep.h: the saturation class of a point needs floor(RN(a0 / b)) itself,

@@ -291,6 +291,8 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       for (int d = 0; d < 3; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + lane];
       T t[3];
       int loc[3];
+      T av[3] = {(T)0, (T)0, (T)0};  // regular grids: the dividends x - izl, their quotients taken behind the gather's loads
+      bool have_t = false;          // ... unless the wave took the divide sequences
       if constexpr (RECT && AXR == 4) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -318,13 +320,15 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
           exact = s.fastdiv != 0;
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
-            const StepCell<T> sc = step_cell_fast<FMA>(xr[d], a.start[d], a.step[d], s.rstep[d], a.n[d] - 2);
-            t[d] = sc.t;
+            // (step_cell_fast in two halves: the cell here, in front of the gather's loads; the quotient behind them)
+            const StepCellIndex<T> sc = step_cell_index<FMA>(xr[d], a.start[d], a.step[d], s.rstep[d], a.n[d] - 2);
+            av[d] = sc.a;
             loc[d] = sc.loc;
             exact = exact && sc.exact;
           }
         }
-        if (__any(!exact)) {  // a lane on a grid plane, far outside the grid, not finite ...: the reference's operations as they stand, for the wave
+        if (__any(!exact)) {
+          have_t = true;  // a lane on a grid plane, far outside the grid, not finite ...: the reference's operations as they stand, for the wave
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
             T floc;
@@ -363,6 +367,14 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         pc[1] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x55, 0xF, 0xF, true) + mypiece));
         pc[2] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xAA, 0xF, 0xF, true) + mypiece));
         pc[3] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xFF, 0xF, 0xF, true) + mypiece));
+        if constexpr (!RECT && ABL != 3) {  // t: only the lerps need it — under the loads' latency (cfg2 -0.5 %)
+          __builtin_amdgcn_sched_barrier(0);
+          if (!have_t) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = step_cell_quotient(av[d], a.step[d], s.rstep[d]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds_piece[(quad * 4 + r) * kPieceRow + q] = pc[r];
         wave_sync();
@@ -374,6 +386,12 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         }
         wave_sync();
       } else {
+        if constexpr (!RECT && ABL != 3) {  // (the other layouts and the no-table measurement build: the quotients in front)
+          if (!have_t) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = step_cell_quotient(av[d], a.step[d], s.rstep[d]);
+          }
+        }
         const unsigned kpart = bk * (unsigned)Geom::ELEMS + ((unsigned)loc[2] - bk * (unsigned)SK);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
