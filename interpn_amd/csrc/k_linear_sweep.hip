@@ -26,8 +26,13 @@ constexpr int kSweepParkedRect = INTERPN_SWEEP_RECT_PARKED;  // rectilinear grid
 constexpr int kSweepRowsF32 = INTERPN_SWEEP_F32_ROWS;    // f32: half the registers per point
 constexpr int kSweepThreads = 768;   // one workgroup per CU
 constexpr int kSweepRowsF32Rect = 20;  // ... less the registers of the cell search (24 rows spill 6-29 VGPRs there)
-template <typename T, bool RECT = false> constexpr int sweep_rows() { return sizeof(T) == 8 ? (RECT ? INTERPN_SWEEP_RECT_ROWS : kSweepRows) : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
-template <typename T, bool RECT = false> constexpr int sweep_parked() { return sizeof(T) == 8 ? (RECT ? kSweepParkedRect : kSweepParked) : (RECT ? 0 : INTERPN_SWEEP_F32_PARKED); }
+#ifndef INTERPN_SWEEP_LANES_ROWS   // f64 rectilinear with the axes in lanes (AXR 1..3): rows in registers + parked (the same 14 rows per round)
+#define INTERPN_SWEEP_LANES_ROWS INTERPN_SWEEP_RECT_ROWS
+#define INTERPN_SWEEP_LANES_PARKED INTERPN_SWEEP_RECT_PARKED
+#endif
+static_assert(INTERPN_SWEEP_LANES_ROWS + INTERPN_SWEEP_LANES_PARKED == INTERPN_SWEEP_RECT_ROWS + INTERPN_SWEEP_RECT_PARKED, "one round size per grid kind");
+template <typename T, bool RECT = false, int AXR = 0> constexpr int sweep_rows() { return sizeof(T) == 8 ? (RECT ? (AXR >= 1 && AXR <= 3 ? INTERPN_SWEEP_LANES_ROWS : INTERPN_SWEEP_RECT_ROWS) : kSweepRows) : (RECT ? kSweepRowsF32Rect : kSweepRowsF32); }
+template <typename T, bool RECT = false, int AXR = 0> constexpr int sweep_parked() { return sizeof(T) == 8 ? (RECT ? (AXR >= 1 && AXR <= 3 ? INTERPN_SWEEP_LANES_PARKED : kSweepParkedRect) : kSweepParked) : (RECT ? 0 : INTERPN_SWEEP_F32_PARKED); }
 // points the chip holds at a time, per CU (the sweep's window, linear_sweep.h)
 constexpr size_t kSweepPointsPerCu = (size_t)(kSweepRows + kSweepParked) * kSweepThreads;
 constexpr size_t kSweepPointsPerCuF32 = (size_t)(kSweepRowsF32 + INTERPN_SWEEP_F32_PARKED) * kSweepThreads;
@@ -82,7 +87,9 @@ int sweep_applies(const GridDesc& g, size_t npts) {
   if ((unsigned long long)g.sweep_nb[0] * g.sweep_nb[1] >= (1ull << 24) || g.sweep_nb[2] >= (1u << 24)) return 0;  // the kernel addresses the table with 32-bit byte offsets (and a table that size is re-used by nobody)
   // the workgroup's LDS (its waves' regions, + the axis image budget on rectilinear grids) must exist on this device
   const size_t lds = g.kind == kRectilinear
-                         ? (size_t)SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWorkgroup + kSweepAxisLds
+                         ? (lane_axes_mode(g) != 0  // axes in lanes: no axis image in LDS
+                                ? (size_t)SweepLds<double, INTERPN_SWEEP_LANES_ROWS, INTERPN_SWEEP_LANES_PARKED>::kWave * (kSweepThreads / 64) + SweepLds<double, INTERPN_SWEEP_LANES_ROWS, INTERPN_SWEEP_LANES_PARKED>::kWorkgroup
+                                : (size_t)SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWave * (kSweepThreads / 64) + SweepLds<double, INTERPN_SWEEP_RECT_ROWS, kSweepParkedRect>::kWorkgroup + kSweepAxisLds)
                          : (size_t)SweepLds<double, kSweepRows, kSweepParked>::kWave * (kSweepThreads / 64) + SweepLds<double, kSweepRows, kSweepParked>::kWorkgroup;  // (the f32 shapes need no more)
   if ((long long)lds > g.cfg.lds_per_cu) return 0;
   if (g.cfg.sweep > 0) return 2;
@@ -104,7 +111,7 @@ int sweep_applies(const GridDesc& g, size_t npts) {
 
 template <typename T, bool RECT, bool FMA, int SI, int SJ, int AXR, int CELL = 0>
 static hipError_t go(const GridDesc& g, const SweepArgs<T>& s, unsigned blocks, hipStream_t stream) {
-  constexpr int K = sweep_rows<T, RECT>(), KL = sweep_parked<T, RECT>(), TH = kSweepThreads;
+  constexpr int K = sweep_rows<T, RECT, AXR>(), KL = sweep_parked<T, RECT, AXR>(), TH = kSweepThreads;
   auto kern = k_linear_sweep<T, RECT, FMA, SI, SJ, K, TH, AXR, false, CELL, KL>;
   const size_t lds = (size_t)SweepLds<T, K, KL>::kWave * (TH / 64) + SweepLds<T, K, KL>::kWorkgroup + ((RECT && AXR == 4 && s.b.ax.use_lds) ? (size_t)s.b.ax.image_bytes : 0);
   static std::atomic<unsigned long long> opted{0};  // bit per device

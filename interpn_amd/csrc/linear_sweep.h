@@ -289,9 +289,16 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
       T xr[3];  // this row's point: from the registers, or from where the sort parked it
 #pragma unroll
       for (int d = 0; d < 3; ++d) xr[d] = k < K ? x[k < K ? k : 0][d] : park[(d * KL + (k - K)) * 64 + lane];
+      // rectilinear grids: t's divisions behind the gather's loads (f32 64^3 0.65 -> 0.63 ms) — except f64 with the axes in
+      // lanes, where the six more registers live across the loads spill (cfg3 +2.5 %: tools/ab_sweep.py)
+#ifndef INTERPN_SWEEP_LANES_LATE
+#define INTERPN_SWEEP_LANES_LATE 0
+#endif
+      constexpr bool RECT_T_LATE = RECT && (sizeof(T) == 4 || AXR == 4 || INTERPN_SWEEP_LANES_LATE);
       T t[3];
       int loc[3];
-      T av[3] = {(T)0, (T)0, (T)0};  // regular grids: the dividends x - izl, their quotients taken behind the gather's loads
+      T av[3] = {(T)0, (T)0, (T)0};  // the dividends of t (regular: x - izl; rectilinear: x - x0), the quotients taken behind the gather's loads
+      T bv[3] = {(T)1, (T)1, (T)1};  // rectilinear: the divisors x1 - x0
       bool have_t = false;          // ... unless the wave took the divide sequences
       if constexpr (RECT && AXR == 4) {
 #pragma unroll
@@ -299,7 +306,8 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
           const Axis<T> ax = make_axis<T, 3>(a.ax, axis_base, d);
           T x0, x1;
           loc[d] = axis_cell<T>(ax, xr[d], &x0, &x1);   // multilinear/rectilinear.rs:353-370, :310-311
-          t[d] = (xr[d] - x0) / (x1 - x0);              // rectilinear.rs:310-313
+          av[d] = xr[d] - x0;                           // rectilinear.rs:310-313: t = (x - x0) / (x1 - x0), the division
+          bv[d] = x1 - x0;                              // behind the gather's loads
         }
       } else if constexpr (RECT) {
         T xin[1][3], x0_r[1][3], x1_r[1][3];
@@ -309,7 +317,9 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         lane_axes_locate<T, 3, 1, AXR>(a.ax, la, xin, cell_r, x0_r, x1_r);  // multilinear/rectilinear.rs:353-370
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          t[d] = (xr[d] - x0_r[0][d]) / (x1_r[0][d] - x0_r[0][d]);        // rectilinear.rs:310-313
+          av[d] = xr[d] - x0_r[0][d];            // rectilinear.rs:310-313: t = (x - x0) / (x1 - x0), the division
+          bv[d] = x1_r[0][d] - x0_r[0][d];       // behind the gather's loads where the registers allow (RECT_T_LATE)
+          if constexpr (!RECT_T_LATE) t[d] = av[d] / bv[d];
           loc[d] = cell_r[0][d];
         }
       } else {
@@ -367,6 +377,12 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         pc[1] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0x55, 0xF, 0xF, true) + mypiece));
         pc[2] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xAA, 0xF, 0xF, true) + mypiece));
         pc[3] = *reinterpret_cast<const P*>(tb + ((unsigned)__builtin_amdgcn_mov_dpp((int)mine_b, 0xFF, 0xF, 0xF, true) + mypiece));
+        if constexpr (RECT && RECT_T_LATE) {  // t: only the lerps need it — the three divide sequences under the loads' latency
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) t[d] = av[d] / bv[d];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (!RECT && ABL != 3) {  // t: only the lerps need it — under the loads' latency (cfg2 -0.5 %)
           __builtin_amdgcn_sched_barrier(0);
           if (!have_t) {
@@ -386,6 +402,10 @@ __global__ void __launch_bounds__(THREADS) k_linear_sweep(const SweepArgs<T> s) 
         }
         wave_sync();
       } else {
+        if constexpr (RECT && RECT_T_LATE) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) t[d] = av[d] / bv[d];
+        }
         if constexpr (!RECT && ABL != 3) {  // (the other layouts and the no-table measurement build: the quotients in front)
           if (!have_t) {
 #pragma unroll
