@@ -171,11 +171,22 @@ def time_launches(torch, it, obs, out, launches=0, seconds=0.0, finish_each=Fals
         if len(pending) >= 64 or finish_each:
             if not finish_each:
                 it.finish()
-            ms += [x.elapsed_time(y) for x, y in pending]
+            ms += _elapsed(pending)
             pending = []
     it.finish()
-    ms += [x.elapsed_time(y) for x, y in pending]
+    ms += _elapsed(pending)
     return ms
+
+
+def _elapsed(pairs):
+    """Event times of completed launches.  `finish()` has seen the status word, so the GPU is done with everything in front
+    of it — but the runtime's own record of an event may lag that by microseconds (seen once with the status word
+    delivered by a kernel): waiting on the (already passed) end event costs nothing and makes the read safe."""
+    out = []
+    for x, y in pairs:
+        y.synchronize()
+        out.append(x.elapsed_time(y))
+    return out
 
 
 def oracle_eval(spec, sub):

@@ -15,7 +15,7 @@ def t(it, obs, out, reps=15):
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); ts.append(a.elapsed_time(b))
+        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); b.synchronize(); ts.append(a.elapsed_time(b))
     return round(float(np.median(ts)), 4)
 res = {}
 for name, method, dims, P, dtype in (("near3_128", "nearest", [128] * 3, 100_000_000, np.float64), ("near2_1000", "nearest", [1000, 1000], 100_000_000, np.float64),

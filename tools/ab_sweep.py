@@ -16,7 +16,7 @@ def t(it, obs, out, reps=30):
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); ts.append(a.elapsed_time(b))
+        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); b.synchronize(); ts.append(a.elapsed_time(b))
     return round(float(np.median(ts)), 4)
 res = {}
 for name, n, rect, dtype in (("cfg2", 64, False, np.float64), ("cfg3", 64, True, np.float64), ("cfg5s", 128, False, np.float64), ("f32_64", 64, False, np.float32), ("f32_rect64", 64, True, np.float32), ("rect80", 80, True, np.float64)):

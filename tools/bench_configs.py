@@ -58,6 +58,7 @@ def run(name, method, kind, n_axis, ndims, P, linearize=False, dtype=np.float64,
         it.eval_tensors(obs, out)
         b.record()
         it.finish()
+        b.synchronize()
         ms.append(a.elapsed_time(b))
     ms.sort()
     med = ms[len(ms) // 2]

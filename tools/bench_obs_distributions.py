@@ -78,7 +78,7 @@ def time_it(it, obs, out, reps=9):
             it.finish()
         except AssertionError:
             pass
-        ts.append(a.elapsed_time(b))
+        b.synchronize(); ts.append(a.elapsed_time(b))
     return float(np.median(ts))
 
 

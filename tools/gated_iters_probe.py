@@ -13,7 +13,7 @@ def t(it, obs, out, reps=15):
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); ts.append(a.elapsed_time(b))
+        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); b.synchronize(); ts.append(a.elapsed_time(b))
     return round(float(np.median(ts)), 4)
 for method, dims, P in (("nearest", [128] * 3, 100_000_000), ("nearest", [1000, 1000], 100_000_000), ("linear", [1000, 1000], 100_000_000), ("cubic", [512, 512], 30_000_000), ("linear", [64] * 3, 100_000_000)):
     nd = len(dims)

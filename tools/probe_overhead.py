@@ -21,7 +21,7 @@ def t(obs, reps=40):
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); ts.append(a.elapsed_time(b))
+        a.record(); it.eval_tensors(obs, out); b.record(); it.finish(); b.synchronize(); ts.append(a.elapsed_time(b))
     return round(float(np.median(ts)), 4)
 for probe, iters in ((0, 8), (1, 1), (1, 4), (1, 8), (1, 16), (1, 64), (0, 8)):
     it.set_option("sweep", -1); it.set_option("sweep_probe", probe); it.set_option("gated_iters", iters)

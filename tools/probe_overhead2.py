@@ -17,7 +17,7 @@ def t(reps=50):
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); it.eval_tensors(rnd, out); b.record(); it.finish(); ts.append(a.elapsed_time(b))
+        a.record(); it.eval_tensors(rnd, out); b.record(); it.finish(); b.synchronize(); ts.append(a.elapsed_time(b))
     return float(np.median(ts))
 it.set_option("sweep", -1)
 res = {0: [], 1: [], 2: []}
