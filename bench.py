@@ -279,6 +279,37 @@ L2_HIT_LINES_PER_S = 2.7e11  # 128 channels x 1 line per clock (DESIGN.md sectio
 L2_MISS_LINES_PER_S = 5.5e10  # random 128-B lines from the Infinity Cache / HBM (tools/tune_sector)
 
 
+def coherent_batch_row(torch, it, out, dev, P, bpp):
+    """The headline handle on a batch that is coherent as it stands — re-gridding onto a 464^3 lattice, last dimension
+    fastest — through the automatic path: the device-side sample in front of the launch sends it to the one-pass kernel
+    (DESIGN.md section 4.4).  Kernel ms of the automatic launch (sample + the kernel that ran + the one that returned at
+    once), of the sweep kernel forced onto the same batch, and whether both leave the same bits."""
+    m = 464
+    ax = torch.linspace(-1.0, 1.0, m, dtype=torch.float64, device=dev)
+    lat = []
+    for t in torch.meshgrid(ax, ax, ax, indexing="ij"):
+        f = t.reshape(-1)
+        lat.append(torch.cat([f, f[:P - m ** 3]]).contiguous())
+        del f
+    try:
+        it.set_option("sweep", 1)
+        forced = float(np.mean(time_launches(torch, it, lat, out, seconds=0.1)))
+        keep = out.clone()
+        it.set_option("sweep", -1)
+        it.set_option("sweep_probe", 1)  # (a sample in front of every launch: this handle's history is of unordered batches)
+        auto = float(np.mean(time_launches(torch, it, lat, out, seconds=0.15)))
+        took = it.get_option("sweep_probe_took_brick")
+        same = bool(torch.equal(out, keep))
+        del keep
+    finally:
+        it.set_option("sweep", -1)
+        it.set_option("sweep_probe", 2)
+    return {"batch": f"{m}^3 lattice over the grid's extent, last dimension fastest, {P:.0e} points",
+            "automatic_ms": round(auto, 4), "sweep_kernel_forced_ms": round(forced, 4),
+            "device_sample_chose_one_pass_kernel": took == 1, "bitwise_equal_to_sweep_kernel": same,
+            "automatic_frac": round(P * bpp / (auto * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
 def configs_summary(rows):
     """Per configuration: kernel ms, roofline fraction, bitwise check against the oracle, fabric traffic over algorithmic."""
     out = []
@@ -1104,6 +1135,11 @@ def worker(args):
                 # the oracle here is the checker, never the thing measured on the GPU side
                 cb["gpu_matches_bitwise"] = bool(np.array_equal(out[:ncpu].cpu().numpy(), cpu_out))
                 rec["cpu_baseline"] = cb
+            if not args.no_configs and workload == "cfg2" and not args.grid and P == 100_000_000:
+                try:
+                    rec["roofline"]["coherent_batch"] = coherent_batch_row(torch, it, out, dev, P, bpp)
+                except Exception as e:  # a side measurement must never take the record down
+                    rec["roofline"]["coherent_batch"] = {"error": repr(e)}
             if not args.no_live_traffic and workload == "cfg2" and not args.grid and P == 100_000_000:
                 lt, lsrc = live_traffic(kernel, n, P)
                 rec["roofline"]["traffic_live"] = {"result": lt, "how": lsrc}
