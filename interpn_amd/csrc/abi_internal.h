@@ -169,6 +169,7 @@ struct interpn_hip_interp {
   unsigned* probe_host_dev = nullptr;
   unsigned probe_seq = 0, probe_seen = 0;
   int probe_streak = 0;     // samples in a row that came out unordered
+  int probe_streak_coherent = 0;  // ... that came out coherent
   int probe_skipped = 0;    // automatic launches since the last sample
   const void* last_probe_word = nullptr;  // device word holding the verdict of the most recent gated launch's sampling kernel (option "sweep_probe_took_brick"; tests, bench)
 };

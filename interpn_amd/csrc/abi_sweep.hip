@@ -39,6 +39,7 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
   bool probe = sweep_probe_applies(g) && npoints >= 256u * 64u;
   unsigned* host_word = nullptr;
   unsigned seq = 0;
+  bool one_pass_only = false;
   if (probe && g.cfg.sweep_probe == 2) {
     // Thinned-out sampling: a handle whose last three samples all said "unordered" is sampled on every 16th automatic
     // launch only (the sample and the gated launch behind the sweep kernel cost ~1.5 % of a 1e8-point launch); one
@@ -60,10 +61,15 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
       if ((w >> 1) != h->probe_seen && (w >> 1) != 0) {
         h->probe_seen = w >> 1;
         h->probe_streak = (w & 1u) ? 0 : h->probe_streak + 1;
+        h->probe_streak_coherent = (w & 1u) ? h->probe_streak_coherent + 1 : 0;
       }
       if (h->probe_streak >= 3 && h->probe_skipped < 15) {
         ++h->probe_skipped;
         probe = false;
+      } else if (h->probe_streak_coherent >= 3 && h->probe_skipped < 15) {
+        ++h->probe_skipped;  // ... and the mirror image: the last three samples all said "coherent" — the one-pass kernel alone
+        probe = false;
+        one_pass_only = true;
       } else {
         h->probe_skipped = 0;
         h->probe_seq = h->probe_seq >= 0x7FFFFFFEu ? 1u : h->probe_seq + 1u;
@@ -73,7 +79,14 @@ int eval_device_sweep(interpn_hip_interp* h, const void* const* obs, void* out, 
     }
   }
   if (probe && err == hipSuccess) err = launch_sweep_probe(g, obs, npoints, slot->scratch, stream, host_word, seq);
-  if (err == hipSuccess) {
+  if (one_pass_only) {
+    if (err == hipSuccess) {
+      GridDesc gb = g;
+      gb.launch_fat = true;  // (the workgroup shape of the gated launch: what coherent batches run best in)
+      err = launch_any(gb, obs, out, npoints, h->first_bad, stream);
+      g.tag = gb.tag;
+    }
+  } else if (err == hipSuccess) {
     if (probe) {
       GridDesc gs = g;
       gs.sweep_gated = true;

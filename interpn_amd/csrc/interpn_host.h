@@ -83,6 +83,7 @@ struct GridDesc {
   // sample's verdict word in device memory (k_linear_sweep.hip::k_sweep_probe).
   const unsigned* launch_gate = nullptr;  // one-pass kernels: do nothing unless this word is non-zero (few, fat workgroups)
   bool sweep_gated = false;               // sweep kernels: do nothing if the scratch block's verdict word is set
+  bool launch_fat = false;                // one-pass kernels: the gated launch's workgroup shape without a gate (a handle whose last samples all said "coherent")
   int method = kLinear;
   int kind = kRegular;
   int dtype = kF64;

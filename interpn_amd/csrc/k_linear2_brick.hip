@@ -303,7 +303,7 @@ hipError_t launch_linear2_brick(const GridDesc& g, const T* const* obs, T* out, 
   const int ppl = (aligned && g.cfg.ppl != 1) ? 2 : 1;
   unsigned blocks = (g.kind == kRegular || axr) ? one_pass_blocks(npts, ppl * (axr ? 4 : 1)) : grid_blocks(npts, ppl, g.cfg);
   a.gate = g.launch_gate;
-  if (a.gate && g.cfg.gated_iters > 1) blocks = (blocks + (unsigned)g.cfg.gated_iters - 1) / (unsigned)g.cfg.gated_iters;  // few, fat workgroups: mostly they return at once
+  if ((a.gate || g.launch_fat) && g.cfg.gated_iters > 1) blocks = (blocks + (unsigned)g.cfg.gated_iters - 1) / (unsigned)g.cfg.gated_iters;  // few, fat workgroups: mostly they return at once
 #define GO2(RECT, FMA, AXR, PPL) do { g.tag.set("k_linear2_brick", {RECT, FMA, AXR, PPL}, 0b0011u); hipLaunchKernelGGL((k_linear2_brick<T, RECT, FMA, AXR, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
 #define GO(RECT, FMA, AXR) do { if (ppl == 2) GO2(RECT, FMA, AXR, 2); else GO2(RECT, FMA, AXR, 1); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }

@@ -130,7 +130,7 @@ static hipError_t launch_kind(const GridDesc& g, BrickArgs<T, N>& a, size_t lds,
   const int axr = lane_axes_mode(g);  // axes in lanes (lane_axes.h) or 0 = LDS / L2 search
   a.iters = brick_iters(g, npts, PPL, /*setup=*/g.kind != kRectilinear ? 0 : (axr == 0 ? 2 : 1));
   // a gated launch mostly returns at once (unordered points: the sweep kernel has the batch): few, fat workgroups
-  if (a.gate && g.cfg.gated_iters > 0 && a.iters < (unsigned)g.cfg.gated_iters) a.iters = (unsigned)g.cfg.gated_iters;
+  if ((a.gate || g.launch_fat) && g.cfg.gated_iters > 0 && a.iters < (unsigned)g.cfg.gated_iters) a.iters = (unsigned)g.cfg.gated_iters;
   const size_t nslots = (npts + PPL - 1) / PPL;
   const size_t per_block = (size_t)kBlock * a.iters;
   const unsigned blocks = (unsigned)((nslots + per_block - 1) / per_block);

@@ -217,7 +217,7 @@ static hipError_t launch_n(const GridDesc& g, const T* const* obs, T* out, size_
   // fewer, fatter workgroups: mostly they return at once (option gated_iters: 4 — lattices walked along the table's slowest
   // dimension lose with fatter ones, 16: -11 %, while those along its fastest gain little beyond 4: tools/gated_iters_lattices.py)
   // (this kernel: half that factor — 128^3 on a lattice 0.566 ms at 2, 0.59 at 4, 0.61 at 8)
-  if (a.gate && g.cfg.gated_iters > 3) blocks = (blocks + (unsigned)(g.cfg.gated_iters / 2) - 1) / (unsigned)(g.cfg.gated_iters / 2);
+  if ((a.gate || g.launch_fat) && g.cfg.gated_iters > 3) blocks = (blocks + (unsigned)(g.cfg.gated_iters / 2) - 1) / (unsigned)(g.cfg.gated_iters / 2);
 #define GO2(RECT, FMA, AXR, PPL) do { g.tag.set("k_nearest", {N, RECT, FMA, AXR, PPL}, 0b00110u); hipLaunchKernelGGL((k_nearest<T, N, RECT, FMA, AXR, PPL>), dim3(blocks), dim3(kBlock), lds, stream, a); } while (0)
 #define GO(RECT, FMA, AXR) do { if (ppl == 2) GO2(RECT, FMA, AXR, 2); else GO2(RECT, FMA, AXR, 1); } while (0)
   if (g.kind == kRegular) { if (g.fma) GO(false, true, 0); else GO(false, false, 0); }

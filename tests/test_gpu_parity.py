@@ -3245,6 +3245,17 @@ def test_automatic_path_thins_the_samples_out(oracle):
             seen.append(it.get_option("sweep_probe_took_brick"))
         assert 1 in seen[:17], seen
         first = seen.index(1)
-        assert all(v == 1 for v in seen[first + 2:]), seen
+        # ... and after three coherent samples in a row the mirror image: the one-pass kernel alone, sampled every 16th launch
+        assert set(seen[first + 2:]) <= {1, -1}, seen
+        assert seen[first + 2:].count(-1) >= 10 and 1 in seen[first + 8:], seen
+        names = []
+        for _ in range(20):  # unordered again: within 16 launches a sample says so and the sweep kernel is back
+            out = it.eval_tensors(rnd)
+            it.finish()
+            assert it.last_path == "sweep" and torch.equal(out, want_rnd)
+            seen.append(it.get_option("sweep_probe_took_brick"))
+            names.append(it.kernel_name())
+        assert 0 in seen[-20:-3], seen
+        assert names[-1].startswith("interpn::k_linear_sweep"), names
     finally:
         it.close()
