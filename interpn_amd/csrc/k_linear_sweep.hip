@@ -1,6 +1,8 @@
 // Host side of the sweep evaluation of 3-D multilinear batches (linear_sweep.h): when it applies,
 // which table it runs on, and the launcher.
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 #include "linear_sweep.h"
 
@@ -63,6 +65,9 @@ bool sweep_layout(const GridDesc& g, int* si, int* sj, int* cell) {
   if (g.dtype == kF32) {  // f32: the 2 x 4 x 4 bricks (one line per cell at 3.56x the grid; linear_brick.h CELL == 2)
     *si = 1; *sj = 1; *cell = 2;
     return true;
+  }
+  if (const char* env = getenv("INTERPN_HIP_SWEEP_LAYOUT")) {  // tuning / tests: "11" or "12"
+    if (!strcmp(env, "11") || !strcmp(env, "12")) { *si = 1; *sj = env[1] - '0'; return true; }
   }
   const size_t window = kSweepPointsPerCu * (size_t)(g.cfg.num_cus > 0 ? g.cfg.num_cus : 256) * 85 / 100;  // ~ the share of a round spent in rows
   const size_t l11 = brick_lines(g, 1, 1), l12 = brick_lines(g, 1, 2);
