@@ -75,7 +75,9 @@
  *                                       multicubic: f64 regular grids from 8 rounds per wave ~ 2.2e7 points), never,
  *                                       or whenever the handle has the table (creation: 0 also skips building it);
  *                                       INTERPN_HIP_SWEEP_PERIOD=n ticks of 10 ns per sweep (0 = what the previous launch
- *                                       measured, 1 = no clock)
+ *                                       measured, 1 = no clock); INTERPN_HIP_SWEEP_LAYOUT=11|12 (creation only, 3-D f64
+ *                                       multilinear: the sweep kernel's table with one line per cell / 1.5 lines per cell at half
+ *                                       the size; default: by the table's size against the points an XCD holds per sweep)
  *       INTERPN_HIP_BIN_SLICE_LOG2=n    log2 of the points sorted per slice (16..27, default 25): bounds a scratch block
  *       INTERPN_HIP_AXIS_RECORDS=0      rectilinear multilinear: search with coordinates + tables, not per-bucket records
  *       INTERPN_HIP_CUBIC_RECORDS=n     rectilinear multicubic (creation only): per-cell records of the axes (cubic_cell_record.h: a

@@ -13,7 +13,7 @@ from tests.helpers import run_hip_raw, run_oracle, synthetic_case
 KNOBS = ("INTERPN_HIP_BRICKS", "INTERPN_HIP_PPL", "INTERPN_HIP_FORCE_GENERIC", "INTERPN_HIP_GENERIC_RUNTIME",
          "INTERPN_HIP_HOST_CHUNK", "INTERPN_HIP_ITERS_PER_BLOCK", "INTERPN_HIP_AXIS_REGS", "INTERPN_HIP_GENERIC_VEC", "INTERPN_HIP_PERSISTENT",
          "INTERPN_HIP_BINNED", "INTERPN_HIP_DEAL", "INTERPN_HIP_COLUMN", "INTERPN_HIP_COLUMN_THREADS", "INTERPN_HIP_COLUMN_PART",
-         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD", "INTERPN_HIP_CUBIC_RECORDS", "INTERPN_HIP_SWEEP_PROBE", "INTERPN_HIP_GATED_ITERS")
+         "INTERPN_HIP_COLUMN_GROUPS", "INTERPN_HIP_COLUMN_CPP", "INTERPN_HIP_COLUMN_COEF", "INTERPN_HIP_COLUMN_PAD", "INTERPN_HIP_COLUMN_TAIL", "INTERPN_HIP_COLUMN_KEYS", "INTERPN_HIP_SCATTER_STAGED", "INTERPN_HIP_BIN_SCRAMBLE", "INTERPN_HIP_AXIS_RECORDS", "INTERPN_HIP_BIN_SLICE_LOG2", "INTERPN_HIP_SWEEP", "INTERPN_HIP_SWEEP_PERIOD", "INTERPN_HIP_CUBIC_RECORDS", "INTERPN_HIP_SWEEP_PROBE", "INTERPN_HIP_GATED_ITERS", "INTERPN_HIP_SWEEP_LAYOUT")
 LAYOUTS_LIN = [None, "off", "11", "12", "22", "c4"]
 LAYOUTS_CUB = [None, "off", "44", "24", "22", "14", "11"]
 
@@ -134,6 +134,7 @@ def run(budget: float, seed: int, max_cases: int = 0):
                 env["INTERPN_HIP_SWEEP"] = "1"
                 env["INTERPN_HIP_SWEEP_PERIOD"] = str(int(rng.choice([0, 0, 1, 300, 2500])))
                 env.pop("INTERPN_HIP_FORCE_GENERIC", None)
+                if rng.random() < 0.4: env["INTERPN_HIP_SWEEP_LAYOUT"] = str(rng.choice(["11", "12"]))  # (round 6: either table, whatever the grid's size)
             if kind == "rectilinear" and rng.random() < 0.3: env["INTERPN_HIP_AXIS_RECORDS"] = "0"
             # round 5, last session: rectilinear multicubic with / without the per-cell records of the axes (or a bound they
             # exceed), and 2-D / 3-D multicubic through the sweep kernel
